@@ -1,0 +1,232 @@
+/*
+ * mtsgpu.h -- C ABI of the MI355X path-tracing hot path (libmtsgpu.so).
+ *
+ * This is the drop-in boundary for Mitsuba 0.2.1's unidirectional path tracer
+ * (reference: src/integrators/path/path.cpp:47-216 driven by
+ * src/librender/integrator.cpp:131-170).  Everything that crosses it is a plain
+ * pointer, a size or a POD struct; no C++/torch types, no exceptions.
+ *
+ * Two clients bind exactly these entry points:
+ *   (1) the Mitsuba integrator plugin `gpupath`, which fills a
+ *       mtsgpu_scene from Scene/ShapeKDTree/TriMesh and overrides
+ *       Integrator::render() (include/mitsuba/render/integrator.h:57);
+ *   (2) the host-side mirror in mitsuba-renderer_amd/ (ctypes), used by tests/ and bench.py.
+ *
+ * All functions return 0 on success or a negative MTSGPU_E* code;
+ * mtsgpu_last_error() gives the text.  One ctx = one GPU = one host thread.
+ */
+#ifndef MTSGPU_H
+#define MTSGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTSGPU_ABI_VERSION 1
+
+enum {
+	MTSGPU_OK = 0,
+	MTSGPU_EINVAL = -1,   /* bad argument / inconsistent scene                  */
+	MTSGPU_EHIP = -2,     /* a HIP runtime call failed                          */
+	MTSGPU_ENODEV = -3,   /* no usable gfx950 device                            */
+	MTSGPU_ECANCEL = -4,  /* *cancel became non-zero (Integrator::cancel)       */
+	MTSGPU_ESTATE = -5    /* call sequence error (e.g. render before upload)    */
+};
+
+/* BSDF plugins on the path (src/bsdfs/{lambertian,dielectric,roughmetal,microfacet}.cpp) */
+enum {
+	MTSGPU_BSDF_LAMBERTIAN = 0, /* params: [0..2] reflectance                                  */
+	MTSGPU_BSDF_DIELECTRIC = 1, /* params: [0] intIOR [1] extIOR [2..4] specRefl [5..7] specTrans */
+	MTSGPU_BSDF_ROUGHMETAL = 2, /* params: [0] alphaB [1..3] ior [4..6] k [7..9] specRefl        */
+	MTSGPU_BSDF_MICROFACET = 3, /* params: [0] alphaB [1] kd [2] ks [3] intIOR [4] extIOR
+	                                       [5..7] diffuseRefl [8..10] specRefl                  */
+	MTSGPU_BSDF_NTYPES = 4
+};
+#define MTSGPU_BSDF_NPARAMS 16
+
+/* Luminaire plugins on the path (src/luminaires/{area,constant}.cpp) */
+enum {
+	MTSGPU_LUM_AREA = 0,     /* params: [0..2] intensity; shape = emitting TriMesh            */
+	MTSGPU_LUM_CONSTANT = 1  /* params: [0..2] intensity [3..5] bsphere centre [6] radius      */
+};
+#define MTSGPU_LUM_NPARAMS 8
+
+/* Sampler kinds.  *_KEYED are the per-(pixel,sample)-keyed forms of the two
+ * reference samplers (src/samplers/{independent,ldsampler}.cpp): identical
+ * integer code, with Random (MT19937-64) replaced by a keyed SplitMix64 stream
+ * so that samples are independent of traversal order. */
+enum {
+	MTSGPU_SAMPLER_INDEPENDENT_KEYED = 0,
+	MTSGPU_SAMPLER_LD_KEYED = 1
+};
+
+/* shape_flags bits */
+#define MTSGPU_SHAPE_HAS_NORMALS 1u  /* TriMesh has per-vertex normals (faceNormals=false) */
+
+/*
+ * Flattened scene.  This is what ShapeKDTree + TriMesh + BSDF/Luminaire
+ * parameter blocks look like once laid out for HBM (Appendix A of SURVEY.md).
+ *
+ * Primitive index space = concatenation of the shapes' triangles in
+ * ShapeKDTree::m_shapes order (src/librender/skdtree.cpp:43-65).
+ */
+typedef struct mtsgpu_scene {
+	uint32_t abi_version;        /* MTSGPU_ABI_VERSION                                        */
+
+	/* --- geometry (TriMesh storage, include/mitsuba/render/trimesh.h) --- */
+	uint32_t n_shapes, n_tris, n_verts;
+	const float    *vtx_pos;     /* [n_verts][3]                                              */
+	const float    *vtx_nrm;     /* [n_verts][3]; rows of shapes without normals are ignored  */
+	const uint32_t *tri_idx;     /* [n_tris][3] indices into the global vertex pool           */
+	const uint32_t *shape_tri_offset; /* [n_shapes+1] prefix sums (m_shapeMap)               */
+	const int32_t  *shape_bsdf;  /* [n_shapes] index into bsdf_* or -1 (not an occluder)      */
+	const int32_t  *shape_lum;   /* [n_shapes] index into lum_* or -1                         */
+	const uint32_t *shape_flags; /* [n_shapes] MTSGPU_SHAPE_*                                 */
+
+	/* --- SAH kd-tree (KDNode, include/mitsuba/render/gkdtree.h:442-470) ---
+	 * node = 2 x u32: inner {axis | relOffsetToLeft<<2, float split},
+	 *                 leaf  {1<<31 | primStart, primEnd}; children adjacent; root = 0 */
+	uint32_t n_nodes, n_indices;
+	const uint32_t *kd_nodes;    /* [n_nodes][2]                                              */
+	const uint32_t *kd_indices;  /* [n_indices] primitive ids                                 */
+	/* TriAccel, 12 x 4 B per primitive (include/mitsuba/render/triaccel.h:34-48) */
+	const uint32_t *triaccel;    /* [n_tris][12]                                              */
+	float aabb_min[3], aabb_max[3]; /* enlarged kd-tree AABB (gkdtree.h:1170-1176)          */
+
+	/* --- BSDF parameter blocks --- */
+	uint32_t n_bsdfs;
+	const uint32_t *bsdf_type;   /* [n_bsdfs]                                                 */
+	const float    *bsdf_params; /* [n_bsdfs][MTSGPU_BSDF_NPARAMS]                            */
+
+	/* --- luminaires (Scene::m_luminaires order) --- */
+	uint32_t n_lums;
+	const uint32_t *lum_type;    /* [n_lums]                                                  */
+	const float    *lum_params;  /* [n_lums][MTSGPU_LUM_NPARAMS]                              */
+	const int32_t  *lum_shape;   /* [n_lums] emitting shape or -1                             */
+	const float    *lum_inv_area;/* [n_lums] TriMesh::m_invSurfaceArea (trimesh.cpp:283)      */
+	const uint32_t *lum_cdf_offset; /* [n_lums+1] into lum_tri_cdf; area: nTris+1 entries    */
+	const float    *lum_tri_cdf; /* per-emitter triangle area CDFs (trimesh.cpp:279-283)      */
+	const float    *lum_sel_cdf; /* [n_lums+1] Scene::m_luminairePDF cdf (scene.cpp:320-330)  */
+	const float    *lum_sel_pdf; /* [n_lums]                                                  */
+	float lum_sel_sum;           /* DiscretePDF::getOriginalSum()                             */
+	int32_t background_lum;      /* index of the background luminaire or -1                   */
+} mtsgpu_scene;
+
+/* PerspectiveCameraImpl state (src/cameras/perspective.cpp:43-112) */
+typedef struct mtsgpu_camera {
+	float raster_to_camera[16]; /* row-major 4x4, m_rasterToCamera                            */
+	float camera_to_world[16];  /* row-major 4x4, m_cameraToWorld                             */
+	float near_clip, far_clip;  /* camera.cpp:121-123                                         */
+	int32_t width, height;      /* film size == crop size                                     */
+} mtsgpu_camera;
+
+/* Per-kernel-class counters/timings of the last render (measurement, section 8d) */
+typedef struct mtsgpu_stats {
+	uint64_t camera_samples;
+	uint64_t rays_closest, rays_shadow;
+	/* algorithmic work of the traversal kernels (only filled when counting is on) */
+	uint64_t n_inner, n_leaf, n_idx, n_tri_tested;
+	uint64_t trace_launches;
+	double trace_ms;     /* sum of HIP-event durations of all traversal launches        */
+	double shade_ms;     /* shade / generate / accumulate kernels                       */
+	double total_ms;     /* first launch -> last kernel end (device events)             */
+} mtsgpu_stats;
+
+typedef struct mtsgpu_ctx mtsgpu_ctx;
+
+/* --- lifecycle ----------------------------------------------------------- */
+int  mtsgpu_create(int device, mtsgpu_ctx **out);
+void mtsgpu_destroy(mtsgpu_ctx *ctx);
+const char *mtsgpu_last_error(const mtsgpu_ctx *ctx); /* ctx may be NULL: global */
+int  mtsgpu_abi_version(void);
+
+/* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL = own stream */
+int  mtsgpu_set_stream(mtsgpu_ctx *ctx, void *hip_stream);
+
+/* --- scene / integrator state (replaces Scene::initialize + plugin configure) */
+int  mtsgpu_upload_scene(mtsgpu_ctx *ctx, const mtsgpu_scene *scene);
+int  mtsgpu_set_camera(mtsgpu_ctx *ctx, const mtsgpu_camera *cam);
+/* MonteCarloIntegrator properties (src/librender/integrator.cpp:272-292) */
+int  mtsgpu_set_integrator(mtsgpu_ctx *ctx, int max_depth, int rr_depth, int strict_normals);
+/* Sampler (src/samplers/{independent,ldsampler}.cpp): kind, sampleCount (LD: rounded up to pow2), LD depth, seed */
+int  mtsgpu_set_sampler(mtsgpu_ctx *ctx, int kind, uint32_t spp, int ld_depth, uint64_t seed);
+/* ImageBlock sharding (src/librender/imageproc.cpp:43-78): this ctx renders the
+ * tiles t of the block_size^2 grid with (t % n_parts) == part. */
+int  mtsgpu_set_tiles(mtsgpu_ctx *ctx, int block_size, int part, int n_parts);
+/* Optional: render into a caller-owned device buffer [H][W][5] f32 (spec rgb, alpha, weight) */
+int  mtsgpu_set_film_buffer(mtsgpu_ctx *ctx, void *device_ptr);
+/* Tuning knobs (0 = default): paths in flight per pass; enable traversal counters */
+int  mtsgpu_set_options(mtsgpu_ctx *ctx, uint64_t max_paths, int count_traversal, int time_kernels);
+
+/* --- the hot path (replaces SampleIntegrator::render, integrator.cpp:87-120) */
+int  mtsgpu_render(mtsgpu_ctx *ctx, volatile const int *cancel);
+int  mtsgpu_sync(mtsgpu_ctx *ctx);
+/* Film::putImageBlock sums: host copy of [H][W][5] f32 */
+int  mtsgpu_read_film(mtsgpu_ctx *ctx, float *rgbaw);
+int  mtsgpu_clear_film(mtsgpu_ctx *ctx);
+int  mtsgpu_get_stats(mtsgpu_ctx *ctx, mtsgpu_stats *out);
+
+/* --- standalone kernels exposed for parity tests and the traversal benchmark */
+/* ShapeKDTree::rayIntersect(ray, its) / (ray) on n host rays.
+ * rays: [n][8] f32 = o.xyz, mint, d.xyz, maxt.   hits: [n][4] u32 = t(f32 bits), u, v, prim
+ * (prim = 0xFFFFFFFF on miss); shadow != 0 -> hits[i][3] = 1/0 occluded (src/librender/skdtree.cpp:108-199) */
+int  mtsgpu_trace_rays(mtsgpu_ctx *ctx, const float *rays, uint32_t n, int shadow, uint32_t *hits);
+/* LowDiscrepancySampler::generate() for one pixel key (keyed stream), tables as f32:
+ * out1d [depth][spp], out2d [depth][spp][2] */
+int  mtsgpu_ld_tables(mtsgpu_ctx *ctx, uint32_t pixel_key, float *out1d, float *out2d);
+/* MIPathTracer::Li for explicit camera samples: in [n][3] u32 = pixel x, y, sample index;
+ * out [n][8] f32 = Li rgb, alpha, raster x, raster y, depth, unused */
+int  mtsgpu_li_samples(mtsgpu_ctx *ctx, const uint32_t *pix_samples, uint32_t n, float *out);
+
+/* --- host-side flattening (what Scene::initialize does on the CPU) ---------
+ * Builds everything a mtsgpu_scene needs from plain meshes: vertex normals
+ * (trimesh.cpp:473-545), area CDFs, TriAccel table, SAH kd-tree (gkdtree.h). */
+typedef struct mtsgpu_mesh {
+	uint32_t n_verts, n_tris;
+	const float    *positions;  /* [n_verts][3]                                   */
+	const float    *normals;    /* [n_verts][3] or NULL                           */
+	const uint32_t *triangles;  /* [n_tris][3]                                    */
+	int32_t face_normals;       /* TriMesh 'faceNormals' property                 */
+	int32_t bsdf;               /* index or -1                                    */
+	int32_t lum;                /* index of the area luminaire attached, or -1    */
+} mtsgpu_mesh;
+
+typedef struct mtsgpu_scene_desc {
+	uint32_t n_meshes;
+	const mtsgpu_mesh *meshes;
+	uint32_t n_bsdfs;
+	const uint32_t *bsdf_type;
+	const float    *bsdf_params;
+	uint32_t n_lums;
+	const uint32_t *lum_type;    /* area luminaires must be referenced by exactly one mesh */
+	const float    *lum_params;  /* constant: only intensity needed, bsphere is computed   */
+	float camera_pos[3];         /* for ConstantLuminaire::preprocess (constant.cpp:49-63) */
+	int32_t has_camera;
+} mtsgpu_scene_desc;
+
+/* kd-tree build parameters (gkdtree.h:711-724 defaults when 0 / negative) */
+typedef struct mtsgpu_kd_params {
+	float traversal_cost, query_cost, empty_space_bonus;
+	int32_t stop_prims, max_bad_refines, exact_prim_threshold, max_depth, min_max_bins;
+	int32_t clip, retract, n_threads;
+} mtsgpu_kd_params;
+
+typedef struct mtsgpu_flat_scene mtsgpu_flat_scene; /* owns the arrays of a mtsgpu_scene */
+int  mtsgpu_flatten(const mtsgpu_scene_desc *desc, const mtsgpu_kd_params *kd, mtsgpu_flat_scene **out);
+const mtsgpu_scene *mtsgpu_flat_scene_get(const mtsgpu_flat_scene *fs);
+void mtsgpu_flat_scene_free(mtsgpu_flat_scene *fs);
+/* kd-tree statistics logged by the reference builder (gkdtree.h:1178-1213) */
+int  mtsgpu_flat_scene_kdstats(const mtsgpu_flat_scene *fs, double *out6 /* inner, leaf, idx, expTrav, expLeaves, expPrims */);
+
+/* PerspectiveCameraImpl::configure for a lookAt camera (perspective.cpp:43-71,
+ * transform.cpp:100-124,174-190).  fov in degrees along the smaller image side. */
+int  mtsgpu_make_camera(const float origin[3], const float target[3], const float up[3],
+                        float fov_deg, int width, int height, mtsgpu_camera *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTSGPU_H */

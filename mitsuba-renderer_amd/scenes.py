@@ -1,0 +1,257 @@
+"""Procedural scene descriptions for the configurations of SURVEY.md section 8(d).
+
+A description is what Mitsuba's XML loader would hand to Scene::addChild: plain
+triangle meshes (TriMesh ctor, include/mitsuba/render/trimesh.h:52-56), BSDF and
+luminaire property blocks and a lookAt camera.  Nothing here is on the hot path;
+flattening (normals, CDFs, TriAccel, kd-tree) happens in mtsgpu_flatten().
+All arithmetic is float32 so the arrays are identical on every host."""
+import ctypes as C
+import numpy as np
+from . import abi
+
+F = np.float32
+
+
+class MeshDesc:
+    def __init__(self, positions, triangles, bsdf=-1, lum=-1, face_normals=True, normals=None, name=""):
+        self.positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        self.triangles = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
+        self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        self.bsdf, self.lum, self.face_normals, self.name = int(bsdf), int(lum), bool(face_normals), name
+
+
+class SceneDescription:
+    """meshes + BSDF blocks + luminaires + camera (+ integrator defaults for the config)"""
+
+    def __init__(self, name):
+        self.name = name
+        self.meshes = []
+        self.bsdf_type = []
+        self.bsdf_params = []
+        self.lum_type = []
+        self.lum_params = []
+        self.camera = dict(origin=(0.0, 1.0, 3.4), target=(0.0, 1.0, 0.0), up=(0.0, 1.0, 0.0), fov=39.3)
+        self.max_depth = -1
+        self.rr_depth = 10
+
+    # --- property blocks --------------------------------------------------
+    def add_bsdf(self, btype, params):
+        p = np.zeros(abi.BSDF_NPARAMS, dtype=np.float32)
+        p[:len(params)] = np.asarray(params, dtype=np.float32)
+        self.bsdf_type.append(int(btype))
+        self.bsdf_params.append(p)
+        return len(self.bsdf_type) - 1
+
+    def lambertian(self, r, g=None, b=None):
+        g = r if g is None else g
+        b = r if b is None else b
+        return self.add_bsdf(abi.BSDF_LAMBERTIAN, [r, g, b])
+
+    def dielectric(self, int_ior=1.5046, ext_ior=1.0):
+        return self.add_bsdf(abi.BSDF_DIELECTRIC, [int_ior, ext_ior, 1, 1, 1, 1, 1, 1])
+
+    def roughmetal(self, alpha=0.1, ior=0.37, k=2.82):
+        return self.add_bsdf(abi.BSDF_ROUGHMETAL, [alpha, ior, ior, ior, k, k, k, 1, 1, 1])
+
+    def microfacet(self, alpha=0.1, kd=0.5, ks=0.5, int_ior=1.5, ext_ior=1.0, rd=1.0, rs=1.0):
+        return self.add_bsdf(abi.BSDF_MICROFACET, [alpha, kd, ks, int_ior, ext_ior, rd, rd, rd, rs, rs, rs])
+
+    def add_lum(self, ltype, intensity):
+        p = np.zeros(abi.LUM_NPARAMS, dtype=np.float32)
+        p[:3] = np.asarray(intensity, dtype=np.float32)
+        self.lum_type.append(int(ltype))
+        self.lum_params.append(p)
+        return len(self.lum_type) - 1
+
+    def add_mesh(self, *a, **k):
+        self.meshes.append(MeshDesc(*a, **k))
+        return self.meshes[-1]
+
+    @property
+    def n_tris(self):
+        return sum(m.triangles.shape[0] for m in self.meshes)
+
+    # --- ctypes view --------------------------------------------------------
+    def to_ctypes(self):
+        """-> (mtsgpu_scene_desc, keepalive list)"""
+        keep = []
+        meshes = (abi.Mesh * len(self.meshes))()
+        for i, m in enumerate(self.meshes):
+            keep += [m.positions, m.triangles, m.normals]
+            meshes[i].n_verts = m.positions.shape[0]
+            meshes[i].n_tris = m.triangles.shape[0]
+            meshes[i].positions = abi.ptr(m.positions, abi.f32p)
+            meshes[i].normals = abi.ptr(m.normals, abi.f32p)
+            meshes[i].triangles = abi.ptr(m.triangles, abi.u32p)
+            meshes[i].face_normals = 1 if m.face_normals else 0
+            meshes[i].bsdf = m.bsdf
+            meshes[i].lum = m.lum
+        bt = np.asarray(self.bsdf_type, dtype=np.uint32)
+        bp = np.ascontiguousarray(np.stack(self.bsdf_params) if self.bsdf_params else np.zeros((0, abi.BSDF_NPARAMS)), dtype=np.float32)
+        lt = np.asarray(self.lum_type, dtype=np.uint32)
+        lp = np.ascontiguousarray(np.stack(self.lum_params) if self.lum_params else np.zeros((0, abi.LUM_NPARAMS)), dtype=np.float32)
+        d = abi.SceneDesc()
+        d.n_meshes = len(self.meshes)
+        d.meshes = C.cast(meshes, C.POINTER(abi.Mesh))
+        d.n_bsdfs = len(bt)
+        d.bsdf_type = abi.ptr(bt, abi.u32p)
+        d.bsdf_params = abi.ptr(bp, abi.f32p)
+        d.n_lums = len(lt)
+        d.lum_type = abi.ptr(lt, abi.u32p)
+        d.lum_params = abi.ptr(lp, abi.f32p)
+        d.camera_pos = (C.c_float * 3)(*[float(v) for v in self.camera["origin"]])
+        d.has_camera = 1
+        keep += [meshes, bt, bp, lt, lp]
+        return d, keep
+
+
+# ---------------------------------------------------------------------------
+# geometry helpers
+# ---------------------------------------------------------------------------
+def _quad(p0, e1, e2, want_normal):
+    """two triangles covering p0 + s*e1 + t*e2, wound so that cross(p1-p0, p2-p0) points along want_normal"""
+    p0, e1, e2 = (np.asarray(v, dtype=np.float32) for v in (p0, e1, e2))
+    if np.dot(np.cross(e1, e2), np.asarray(want_normal, dtype=np.float32)) < 0:
+        e1, e2 = e2, e1
+    pos = np.stack([p0, p0 + e1, p0 + e1 + e2, p0 + e2]).astype(np.float32)
+    tri = np.array([[0, 1, 2], [0, 2, 3]], dtype=np.uint32)
+    return pos, tri
+
+
+def hash32(a, b, c, seed=1):
+    """fixed integer mixer (uint32 arithmetic), vectorised"""
+    with np.errstate(over="ignore"):
+        h = (np.asarray(a, dtype=np.uint32) * np.uint32(0x9E3779B1)
+             ^ np.asarray(b, dtype=np.uint32) * np.uint32(0x85EBCA77)
+             ^ np.asarray(c, dtype=np.uint32) * np.uint32(0xC2B2AE3D)
+             ^ np.uint32(seed) * np.uint32(0x27D4EB2F))
+        h ^= h >> np.uint32(15)
+        h *= np.uint32(0x2C1B3C6D)
+        h ^= h >> np.uint32(12)
+        h *= np.uint32(0x297A2D39)
+        h ^= h >> np.uint32(15)
+    return h
+
+
+def _grid_face(face_id, p0, e1, e2, normal, n, amp):
+    """n x n grid of cells x 2 triangles with unshared vertices; interior grid points are
+    displaced along `normal` by amp*(hash/2^32 - 0.5); border points stay put (watertight box)."""
+    p0, e1, e2, normal = (np.asarray(v, dtype=np.float32) for v in (p0, e1, e2, normal))
+    if np.dot(np.cross(e1, e2), normal) < 0:
+        e1, e2 = e2, e1
+    ii, jj = np.meshgrid(np.arange(n + 1, dtype=np.uint32), np.arange(n + 1, dtype=np.uint32), indexing="ij")
+    s = ii.astype(np.float32) / F(n)
+    t = jj.astype(np.float32) / F(n)
+    disp = (hash32(np.uint32(face_id), ii, jj).astype(np.float32) / F(4294967296.0) - F(0.5)) * F(amp)
+    border = (ii == 0) | (ii == n) | (jj == 0) | (jj == n)
+    disp = np.where(border, F(0), disp).astype(np.float32)
+    grid = (p0[None, None, :] + s[..., None] * e1[None, None, :] + t[..., None] * e2[None, None, :]
+            + disp[..., None] * normal[None, None, :]).astype(np.float32)
+    a = grid[:-1, :-1]; b = grid[1:, :-1]; c = grid[1:, 1:]; d = grid[:-1, 1:]
+    # two triangles per cell: (a, b, c), (a, c, d); 6 unshared vertices per cell
+    pos = np.stack([a, b, c, a, c, d], axis=2).reshape(-1, 3).astype(np.float32)
+    tri = np.arange(pos.shape[0], dtype=np.uint32).reshape(-1, 3)
+    return pos, tri
+
+
+def icosphere(subdiv, radius, centre):
+    """icosahedron subdivided `subdiv` times, shared vertices, outward winding"""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], dtype=np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2],
+                  [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5],
+                  [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], dtype=np.int64)
+    for _ in range(subdiv):
+        edges = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], axis=0)
+        es = np.sort(edges, axis=1)
+        uniq, inv = np.unique(es, axis=0, return_inverse=True)
+        mid = v[uniq[:, 0]] + v[uniq[:, 1]]
+        mid /= np.linalg.norm(mid, axis=1, keepdims=True)
+        base = v.shape[0]
+        v = np.concatenate([v, mid], axis=0)
+        nf = f.shape[0]
+        inv = inv.reshape(-1)
+        m01, m12, m20 = base + inv[:nf], base + inv[nf:2 * nf], base + inv[2 * nf:]
+        f = np.concatenate([
+            np.stack([f[:, 0], m01, m20], axis=1), np.stack([f[:, 1], m12, m01], axis=1),
+            np.stack([f[:, 2], m20, m12], axis=1), np.stack([m01, m12, m20], axis=1)], axis=0)
+    pos = (v * radius + np.asarray(centre, dtype=np.float64)[None, :]).astype(np.float32)
+    # make sure the winding is outward (cross(p1-p0, p2-p0) . (centroid - centre) > 0)
+    p = v[f]
+    n = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    flip = np.einsum("ij,ij->i", n, p.mean(axis=1)) < 0
+    f[flip] = f[flip][:, [0, 2, 1]]
+    return pos, f.astype(np.uint32)
+
+
+# ---------------------------------------------------------------------------
+# configurations
+# ---------------------------------------------------------------------------
+def _box_faces():
+    # (name, p0, e1, e2, inward normal)
+    return [
+        ("floor",   (-1, 0, -1), (2, 0, 0), (0, 0, 2), (0, 1, 0)),
+        ("ceiling", (-1, 2, -1), (2, 0, 0), (0, 0, 2), (0, -1, 0)),
+        ("back",    (-1, 0, -1), (2, 0, 0), (0, 2, 0), (0, 0, 1)),
+        ("left",    (-1, 0, -1), (0, 0, 2), (0, 2, 0), (1, 0, 0)),
+        ("right",   (1, 0, -1),  (0, 0, 2), (0, 2, 0), (-1, 0, 0)),
+    ]
+
+
+def _add_light(sd, intensity=15.0):
+    black = sd.lambertian(0.0)
+    lum = sd.add_lum(abi.LUM_AREA, [intensity] * 3)
+    pos, tri = _quad((-0.25, 1.99, -0.25), (0.5, 0, 0), (0, 0, 0.5), (0, -1, 0))
+    sd.add_mesh(pos, tri, bsdf=black, lum=lum, face_normals=True, name="light")
+
+
+def cornell_c1():
+    """C1/C2: 6 quads / 12 triangles, lambertian walls, one area luminaire"""
+    sd = SceneDescription("cornell_c1")
+    white = sd.lambertian(0.73)
+    red = sd.lambertian(0.63, 0.065, 0.05)
+    green = sd.lambertian(0.14, 0.45, 0.091)
+    for name, p0, e1, e2, nrm in _box_faces():
+        pos, tri = _quad(p0, e1, e2, nrm)
+        sd.add_mesh(pos, tri, bsdf={"left": red, "right": green}.get(name, white), face_normals=True, name=name)
+    _add_light(sd)
+    sd.max_depth = 4
+    return sd
+
+
+def cornell_c3(grid=320, sphere_subdiv=5):
+    """C3/C4: one displaced walls TriMesh (5 faces x grid^2 x 2 tris; 1 024 000 at grid=320),
+    a dielectric icosphere and the light quad"""
+    sd = SceneDescription("cornell_c3_g%d" % grid)
+    white = sd.lambertian(0.73)
+    glass = sd.dielectric(1.5046, 1.0)
+    ps, ts, base = [], [], 0
+    for fid, (name, p0, e1, e2, nrm) in enumerate(_box_faces()):
+        pos, tri = _grid_face(fid, p0, e1, e2, nrm, grid, 0.01)
+        ps.append(pos); ts.append(tri + np.uint32(base)); base += pos.shape[0]
+    sd.add_mesh(np.concatenate(ps), np.concatenate(ts), bsdf=white, face_normals=True, name="walls")
+    pos, tri = icosphere(sphere_subdiv, 0.4, (0.3, 0.4, 0.2))
+    sd.add_mesh(pos, tri, bsdf=glass, face_normals=False, name="glass")
+    _add_light(sd)
+    sd.max_depth = 16
+    return sd
+
+
+def cornell_c5(sphere_subdiv=4):
+    """C5: C1 box + four icospheres (lambertian, roughmetal, dielectric, microfacet) + constant env"""
+    sd = cornell_c1()
+    sd.name = "cornell_c5"
+    mats = [sd.lambertian(0.5), sd.roughmetal(), sd.dielectric(), sd.microfacet()]
+    centres = [(-0.5, 0.3, -0.4), (0.5, 0.3, -0.4), (-0.5, 0.3, 0.45), (0.5, 0.3, 0.45)]
+    for m, c in zip(mats, centres):
+        pos, tri = icosphere(sphere_subdiv, 0.3, c)
+        sd.add_mesh(pos, tri, bsdf=m, face_normals=False, name="sphere")
+    sd.add_lum(abi.LUM_CONSTANT, [1.0, 1.0, 1.0])
+    sd.max_depth = 32
+    return sd
+
+
+def by_name(name, **kw):
+    return {"c1": cornell_c1, "c3": cornell_c3, "c5": cornell_c5}[name](**kw)

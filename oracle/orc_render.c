@@ -1,0 +1,1097 @@
+/*
+ * orc_render.c -- oracle (TEST INFRASTRUCTURE ONLY): kd-tree traversal,
+ * intersection records, luminaire sampling, BSDFs, MIPathTracer::Li,
+ * SampleIntegrator::renderBlock and ImageBlock::putSample, restated in plain C.
+ */
+#include "orc_internal.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct { float o[3], d[3], dRcp[3], mint, maxt; } ray_t;
+
+typedef struct {
+	float t, p[3];
+	float geoS[3], geoT[3], geoN[3];
+	float shS[3], shT[3], shN[3];
+	float wi[3];
+	uint32_t shape, prim;   /* prim = global primitive id */
+} its_t;
+
+/* Ray(o, d, time): mint = Epsilon, maxt = inf, dRcp = 1/d (include/mitsuba/core/ray.h:63-74) */
+static void ray_init(ray_t *r, const float o[3], const float d[3]) {
+	for (int i = 0; i < 3; ++i) { r->o[i] = o[i]; r->d[i] = d[i]; r->dRcp[i] = (float) 1.0f / d[i]; }
+	r->mint = ORC_EPS; r->maxt = INFINITY;
+}
+
+/* AABB::rayIntersect (include/mitsuba/core/aabb.h:349-382) */
+static int aabb_ray_intersect(const float bmin[3], const float bmax[3], const ray_t *ray, float *nearT, float *farT) {
+	*nearT = -INFINITY; *farT = INFINITY;
+	for (int i = 0; i < 3; i++) {
+		const float direction = ray->d[i], origin = ray->o[i];
+		const float minVal = bmin[i], maxVal = bmax[i];
+		if (direction == 0) {
+			if (origin < minVal || origin > maxVal)
+				return 0;
+		} else {
+			float t1 = (minVal - origin) * ray->dRcp[i];
+			float t2 = (maxVal - origin) * ray->dRcp[i];
+			if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
+			*nearT = fmaxf_(*nearT, t1);
+			*farT = fminf_(*farT, t2);
+			if (*nearT > *farT)
+				return 0;
+		}
+	}
+	return 1;
+}
+
+typedef struct { uint32_t node; float t; uint32_t prev; float p[3]; } kdstack_t;
+#define KD_NULL 0xFFFFFFFFu
+#define KD_MAXDEPTH 48
+#define MAILBOX_SIZE 8   /* MTS_KD_MAILBOX_SIZE (sahkdtree3.h:28-29) */
+#define MAILBOX_MASK 7
+
+typedef struct { uint32_t shapeIndex, primIndex, prim; float u, v; } icache_t;
+
+/* rayIntersectHavran<shadowRay> (include/mitsuba/render/sahkdtree3.h:170-300) with
+ * ShapeKDTree::intersect (include/mitsuba/render/skdtree.h:244-336) inlined */
+static int havran(const mtsgpu_scene *sc, const ray_t *ray, float mint, float maxt, float *t,
+                  icache_t *cache, int shadowRay, orc_trace_counts *cnt) {
+	kdstack_t stack[KD_MAXDEPTH + 2];
+	uint32_t mailbox[MAILBOX_SIZE];
+	memset(mailbox, 0xFF, sizeof(mailbox));
+	uint32_t enPt = 0;
+	stack[enPt].t = mint;
+	for (int i = 0; i < 3; ++i) stack[enPt].p[i] = ray->o[i] + mint * ray->d[i];
+	uint32_t exPt = 1;
+	stack[exPt].t = maxt;
+	for (int i = 0; i < 3; ++i) stack[exPt].p[i] = ray->o[i] + maxt * ray->d[i];
+	stack[exPt].node = KD_NULL;
+
+	int foundIntersection = 0;
+	uint32_t currNode = 0;
+	while (currNode != KD_NULL) {
+		const uint32_t *n = sc->kd_nodes + 2 * (size_t) currNode;
+		while (!(n[0] & 0x80000000u)) {
+			float splitVal; memcpy(&splitVal, &n[1], 4);
+			const int axis = (int) (n[0] & 0x3);
+			const uint32_t left = currNode + ((n[0] & ~(0x3u + 0x40000000u)) >> 2);
+			uint32_t farChild;
+			if (cnt) cnt->n_inner++;
+			if (stack[enPt].p[axis] <= splitVal) {
+				if (stack[exPt].p[axis] <= splitVal) {
+					currNode = left; n = sc->kd_nodes + 2 * (size_t) currNode;
+					continue;
+				}
+				if (stack[enPt].p[axis] == splitVal) {
+					currNode = left + 1; n = sc->kd_nodes + 2 * (size_t) currNode;
+					continue;
+				}
+				currNode = left;
+				farChild = left + 1;
+			} else {
+				if (splitVal < stack[exPt].p[axis]) {
+					currNode = left + 1; n = sc->kd_nodes + 2 * (size_t) currNode;
+					continue;
+				}
+				farChild = left;
+				currNode = left + 1;
+			}
+			n = sc->kd_nodes + 2 * (size_t) currNode;
+			float distToSplit = (splitVal - ray->o[axis]) * ray->dRcp[axis];
+			const uint32_t tmp = exPt++;
+			if (exPt == enPt)
+				++exPt;
+			stack[exPt].prev = tmp;
+			stack[exPt].t = distToSplit;
+			stack[exPt].node = farChild;
+			for (int i = 0; i < 3; ++i) stack[exPt].p[i] = ray->o[i] + distToSplit * ray->d[i];
+			stack[exPt].p[axis] = splitVal;
+		}
+
+		if (cnt) cnt->n_leaf++;
+		for (uint32_t entry = n[0] & 0x7FFFFFFFu, last = n[1]; entry != last; entry++) {
+			const uint32_t primIdx = sc->kd_indices[entry];
+			if (cnt) cnt->n_idx++;
+			if (mailbox[primIdx & MAILBOX_MASK] == primIdx)
+				continue;
+			if (cnt) cnt->n_tri_tested++;
+			const uint32_t *ta = sc->triaccel + 12 * (size_t) primIdx;
+			float tempU, tempV, tempT;
+			int result;
+			if (!shadowRay) {
+				result = orc_triaccel_intersect(ta, ray->o, ray->d, mint, maxt, &tempU, &tempV, &tempT);
+				if (result) {
+					*t = tempT;
+					cache->shapeIndex = ta[10]; cache->primIndex = ta[11]; cache->prim = primIdx;
+					cache->u = tempU; cache->v = tempV;
+				}
+			} else {
+				/* shape->isOccluder() == has a BSDF (shape.h:324, shape.cpp:88-90) */
+				result = sc->shape_bsdf[ta[10]] >= 0 &&
+					orc_triaccel_intersect(ta, ray->o, ray->d, mint, maxt, &tempU, &tempV, &tempT);
+			}
+			if (result) {
+				if (shadowRay)
+					return 1;
+				maxt = *t;
+				foundIntersection = 1;
+			}
+			mailbox[primIdx & MAILBOX_MASK] = primIdx;
+		}
+
+		if (stack[exPt].t > maxt)
+			break;
+		enPt = exPt;
+		currNode = stack[exPt].node;
+		exPt = stack[enPt].prev;
+	}
+	return foundIntersection;
+}
+
+/* the common prologue of ShapeKDTree::rayIntersect (skdtree.cpp:108-123 / :180-192) */
+static int kd_clip(const mtsgpu_scene *sc, const ray_t *ray, int closest, float *mint, float *maxt) {
+	if (!aabb_ray_intersect(sc->aabb_min, sc->aabb_max, ray, mint, maxt))
+		return 0;
+	float rayMinT = ray->mint;
+	if (rayMinT == ORC_EPS) {
+		float m = fmaxf_(fmaxf_(fabsf(ray->o[0]), fabsf(ray->o[1])), fabsf(ray->o[2]));
+		if (closest)
+			m = fmaxf_(m, ORC_EPS);   /* only the (ray, its) variant has the inner max */
+		rayMinT *= m;
+	}
+	if (rayMinT > *mint) *mint = rayMinT;
+	if (ray->maxt < *maxt) *maxt = ray->maxt;
+	return *maxt > *mint;
+}
+
+/* fillIntersectionRecord<true> (include/mitsuba/render/skdtree.h:352-432) */
+static void fill_its(const mtsgpu_scene *sc, const ray_t *ray, const icache_t *cache, its_t *its) {
+	const uint32_t *tri = sc->tri_idx + 3 * (size_t) cache->prim;
+	const float b[3] = { 1 - cache->u - cache->v, cache->u, cache->v };
+	const float *p0 = sc->vtx_pos + 3 * (size_t) tri[0];
+	const float *p1 = sc->vtx_pos + 3 * (size_t) tri[1];
+	const float *p2 = sc->vtx_pos + 3 * (size_t) tri[2];
+	for (int i = 0; i < 3; ++i)
+		its->p[i] = p0[i] * b[0] + p1[i] * b[1] + p2[i] * b[2];
+	float e1[3], e2[3], faceNormal[3];
+	v3_sub(e1, p1, p0); v3_sub(e2, p2, p0);
+	v3_cross(faceNormal, e1, e2);
+	float length = v3_length(faceNormal);
+	if (!(faceNormal[0] == 0 && faceNormal[1] == 0 && faceNormal[2] == 0))
+		v3_div(faceNormal, faceNormal, length);
+	for (int i = 0; i < 3; ++i) its->geoN[i] = faceNormal[i];
+	orc_coordinate_system(its->geoN, its->geoS, its->geoT);
+	if (sc->shape_flags[cache->shapeIndex] & MTSGPU_SHAPE_HAS_NORMALS) {
+		const float *n0 = sc->vtx_nrm + 3 * (size_t) tri[0];
+		const float *n1 = sc->vtx_nrm + 3 * (size_t) tri[1];
+		const float *n2 = sc->vtx_nrm + 3 * (size_t) tri[2];
+		float n[3];
+		for (int i = 0; i < 3; ++i)
+			n[i] = n0[i] * b[0] + n1[i] * b[1] + n2[i] * b[2];
+		v3_normalize(its->shN, n);
+		orc_coordinate_system(its->shN, its->shS, its->shT);
+	} else {
+		for (int i = 0; i < 3; ++i) { its->shN[i] = its->geoN[i]; its->shS[i] = its->geoS[i]; its->shT[i] = its->geoT[i]; }
+	}
+	float md[3] = { -ray->d[0], -ray->d[1], -ray->d[2] };
+	its->wi[0] = v3_dot(md, its->shS); its->wi[1] = v3_dot(md, its->shT); its->wi[2] = v3_dot(md, its->shN);
+	its->shape = cache->shapeIndex;
+	its->prim = cache->prim;
+}
+
+/* ShapeKDTree::rayIntersect(ray, its) (skdtree.cpp:108-132) */
+static int scene_ray_intersect(const mtsgpu_scene *sc, const ray_t *ray, its_t *its, mtsgpu_stats *st) {
+	icache_t cache;
+	float mint, maxt;
+	its->t = INFINITY;
+	if (st) st->rays_closest++;
+	if (kd_clip(sc, ray, 1, &mint, &maxt)) {
+		if (havran(sc, ray, mint, maxt, &its->t, &cache, 0, NULL)) {
+			fill_its(sc, ray, &cache, its);
+			return 1;
+		}
+	}
+	return 0;
+}
+
+/* Scene::isOccluded (include/mitsuba/render/scene.h:241-246) -> ShapeKDTree::rayIntersect(ray) (skdtree.cpp:180-199) */
+static int scene_is_occluded(const mtsgpu_scene *sc, const float p1[3], const float p2[3], mtsgpu_stats *st) {
+	ray_t ray; float d[3], mint, maxt, t = INFINITY;
+	v3_sub(d, p2, p1);
+	ray_init(&ray, p1, d);
+	ray.mint = ORC_SHADOW_EPS;
+	ray.maxt = 1 - ORC_SHADOW_EPS;
+	if (st) st->rays_shadow++;
+	if (kd_clip(sc, &ray, 0, &mint, &maxt))
+		if (havran(sc, &ray, mint, maxt, &t, NULL, 1, NULL))
+			return 1;
+	return 0;
+}
+
+void orc_trace_rays(const mtsgpu_scene *sc, const float *rays, uint32_t n, int shadow,
+                    uint32_t *hits, orc_trace_counts *counts) {
+	if (counts) memset(counts, 0, sizeof(*counts));
+	for (uint32_t i = 0; i < n; ++i) {
+		const float *r = rays + 8 * (size_t) i;
+		ray_t ray;
+		ray_init(&ray, r, r + 4);
+		ray.mint = r[3]; ray.maxt = r[7];
+		uint32_t *h = hits + 4 * (size_t) i;
+		float mint, maxt, t = INFINITY;
+		icache_t cache; memset(&cache, 0, sizeof(cache));
+		int found = 0;
+		if (kd_clip(sc, &ray, !shadow, &mint, &maxt))
+			found = havran(sc, &ray, mint, maxt, &t, &cache, shadow, counts);
+		if (shadow) {
+			h[0] = h[1] = h[2] = 0; h[3] = found ? 1u : 0u;
+		} else if (found) {
+			memcpy(&h[0], &t, 4); memcpy(&h[1], &cache.u, 4); memcpy(&h[2], &cache.v, 4); h[3] = cache.prim;
+		} else {
+			float inf = INFINITY;
+			memcpy(&h[0], &inf, 4); h[1] = h[2] = 0; h[3] = 0xFFFFFFFFu;
+		}
+	}
+}
+
+/* ========================================================================== */
+/* DiscretePDF sampling (include/mitsuba/core/pdf.h:102-133)                  */
+/* ========================================================================== */
+static int dpdf_sample(const float *cdf, uint32_t n, float sampleValue) {
+	/* std::lower_bound over n+1 entries: first element >= sampleValue */
+	uint32_t lo = 0, count = n + 1;
+	while (count > 0) {
+		uint32_t step = count / 2, it = lo + step;
+		if (cdf[it] < sampleValue) { lo = it + 1; count -= step + 1; }
+		else count = step;
+	}
+	int index = (int) lo - 1;
+	if (index < 0) index = 0;
+	if (index > (int) n - 1) index = (int) n - 1;
+	return index;
+}
+static int dpdf_sample_reuse(const float *cdf, uint32_t n, float *sampleValue) {
+	int index = dpdf_sample(cdf, n, *sampleValue);
+	*sampleValue = (*sampleValue - cdf[index]) / (cdf[index + 1] - cdf[index]);
+	return index;
+}
+
+/* ========================================================================== */
+/* Luminaires                                                                 */
+/* ========================================================================== */
+typedef struct { float p[3], n[3], d[3], pdf, value[3]; int lum; } lrec_t;
+
+/* BSphere::rayIntersect (include/mitsuba/core/bsphere.h:85-118) */
+static int bsphere_ray_intersect(const float center[3], float radius, const float o[3], const float d[3],
+                                 float *nearHit, float *farHit) {
+	float originToCenter[3];
+	v3_sub(originToCenter, center, o);
+	float distToRayClosest = v3_dot(originToCenter, d);
+	float tmp1 = v3_dot(originToCenter, originToCenter) - radius*radius;
+	if (tmp1 <= 0.0f) {
+		*nearHit = *farHit = sqrtf(distToRayClosest * distToRayClosest - tmp1) + distToRayClosest;
+		return 1;
+	}
+	if (distToRayClosest < 0.0f)
+		return 0;
+	float sqrOriginToCenterLength = v3_dot(originToCenter, originToCenter);
+	float sqrHalfChordDist = radius * radius - sqrOriginToCenterLength + distToRayClosest * distToRayClosest;
+	if (sqrHalfChordDist < 0)
+		return 0;
+	float hitDistance = sqrtf(sqrHalfChordDist);
+	*nearHit = distToRayClosest - hitDistance;
+	*farHit = distToRayClosest + hitDistance;
+	if (*nearHit == 0)
+		*nearHit = *farHit;
+	return 1;
+}
+
+/* Luminaire::sample for the two plugins (src/luminaires/area.cpp:68-79, constant.cpp:73-87) */
+static void luminaire_sample(const mtsgpu_scene *sc, int l, const float p[3], lrec_t *lRec, const float sample[2]) {
+	const float *P = sc->lum_params + MTSGPU_LUM_NPARAMS * (size_t) l;
+	if (sc->lum_type[l] == MTSGPU_LUM_AREA) {
+		/* Shape::sampleSolidAngle (shape.cpp:65-75) -> TriMesh::sampleArea (trimesh.cpp:297-302) */
+		const uint32_t s = (uint32_t) sc->lum_shape[l];
+		const uint32_t t0 = sc->shape_tri_offset[s], nT = sc->shape_tri_offset[s+1] - t0;
+		float newSeed[2] = { sample[0], sample[1] };
+		int index = dpdf_sample_reuse(sc->lum_tri_cdf + sc->lum_cdf_offset[l], nT, &newSeed[1]);
+		/* Triangle::sample (src/libcore/triangle.cpp:23-47) */
+		const uint32_t *tri = sc->tri_idx + 3 * ((size_t) t0 + (uint32_t) index);
+		const float *p0 = sc->vtx_pos + 3 * (size_t) tri[0];
+		const float *p1 = sc->vtx_pos + 3 * (size_t) tri[1];
+		const float *p2 = sc->vtx_pos + 3 * (size_t) tri[2];
+		float bary[2], sideA[3], sideB[3];
+		orc_square_to_triangle(newSeed, bary);
+		v3_sub(sideA, p1, p0); v3_sub(sideB, p2, p0);
+		for (int i = 0; i < 3; ++i)
+			lRec->p[i] = p0[i] + (sideA[i] * bary[0]) + (sideB[i] * bary[1]);
+		if (sc->shape_flags[s] & MTSGPU_SHAPE_HAS_NORMALS) {
+			const float *n0 = sc->vtx_nrm + 3 * (size_t) tri[0];
+			const float *n1 = sc->vtx_nrm + 3 * (size_t) tri[1];
+			const float *n2 = sc->vtx_nrm + 3 * (size_t) tri[2];
+			float n[3];
+			for (int i = 0; i < 3; ++i)
+				n[i] = n0[i] * (1.0f - bary[0] - bary[1]) + n1[i] * bary[0] + n2[i] * bary[1];
+			v3_normalize(lRec->n, n);
+		} else {
+			float n[3];
+			v3_cross(n, sideA, sideB);
+			v3_normalize(lRec->n, n);
+		}
+		float pdfArea = sc->lum_inv_area[l];
+		float lumToPoint[3];
+		v3_sub(lumToPoint, p, lRec->p);
+		float distSquared = v3_dot(lumToPoint, lumToPoint), dp = v3_dot(lumToPoint, lRec->n);
+		if (dp > 0)
+			lRec->pdf = pdfArea * distSquared * sqrtf(distSquared) / dp;
+		else
+			lRec->pdf = 0.0f;
+		/* AreaLuminaire::sample (area.cpp:68-79) */
+		v3_sub(lRec->d, p, lRec->p);
+		if (lRec->pdf > 0 && v3_dot(lRec->d, lRec->n) > 0) {
+			lRec->value[0] = P[0]; lRec->value[1] = P[1]; lRec->value[2] = P[2];
+			v3_normalize(lRec->d, lRec->d);
+		} else {
+			lRec->pdf = 0;
+		}
+	} else {
+		/* ConstantLuminaire::sample (constant.cpp:73-87) */
+		float d[3], nearHit, farHit, dv[3];
+		orc_square_to_sphere(sample, d);
+		const float *center = P + 3; const float radius = P[6];
+		v3_sub(dv, p, center);
+		if (v3_length(dv) <= radius && bsphere_ray_intersect(center, radius, p, d, &nearHit, &farHit)) {
+			for (int i = 0; i < 3; ++i) lRec->p[i] = p[i] + d[i] * nearHit;
+			lRec->pdf = 1.0f / (4*ORC_PI);
+			float cn[3];
+			v3_sub(cn, center, lRec->p);
+			v3_normalize(lRec->n, cn);
+			lRec->d[0] = -d[0]; lRec->d[1] = -d[1]; lRec->d[2] = -d[2];
+			lRec->value[0] = P[0]; lRec->value[1] = P[1]; lRec->value[2] = P[2];
+		} else {
+			lRec->pdf = 0.0f;
+		}
+	}
+}
+
+/* Scene::sampleLuminaire (src/librender/scene.cpp:396-415) */
+static int scene_sample_luminaire(const mtsgpu_scene *sc, const float p[3], lrec_t *lRec, const float s[2], mtsgpu_stats *st) {
+	float sample[2] = { s[0], s[1] };
+	int index = dpdf_sample_reuse(sc->lum_sel_cdf, sc->n_lums, &sample[0]);
+	float lumPdf = sc->lum_sel_pdf[index];
+	luminaire_sample(sc, index, p, lRec, sample);
+	if (lRec->pdf != 0) {
+		if (scene_is_occluded(sc, p, lRec->p, st))
+			return 0;
+		lRec->pdf *= lumPdf;
+		float recip = 1.0f / lRec->pdf;
+		lRec->value[0] *= recip; lRec->value[1] *= recip; lRec->value[2] *= recip;
+		lRec->lum = index;
+		return 1;
+	}
+	return 0;
+}
+
+/* Scene::pdfLuminaire (scene.cpp:381-394) with Luminaire::pdf (area.cpp:81-83 ->
+ * Shape::pdfSolidAngle shape.cpp:77-83; constant.cpp:89-91) */
+static float scene_pdf_luminaire(const mtsgpu_scene *sc, const float p[3], const lrec_t *lRec) {
+	const float luminance = 1.0f;   /* getSamplingWeight(), luminaire.cpp:33 */
+	const float fraction = luminance / sc->lum_sel_sum;
+	float pdf;
+	if (sc->lum_type[lRec->lum] == MTSGPU_LUM_AREA) {
+		float lumToPoint[3];
+		v3_sub(lumToPoint, p, lRec->p);
+		float distSquared = v3_dot(lumToPoint, lumToPoint);
+		float invDP = fmaxf_((float) 0, sqrtf(distSquared) / v3_dot(lumToPoint, lRec->n));
+		pdf = sc->lum_inv_area[lRec->lum] * distSquared * invDP;
+	} else {
+		pdf = 1.0f / (4*ORC_PI);
+	}
+	return pdf * fraction;
+}
+
+/* AreaLuminaire::Le (area.cpp:62-66) */
+static void area_le(const mtsgpu_scene *sc, int l, const float n[3], const float d[3], float out[3]) {
+	const float *P = sc->lum_params + MTSGPU_LUM_NPARAMS * (size_t) l;
+	if (v3_dot(d, n) <= 0) { out[0] = out[1] = out[2] = 0.0f; return; }
+	out[0] = P[0]; out[1] = P[1]; out[2] = P[2];
+}
+
+/* ========================================================================== */
+/* BSDFs (local shading frame)                                                */
+/* ========================================================================== */
+enum { T_DIFFUSE_REFL = 0x1, T_DELTA_REFL = 0x4, T_DELTA_TRANS = 0x8, T_GLOSSY_REFL = 0x10,
+       T_DELTA = 0x4 | 0x8, T_TRANSMISSION = 0x2 | 0x8 | 0x20 };
+
+static inline int spec_is_zero(const float s[3]) { return !(s[0] != 0.0f) && !(s[1] != 0.0f) && !(s[2] != 0.0f); }
+
+/* Frame::tanTheta (include/mitsuba/core/frame.h:98-103) */
+static inline float frame_tan_theta(const float v[3]) {
+	float temp = 1 - v[2]*v[2];
+	if (temp <= 0.0f)
+		return 0.0f;
+	return sqrtf(temp) / v[2];
+}
+
+/* beckmannD (roughmetal.cpp:75-79 == microfacet.cpp:95-99) */
+static float beckmann_d(float alphaB, const float m[3]) {
+	float ex = frame_tan_theta(m) / alphaB;
+	return orc_expf(-(ex*ex)) / (ORC_PI * alphaB*alphaB * orc_pow4f(m[2]));
+}
+
+/* sampleBeckmannD (roughmetal.cpp:85-90) + sphericalDirection (util.cpp:543-550) */
+static void sample_beckmann_d(float alphaB, const float sample[2], float m[3]) {
+	float thetaM = orc_atanf(sqrtf(-alphaB*alphaB * orc_logf(1.0f - sample[0])));
+	float phiM = (2.0f * ORC_PI) * sample[1];
+	float sinTheta = orc_sinf(thetaM);
+	m[0] = sinTheta * orc_cosf(phiM);
+	m[1] = sinTheta * orc_sinf(phiM);
+	m[2] = orc_cosf(thetaM);
+}
+
+/* smithBeckmannG1 (roughmetal.cpp:97-113) */
+static float smith_beckmann_g1(float alphaB, const float v[3], const float m[3]) {
+	if (v3_dot(v, m) * v[2] <= 0)
+		return 0.0;
+	const float tanTheta = frame_tan_theta(v);
+	if (tanTheta == 0.0f)
+		return 1.0f;
+	const float a = 1.0f / (alphaB * tanTheta);
+	const float aSqr = a * a;
+	if (a >= 1.6f)
+		return 1.0f;
+	return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+}
+
+/* reflect(wi, n) = n*(2*dot(n, wi)) - wi  (roughmetal.cpp:115-117) */
+static void mf_reflect(const float wi[3], const float n[3], float wo[3]) {
+	float s = 2.0f * v3_dot(n, wi);
+	wo[0] = n[0]*s - wi[0]; wo[1] = n[1]*s - wi[1]; wo[2] = n[2]*s - wi[2];
+}
+
+/* ---- Lambertian (src/bsdfs/lambertian.cpp:95-126) ---- */
+static void lambertian_f(const float *P, const float wi[3], const float wo[3], float out[3]) {
+	if (wi[2] <= 0 || wo[2] <= 0) { out[0] = out[1] = out[2] = 0.0f; return; }
+	out[0] = P[0] * ORC_INV_PI; out[1] = P[1] * ORC_INV_PI; out[2] = P[2] * ORC_INV_PI;
+}
+static float lambertian_pdf(const float wi[3], const float wo[3]) {
+	if (wi[2] <= 0 || wo[2] <= 0)
+		return 0.0f;
+	return wo[2] * ORC_INV_PI;
+}
+
+/* ---- RoughMetal (src/bsdfs/roughmetal.cpp:119-167) ---- */
+static void roughmetal_f(const float *P, const float wi[3], const float wo[3], float out[3]) {
+	if (wi[2] <= 0 || wo[2] <= 0) { out[0] = out[1] = out[2] = 0.0f; return; }
+	float h[3], Hr[3], F[3];
+	v3_add(h, wi, wo); v3_normalize(Hr, h);
+	orc_fresnel_conductor(v3_dot(wi, Hr), P + 1, P + 4, F);
+	float D = beckmann_d(P[0], Hr);
+	float G = smith_beckmann_g1(P[0], wi, Hr) * smith_beckmann_g1(P[0], wo, Hr);
+	float k = D * G / (4.0f * wi[2] * wo[2]);
+	for (int i = 0; i < 3; ++i) out[i] = P[7+i] * (F[i] * k);
+}
+static float roughmetal_pdf(const float *P, const float wi[3], const float wo[3]) {
+	if (wi[2] <= 0 || wo[2] <= 0)
+		return 0.0f;
+	float h[3], Hr[3];
+	v3_add(h, wi, wo); v3_normalize(Hr, h);
+	float dwhr_dwo = 1.0f / (4.0f * fabsf(v3_dot(wo, Hr)));
+	return beckmann_d(P[0], Hr) * Hr[2] * dwhr_dwo;
+}
+
+/* ---- Microfacet (src/bsdfs/microfacet.cpp:151-269) ---- */
+static void microfacet_f(const float *P, const float wi[3], const float wo[3], float out[3]) {
+	out[0] = out[1] = out[2] = 0.0f;
+	if (wi[2] <= 0 || wo[2] <= 0)
+		return;
+	const float alphaB = P[0], kd = P[1], ks = P[2], intIOR = P[3], extIOR = P[4];
+	float h[3], Hr[3];
+	v3_add(h, wi, wo); v3_normalize(Hr, h);
+	float F = orc_fresnel(v3_dot(wi, Hr), extIOR, intIOR);
+	/* fSpec (:151-161) * (F * m_ks) */
+	float D = beckmann_d(alphaB, Hr);
+	float G = smith_beckmann_g1(alphaB, wi, Hr) * smith_beckmann_g1(alphaB, wo, Hr);
+	float specRef = D * G / (4.0f * wi[2] * wo[2]);
+	float fk = F * ks;
+	for (int i = 0; i < 3; ++i) out[i] += (P[8+i] * specRef) * fk;
+	float dk = ORC_INV_PI * (1-F) * kd;
+	for (int i = 0; i < 3; ++i) out[i] += P[5+i] * dk;
+}
+static float microfacet_pdf_spec(const float *P, const float wi[3], const float wo[3]) {
+	float h[3], Hr[3];
+	v3_add(h, wi, wo); v3_normalize(Hr, h);
+	return beckmann_d(P[0], Hr) * Hr[2] / (4.0f * fabsf(v3_dot(wo, Hr)));
+}
+static float microfacet_pdf(const float *P, const float wi[3], const float wo[3]) {
+	if (wi[2] <= 0 || wo[2] <= 0)
+		return 0.0f;
+	const float kd = P[1], ks = P[2], intIOR = P[3], extIOR = P[4];
+	float fr = orc_fresnel(wi[2], extIOR, intIOR);
+	fr = fminf_(fmaxf_(fr, (float) 0.05f), (float) 0.95f);
+	float diffuseSamplingWeight = (1-fr) * kd;
+	float specularSamplingWeight = fr * ks;
+	float normalization = 1 / (diffuseSamplingWeight + specularSamplingWeight);
+	return (specularSamplingWeight * microfacet_pdf_spec(P, wi, wo)
+	      + diffuseSamplingWeight * (wo[2] * ORC_INV_PI)) * normalization;
+}
+/* Microfacet::sample(bRec, sample) (:233-262): returns f/pdf */
+static void microfacet_sample(const float *P, const float wi[3], const float _sample[2],
+                              float wo[3], uint32_t *stype, float out[3]) {
+	float sample[2] = { _sample[0], _sample[1] };
+	out[0] = out[1] = out[2] = 0.0f;
+	if (wi[2] <= 0)
+		return;
+	const float kd = P[1], ks = P[2], intIOR = P[3], extIOR = P[4];
+	float fr = orc_fresnel(wi[2], extIOR, intIOR);
+	fr = fminf_(fmaxf_(fr, (float) 0.05f), (float) 0.95f);
+	float diffuseSamplingWeight = (1-fr) * kd;
+	float specularSamplingWeight = fr * ks;
+	float normalization = 1 / (diffuseSamplingWeight + specularSamplingWeight);
+	specularSamplingWeight *= normalization;
+	diffuseSamplingWeight *= normalization;
+	if (sample[0] < specularSamplingWeight) {
+		sample[0] /= specularSamplingWeight;
+		/* sampleSpecular (:203-218) */
+		float m[3];
+		sample_beckmann_d(P[0], sample, m);
+		mf_reflect(wi, m, wo);
+		*stype = T_GLOSSY_REFL;
+		if (wo[2] <= 0)
+			return;
+		float pdfValue = microfacet_pdf(P, wi, wo);
+		if (pdfValue == 0)
+			return;
+		float f[3]; microfacet_f(P, wi, wo, f);
+		float recip = 1.0f / pdfValue;
+		out[0] = f[0] * recip; out[1] = f[1] * recip; out[2] = f[2] * recip;
+	} else {
+		sample[0] = (sample[0] - specularSamplingWeight) / diffuseSamplingWeight;
+		/* sampleLambertian (:224-229) */
+		orc_square_to_hemisphere_psa(sample, wo);
+		*stype = T_DIFFUSE_REFL;
+		float f[3]; microfacet_f(P, wi, wo, f);
+		float recip = 1.0f / microfacet_pdf(P, wi, wo);
+		out[0] = f[0] * recip; out[1] = f[1] * recip; out[2] = f[2] * recip;
+	}
+}
+
+void orc_bsdf_f(uint32_t type, const float *P, const float wi[3], const float wo[3], float out[3]) {
+	switch (type) {
+		case MTSGPU_BSDF_LAMBERTIAN: lambertian_f(P, wi, wo, out); break;
+		case MTSGPU_BSDF_ROUGHMETAL: roughmetal_f(P, wi, wo, out); break;
+		case MTSGPU_BSDF_MICROFACET: microfacet_f(P, wi, wo, out); break;
+		default: out[0] = out[1] = out[2] = 0.0f; break;   /* dielectric.cpp:101-103 */
+	}
+}
+
+float orc_bsdf_pdf(uint32_t type, const float *P, const float wi[3], const float wo[3]) {
+	switch (type) {
+		case MTSGPU_BSDF_LAMBERTIAN: return lambertian_pdf(wi, wo);
+		case MTSGPU_BSDF_ROUGHMETAL: return roughmetal_pdf(P, wi, wo);
+		case MTSGPU_BSDF_MICROFACET: return microfacet_pdf(P, wi, wo);
+		default: return 0.0f;                              /* dielectric.cpp:105-107 */
+	}
+}
+
+/* BSDF::sample(bRec, pdf, sample): value NOT divided by pdf */
+void orc_bsdf_sample(uint32_t type, const float *P, const float wi[3], const float s[2],
+                     float wo[3], float *pdf, uint32_t *stype, float out[3]) {
+	out[0] = out[1] = out[2] = 0.0f; *pdf = 0.0f; *stype = 0;
+	wo[0] = wo[1] = wo[2] = 0.0f;
+	switch (type) {
+	case MTSGPU_BSDF_LAMBERTIAN: {
+		/* lambertian.cpp:118-126 */
+		if (wi[2] <= 0)
+			return;
+		orc_square_to_hemisphere_psa(s, wo);
+		*stype = T_DIFFUSE_REFL;
+		*pdf = wo[2] * ORC_INV_PI;
+		out[0] = P[0] * ORC_INV_PI; out[1] = P[1] * ORC_INV_PI; out[2] = P[2] * ORC_INV_PI;
+		return;
+	}
+	case MTSGPU_BSDF_DIELECTRIC: {
+		/* dielectric.cpp:200-261 (both components sampled, quantity == ERadiance) */
+		float cosThetaI = wi[2], etaI = P[1], etaT = P[0];
+		int entering = cosThetaI > 0.0f;
+		if (!entering) { float t = etaI; etaI = etaT; etaT = t; }
+		float eta = etaI / etaT, sinThetaTSqr = eta*eta * (1.0f - wi[2] * wi[2]);
+		float Fr, cosThetaT = 0;
+		if (sinThetaTSqr >= 1.0f) {
+			Fr = 1.0f;
+		} else {
+			cosThetaT = sqrtf(1.0f - sinThetaTSqr);
+			Fr = orc_fresnel_dielectric(fabsf(cosThetaI), cosThetaT, etaI, etaT);
+			if (entering)
+				cosThetaT = -cosThetaT;
+		}
+		if (s[0] <= Fr) {
+			*stype = T_DELTA_REFL;
+			wo[0] = -wi[0]; wo[1] = -wi[1]; wo[2] = wi[2];
+			*pdf = Fr * fabsf(wo[2]);
+			out[0] = P[2] * Fr; out[1] = P[3] * Fr; out[2] = P[4] * Fr;
+		} else {
+			*stype = T_DELTA_TRANS;
+			wo[0] = -eta*wi[0]; wo[1] = -eta*wi[1]; wo[2] = cosThetaT;
+			*pdf = (1-Fr) * fabsf(wo[2]);
+			for (int i = 0; i < 3; ++i) out[i] = P[5+i] * (1-Fr) * (eta*eta);
+		}
+		return;
+	}
+	case MTSGPU_BSDF_ROUGHMETAL: {
+		/* BSDF::sample(bRec, pdf, sample) fallback (bsdf.cpp:37-48) over roughmetal.cpp:148-167 */
+		if (wi[2] <= 0)
+			return;
+		float m[3];
+		sample_beckmann_d(P[0], s, m);
+		mf_reflect(wi, m, wo);
+		*stype = T_GLOSSY_REFL;
+		if (wo[2] <= 0)
+			return;
+		float f[3]; roughmetal_f(P, wi, wo, f);
+		float p = roughmetal_pdf(P, wi, wo);
+		float recip = 1.0f / p;
+		float q[3] = { f[0] * recip, f[1] * recip, f[2] * recip };
+		if (spec_is_zero(q))
+			return;
+		*pdf = p;
+		out[0] = f[0]; out[1] = f[1]; out[2] = f[2];
+		return;
+	}
+	case MTSGPU_BSDF_MICROFACET: {
+		float q[3];
+		microfacet_sample(P, wi, s, wo, stype, q);
+		if (spec_is_zero(q))
+			return;
+		*pdf = microfacet_pdf(P, wi, wo);
+		microfacet_f(P, wi, wo, out);
+		return;
+	}
+	default: return;
+	}
+}
+
+/* ========================================================================== */
+/* Samplers                                                                   */
+/* ========================================================================== */
+typedef struct {
+	int kind;            /* 0 keyed independent, 1 keyed LD, 2 MT independent, 3 MT LD */
+	uint64_t stream;     /* keyed overflow / independent stream */
+	orc_random *mt;
+	/* LD state */
+	int depth, d1, d2; uint32_t spp, index;
+	const uint32_t *scr, *perm;      /* keyed tables */
+	const float *t1d, *t2d;          /* MT tables */
+} sampler_t;
+
+static float sampler_next_float(sampler_t *s) {
+	if (s->mt) return orc_random_next_float(s->mt);
+	return orc_ulong_to_float(orc_keyed_next(&s->stream));
+}
+
+/* next1D (independent.cpp:72-74, ldsampler.cpp:172-178) */
+static float sampler_next1d(sampler_t *s) {
+	if ((s->kind == 1 || s->kind == 3) && s->d1 < s->depth) {
+		int i = s->d1++;
+		if (s->kind == 3) return s->t1d[(size_t) i * s->spp + s->index];
+		return orc_u32_to_unit(orc_vdc_bits(s->perm[((size_t) i * 2 + 0) * s->spp + s->index], s->scr[i*3+0]));
+	}
+	return sampler_next_float(s);
+}
+
+/* next2D (independent.cpp:76-81, ldsampler.cpp:180-186).  The overflow branch of
+ * ldsampler.cpp:185 leaves the evaluation order of its two nextFloat() calls to
+ * the compiler; x-then-y is used here, as independent.cpp enforces. */
+static void sampler_next2d(sampler_t *s, float out[2]) {
+	if ((s->kind == 1 || s->kind == 3) && s->d2 < s->depth) {
+		int i = s->d2++;
+		if (s->kind == 3) {
+			out[0] = s->t2d[((size_t) i * s->spp + s->index) * 2 + 0];
+			out[1] = s->t2d[((size_t) i * s->spp + s->index) * 2 + 1];
+			return;
+		}
+		uint32_t k = s->perm[((size_t) i * 2 + 1) * s->spp + s->index];
+		out[0] = orc_u32_to_unit(orc_vdc_bits(k, s->scr[i*3+1]));
+		out[1] = orc_u32_to_unit(orc_sobol2_bits(k, s->scr[i*3+2]));
+		return;
+	}
+	float value1 = sampler_next_float(s);
+	float value2 = sampler_next_float(s);
+	out[0] = value1; out[1] = value2;
+}
+
+/* ========================================================================== */
+/* Camera (src/cameras/perspective.cpp:77-112)                                */
+/* ========================================================================== */
+static void camera_generate_ray(const mtsgpu_camera *cam, const float dirSample[2], ray_t *ray) {
+	const float (*m)[4] = (const float (*)[4]) cam->raster_to_camera;
+	const float (*w)[4] = (const float (*)[4]) cam->camera_to_world;
+	/* Transform::operator()(Point, Point&) (transform.h:133-149) on (x, y, 0) */
+	float px = dirSample[0], py = dirSample[1], pz = 0;
+	float ic[3];
+	ic[0] = m[0][0] * px + m[0][1] * py + m[0][2] * pz + m[0][3];
+	ic[1] = m[1][0] * px + m[1][1] * py + m[1][2] * pz + m[1][3];
+	ic[2] = m[2][0] * px + m[2][1] * py + m[2][2] * pz + m[2][3];
+	float wv = m[3][0] * px + m[3][1] * py + m[3][2] * pz + m[3][3];
+	if (wv != 1.0f)
+		v3_div(ic, ic, wv);
+	float ld[3];
+	v3_normalize(ld, ic);
+	float invZ = 1.0f / ld[2];
+	float mint = cam->near_clip * invZ, maxt = cam->far_clip * invZ;
+	/* Transform::operator()(Ray, Ray&) (transform.h:219-235): o as point, d as vector */
+	float o[3], d[3];
+	for (int i = 0; i < 3; ++i) {
+		o[i] = w[i][0] * 0.0f + w[i][1] * 0.0f + w[i][2] * 0.0f + w[i][3];
+		d[i] = w[i][0] * ld[0] + w[i][1] * ld[1] + w[i][2] * ld[2];
+	}
+	float wv2 = w[3][0] * 0.0f + w[3][1] * 0.0f + w[3][2] * 0.0f + w[3][3];
+	if (wv2 != 1.0f)
+		v3_div(o, o, wv2);
+	ray_init(ray, o, d);
+	ray->mint = mint; ray->maxt = maxt;
+}
+
+/* ========================================================================== */
+/* MIPathTracer::Li (src/integrators/path/path.cpp:47-216)                    */
+/* ========================================================================== */
+static inline float mi_weight(float pdfA, float pdfB) {
+	pdfA *= pdfA;
+	pdfB *= pdfB;
+	return pdfA / (pdfA + pdfB);
+}
+
+typedef struct { float Li[3], alpha; int depth; } li_result;
+
+static void path_li(const mtsgpu_scene *sc, const orc_render_params *prm, const ray_t *r, sampler_t *smp,
+                    li_result *res, mtsgpu_stats *st) {
+	const int maxDepth = prm->max_depth, rrDepth = prm->rr_depth, strictNormals = prm->strict_normals;
+	its_t its;
+	ray_t ray = *r;
+	float Li[3] = { 0.0f, 0.0f, 0.0f };
+	int depth = 1;                 /* RadianceQueryRecord::newQuery (integrator.h:186-191) */
+	int emitted = 1;               /* type & EEmittedRadiance; ECameraRay has it */
+
+	/* rRec.rayIntersect(ray) (records.inl:89-105): alpha = 1 on hit, 0 on miss (no medium) */
+	int valid = scene_ray_intersect(sc, &ray, &its, st);
+	res->alpha = valid ? 1.0f : 0.0f;
+	ray.mint = ORC_EPS;
+
+	float pathThroughput[3] = { 1.0f, 1.0f, 1.0f };
+
+	while (depth <= maxDepth || maxDepth < 0) {
+		if (!valid) {
+			/* scene->LeBackground(ray) (scene.h:403-405): ConstantLuminaire::Le = intensity */
+			if (emitted && sc->background_lum >= 0) {
+				const float *P = sc->lum_params + MTSGPU_LUM_NPARAMS * (size_t) sc->background_lum;
+				for (int i = 0; i < 3; ++i) Li[i] += pathThroughput[i] * P[i];
+			}
+			break;
+		}
+		const int bsdfIdx = sc->shape_bsdf[its.shape];
+		if (bsdfIdx < 0)
+			break;
+		const uint32_t btype = sc->bsdf_type[bsdfIdx];
+		const float *BP = sc->bsdf_params + MTSGPU_BSDF_NPARAMS * (size_t) bsdfIdx;
+		const int shapeLum = sc->shape_lum[its.shape];
+		float md[3] = { -ray.d[0], -ray.d[1], -ray.d[2] };
+
+		if (shapeLum >= 0 && emitted) {
+			float le[3];
+			area_le(sc, shapeLum, its.geoN, md, le);
+			for (int i = 0; i < 3; ++i) Li[i] += pathThroughput[i] * le[i];
+		}
+
+		if (maxDepth > 0 && depth >= maxDepth)
+			break;
+
+		/* ---- luminaire sampling ---- */
+		float wiDotGeoN = -v3_dot(its.geoN, ray.d), wiDotShN = its.wi[2];
+		if (wiDotGeoN * wiDotShN < 0 && strictNormals)
+			break;
+
+		lrec_t lRec; memset(&lRec, 0, sizeof(lRec));
+		float s2[2];
+		sampler_next2d(smp, s2);
+		if (scene_sample_luminaire(sc, its.p, &lRec, s2, st)) {
+			const float wo[3] = { -lRec.d[0], -lRec.d[1], -lRec.d[2] };
+			float woL[3] = { v3_dot(wo, its.shS), v3_dot(wo, its.shT), v3_dot(wo, its.shN) };
+			float bsdfVal[3];
+			orc_bsdf_f(btype, BP, its.wi, woL, bsdfVal);
+			float ac = fabsf(woL[2]);
+			bsdfVal[0] *= ac; bsdfVal[1] *= ac; bsdfVal[2] *= ac;
+			float woDotGeoN = v3_dot(its.geoN, wo);
+			if (!spec_is_zero(bsdfVal) && (!strictNormals || woDotGeoN * woL[2] > 0)) {
+				/* both luminaire plugins are intersectable or background */
+				float bsdfPdf = orc_bsdf_pdf(btype, BP, its.wi, woL);
+				const float weight = mi_weight(lRec.pdf, bsdfPdf);
+				for (int i = 0; i < 3; ++i)
+					Li[i] += pathThroughput[i] * lRec.value[i] * bsdfVal[i] * weight;
+			}
+		}
+
+		/* ---- BSDF sampling ---- */
+		float woL[3], bsdfPdf, bsdfVal[3];
+		uint32_t sampledType;
+		sampler_next2d(smp, s2);
+		orc_bsdf_sample(btype, BP, its.wi, s2, woL, &bsdfPdf, &sampledType, bsdfVal);
+		if (!spec_is_zero(bsdfVal)) {      /* sampleCos: * |cosTheta(wo)| (bsdf.h:273-279) */
+			float ac = fabsf(woL[2]);
+			bsdfVal[0] *= ac; bsdfVal[1] *= ac; bsdfVal[2] *= ac;
+		}
+		if (spec_is_zero(bsdfVal))
+			break;
+		{
+			float recip = 1.0f / bsdfPdf;
+			bsdfVal[0] *= recip; bsdfVal[1] *= recip; bsdfVal[2] *= recip;
+		}
+		float wo[3];
+		for (int i = 0; i < 3; ++i)
+			wo[i] = its.shS[i] * woL[0] + its.shT[i] * woL[1] + its.shN[i] * woL[2];
+		float woDotGeoN = v3_dot(its.geoN, wo);
+		if (woDotGeoN * woL[2] <= 0 && strictNormals)
+			break;
+
+		ray_init(&ray, its.p, wo);
+		int hitLuminaire = 0;
+		valid = scene_ray_intersect(sc, &ray, &its, st);
+		if (valid) {
+			int l = sc->shape_lum[its.shape];
+			if (l >= 0) {
+				/* LuminaireSamplingRecord(its, -ray.d) (records.inl:82-87) */
+				float nd[3] = { -ray.d[0], -ray.d[1], -ray.d[2] };
+				for (int i = 0; i < 3; ++i) { lRec.p[i] = its.p[i]; lRec.n[i] = its.geoN[i]; lRec.d[i] = nd[i]; }
+				lRec.lum = l;
+				area_le(sc, l, its.geoN, nd, lRec.value);
+				hitLuminaire = 1;
+			}
+		} else {
+			if (sc->background_lum >= 0) {
+				const float *P = sc->lum_params + MTSGPU_LUM_NPARAMS * (size_t) sc->background_lum;
+				lRec.lum = sc->background_lum;
+				lRec.value[0] = P[0]; lRec.value[1] = P[1]; lRec.value[2] = P[2];
+				lRec.d[0] = -ray.d[0]; lRec.d[1] = -ray.d[1]; lRec.d[2] = -ray.d[2];
+				hitLuminaire = 1;
+			} else {
+				depth++;
+				break;
+			}
+		}
+
+		if (hitLuminaire) {
+			const float lumPdf = (!(sampledType & T_DELTA)) ? scene_pdf_luminaire(sc, ray.o, &lRec) : 0;
+			const float weight = mi_weight(bsdfPdf, lumPdf);
+			for (int i = 0; i < 3; ++i)
+				Li[i] += pathThroughput[i] * lRec.value[i] * bsdfVal[i] * weight;
+		}
+
+		/* ---- indirect illumination ---- */
+		if (!valid)
+			break;
+		emitted = 0;                 /* rRec.type = ERadianceNoEmission */
+
+		if (depth >= rrDepth && !(sampledType & T_TRANSMISSION)) {
+			float mx = bsdfVal[0];
+			mx = fmaxf_(mx, bsdfVal[1]); mx = fmaxf_(mx, bsdfVal[2]);
+			float approxAlbedo = fminf_((float) 0.9f, mx);
+			if (sampler_next1d(smp) > approxAlbedo) {
+				break;
+			} else {
+				float recip = 1.0f / approxAlbedo;
+				pathThroughput[0] *= recip; pathThroughput[1] *= recip; pathThroughput[2] *= recip;
+			}
+		}
+		pathThroughput[0] *= bsdfVal[0]; pathThroughput[1] *= bsdfVal[1]; pathThroughput[2] *= bsdfVal[2];
+		depth++;
+	}
+	res->Li[0] = Li[0]; res->Li[1] = Li[1]; res->Li[2] = Li[2];
+	res->depth = depth;
+}
+
+/* ========================================================================== */
+/* ImageBlock::putSample with the tabulated box filter                        */
+/* (include/mitsuba/render/imageblock.h:80-138, src/librender/rfilter.cpp:40-69,*/
+/*  src/rfilters/box.cpp).  border = 0, block offset = 0: the film is the     */
+/*  union of the blocks (Film::putImageBlock sums them, mfilm.cpp:118-143).   */
+/* ========================================================================== */
+#define FILTER_RESOLUTION 15
+typedef struct { float sizeX, sizeY, factorX, factorY, values[FILTER_RESOLUTION+1][FILTER_RESOLUTION+1]; } tabfilter_t;
+
+static void tabfilter_box(tabfilter_t *f) {
+	f->sizeX = f->sizeY = 0.5f;
+	f->factorX = FILTER_RESOLUTION / f->sizeX; f->factorY = FILTER_RESOLUTION / f->sizeY;
+	float sum = 0;
+	for (int y = 0; y < FILTER_RESOLUTION+1; ++y)
+		for (int x = 0; x < FILTER_RESOLUTION+1; ++x) {
+			if (x == FILTER_RESOLUTION || y == FILTER_RESOLUTION) f->values[y][x] = 0;
+			else f->values[y][x] = 1.0f;
+			sum += f->values[y][x];
+		}
+	sum *= 4*f->sizeX*f->sizeY / (FILTER_RESOLUTION*FILTER_RESOLUTION);
+	for (int y = 0; y < FILTER_RESOLUTION+1; ++y)
+		for (int x = 0; x < FILTER_RESOLUTION+1; ++x)
+			f->values[y][x] /= sum;
+}
+
+static int put_sample(float *film, int W, int H, const tabfilter_t *filter, float sx, float sy,
+                      const float spec[3], float alphaValue) {
+	/* Spectrum::isValid (spectrum.h:285-290) */
+	for (int i = 0; i < 3; ++i)
+		if (spec[i] != spec[i] || spec[i] < 0.0f)
+			return 0;
+	sx = sx - 0.5f - 0; sy = sy - 0.5f - 0;
+	int xStart = (int) ceilf(sx - filter->sizeX), xEnd = (int) floorf(sx + filter->sizeX);
+	int yStart = (int) ceilf(sy - filter->sizeY), yEnd = (int) floorf(sy + filter->sizeY);
+	if (xStart < 0) xStart = 0;
+	if (yStart < 0) yStart = 0;
+	if (xEnd > W-1) xEnd = W-1;
+	if (yEnd > H-1) yEnd = H-1;
+	for (int y = yStart; y <= yEnd; ++y) {
+		const float trafoY = filter->factorY * fabsf(y - sy);
+		int iy = (int) trafoY; if (iy > FILTER_RESOLUTION) iy = FILTER_RESOLUTION;
+		for (int x = xStart; x <= xEnd; ++x) {
+			const float trafoX = filter->factorX * fabsf(x - sx);
+			int ix = (int) trafoX; if (ix > FILTER_RESOLUTION) ix = FILTER_RESOLUTION;
+			float weight = filter->values[iy][ix];
+			/* the reference adds spec*0 here; for the finite, non-negative spec that
+			 * passed isValid() that is a no-op, and skipping it keeps the multi-threaded
+			 * oracle free of writes outside the sample's own pixel */
+			if (weight == 0.0f)
+				continue;
+			float *px = film + 5 * ((size_t) y * W + x);
+			px[0] += spec[0] * weight; px[1] += spec[1] * weight; px[2] += spec[2] * weight;
+			px[3] += alphaValue * weight;
+			px[4] += weight;
+		}
+	}
+	return 1;
+}
+
+/* ========================================================================== */
+/* SampleIntegrator::renderBlock (src/librender/integrator.cpp:131-170)       */
+/* ========================================================================== */
+static uint32_t round_to_pow2(uint32_t v) { uint32_t r = 1; while (r < v) r <<= 1; return r; }
+
+static uint32_t effective_spp(const orc_render_params *p) {
+	/* ldsampler.cpp:52-57: rounded up to a power of two */
+	if (p->sampler_kind == MTSGPU_SAMPLER_LD_KEYED) return round_to_pow2(p->spp);
+	return p->spp;
+}
+
+void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *prm,
+                     int x0, int y0, int x1, int y1, float *film, mtsgpu_stats *stats) {
+	const uint32_t spp = effective_spp(prm);
+	const int W = cam->width, H = cam->height;
+	tabfilter_t filter; tabfilter_box(&filter);
+	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED;
+	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
+	uint64_t nClosest = 0, nShadow = 0;
+#ifdef _OPENMP
+	int nthreads = prm->n_threads > 0 ? prm->n_threads : omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads) reduction(+:nClosest,nShadow)
+#endif
+	{
+		uint32_t *scr = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 3 * (size_t) depth) : NULL;
+		uint32_t *perm = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 2 * (size_t) depth * spp) : NULL;
+		mtsgpu_stats st; memset(&st, 0, sizeof(st));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1) collapse(2)
+#endif
+		for (int y = y0; y < y1; ++y) {
+			for (int x = x0; x < x1; ++x) {
+				const uint32_t pixelKey = (uint32_t) y * (uint32_t) W + (uint32_t) x;
+				if (isLD)
+					orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);   /* sampler->generate() */
+				for (uint32_t j = 0; j < spp; ++j) {
+					sampler_t smp; memset(&smp, 0, sizeof(smp));
+					smp.kind = isLD ? 1 : 0;
+					smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
+					smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm;
+					float sample[2];
+					sampler_next2d(&smp, sample);
+					sample[0] += x; sample[1] += y;
+					ray_t eyeRay;
+					camera_generate_ray(cam, sample, &eyeRay);
+					li_result res;
+					path_li(sc, prm, &eyeRay, &smp, &res, &st);
+					put_sample(film, W, H, &filter, sample[0], sample[1], res.Li, res.alpha);
+				}
+			}
+		}
+		nClosest += st.rays_closest; nShadow += st.rays_shadow;
+		free(scr); free(perm);
+	}
+	if (stats) {
+		stats->camera_samples += (uint64_t) (x1 - x0) * (uint64_t) (y1 - y0) * spp;
+		stats->rays_closest += nClosest; stats->rays_shadow += nShadow;
+	}
+}
+
+void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *prm,
+                    const uint32_t *pix_samples, uint32_t n, float *out) {
+	const uint32_t spp = effective_spp(prm);
+	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED;
+	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
+	uint32_t *scr = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 3 * (size_t) depth) : NULL;
+	uint32_t *perm = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 2 * (size_t) depth * spp) : NULL;
+	uint32_t lastKey = 0xFFFFFFFFu;
+	for (uint32_t i = 0; i < n; ++i) {
+		const uint32_t x = pix_samples[3*(size_t)i], y = pix_samples[3*(size_t)i+1], j = pix_samples[3*(size_t)i+2];
+		const uint32_t pixelKey = y * (uint32_t) cam->width + x;
+		if (isLD && pixelKey != lastKey) {
+			orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);
+			lastKey = pixelKey;
+		}
+		sampler_t smp; memset(&smp, 0, sizeof(smp));
+		smp.kind = isLD ? 1 : 0;
+		smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
+		smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm;
+		float sample[2];
+		sampler_next2d(&smp, sample);
+		sample[0] += x; sample[1] += y;
+		ray_t eyeRay;
+		camera_generate_ray(cam, sample, &eyeRay);
+		li_result res;
+		path_li(sc, prm, &eyeRay, &smp, &res, NULL);
+		float *o = out + 8 * (size_t) i;
+		o[0] = res.Li[0]; o[1] = res.Li[1]; o[2] = res.Li[2]; o[3] = res.alpha;
+		o[4] = sample[0]; o[5] = sample[1]; o[6] = (float) res.depth; o[7] = 0.0f;
+	}
+	free(scr); free(perm);
+}
+
+/* The reference's own sequential sampling: one Random (default seed 5489, the
+ * un-cloned sampler), scanline order inside the rectangle (integrator.cpp:204-226) */
+void orc_render_rect_mt(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *prm,
+                        int kind, int x0, int y0, int x1, int y1, float *film) {
+	const int W = cam->width, H = cam->height;
+	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
+	const uint32_t spp = kind == 1 ? round_to_pow2(prm->spp) : prm->spp;
+	tabfilter_t filter; tabfilter_box(&filter);
+	orc_random rnd; rnd.mti = ORC_MT_N + 1;
+	orc_random_seed(&rnd, prm->seed ? prm->seed : 5489ULL);
+	float *t1d = kind == 1 ? (float *) malloc(sizeof(float) * (size_t) depth * spp) : NULL;
+	float *t2d = kind == 1 ? (float *) malloc(sizeof(float) * 2 * (size_t) depth * spp) : NULL;
+	for (int y = y0; y < y1; ++y) {
+		for (int x = x0; x < x1; ++x) {
+			if (kind == 1)
+				orc_ld_generate_mt(&rnd, spp, depth, t1d, t2d);
+			for (uint32_t j = 0; j < spp; ++j) {
+				sampler_t smp; memset(&smp, 0, sizeof(smp));
+				smp.kind = kind == 1 ? 3 : 2;
+				smp.mt = &rnd;
+				smp.depth = depth; smp.spp = spp; smp.index = j; smp.t1d = t1d; smp.t2d = t2d;
+				float sample[2];
+				sampler_next2d(&smp, sample);
+				sample[0] += x; sample[1] += y;
+				ray_t eyeRay;
+				camera_generate_ray(cam, sample, &eyeRay);
+				li_result res;
+				path_li(sc, prm, &eyeRay, &smp, &res, NULL);
+				put_sample(film, W, H, &filter, sample[0], sample[1], res.Li, res.alpha);
+			}
+		}
+	}
+	free(t1d); free(t2d);
+}

@@ -1,0 +1,379 @@
+/*
+ * orc_scene.c -- oracle (TEST INFRASTRUCTURE ONLY): what Scene::initialize,
+ * TriMesh::configure and PerspectiveCameraImpl::configure compute on the host,
+ * restated in plain C and written into the flat mtsgpu_scene layout.
+ */
+#include "orc_internal.h"
+
+struct orc_flat_scene {
+	mtsgpu_scene sc;
+	orc_kdtree kd;
+	float *vtx_pos, *vtx_nrm;
+	uint32_t *tri_idx, *shape_tri_offset, *shape_flags, *triaccel;
+	int32_t *shape_bsdf, *shape_lum;
+	uint32_t *bsdf_type; float *bsdf_params;
+	uint32_t *lum_type; float *lum_params; int32_t *lum_shape; float *lum_inv_area;
+	uint32_t *lum_cdf_offset; float *lum_tri_cdf, *lum_sel_cdf, *lum_sel_pdf;
+};
+
+/* unitAngle (include/mitsuba/core/util.h:343-348) */
+static float unit_angle(const float u[3], const float v[3]) {
+	float t[3];
+	if (v3_dot(u, v) < 0) {
+		v3_add(t, v, u);
+		return ORC_PI - 2 * asinf(v3_length(t) / 2);
+	} else {
+		v3_sub(t, v, u);
+		return 2 * asinf(v3_length(t) / 2);
+	}
+}
+
+/* TriMesh::computeNormals, smooth branch (src/librender/trimesh.cpp:497-539) */
+static void compute_normals(const float *pos, uint32_t nVerts, const uint32_t *tris, uint32_t nTris, float *nrm) {
+	memset(nrm, 0, sizeof(float) * 3 * (size_t) nVerts);
+	for (uint32_t i = 0; i < nTris; i++) {
+		const uint32_t *tri = tris + 3 * (size_t) i;
+		float n[3] = { 0.0f, 0.0f, 0.0f };
+		for (int k = 0; k < 3; ++k) {
+			const float *v0 = pos + 3 * (size_t) tri[k];
+			const float *v1 = pos + 3 * (size_t) tri[(k+1)%3];
+			const float *v2 = pos + 3 * (size_t) tri[(k+2)%3];
+			float sideA[3], sideB[3];
+			v3_sub(sideA, v1, v0); v3_sub(sideB, v2, v0);
+			if (k == 0) {
+				v3_cross(n, sideA, sideB);
+				float length = v3_length(n);
+				if (length == 0)
+					break;
+				v3_div(n, n, length);
+			}
+			float a[3], b[3];
+			v3_normalize(a, sideA); v3_normalize(b, sideB);
+			float angle = unit_angle(a, b);
+			float *dst = nrm + 3 * (size_t) tri[k];
+			dst[0] += n[0] * angle; dst[1] += n[1] * angle; dst[2] += n[2] * angle;
+		}
+	}
+	for (uint32_t i = 0; i < nVerts; i++) {
+		float *n = nrm + 3 * (size_t) i;
+		float length = v3_length(n);
+		if (length != 0) {
+			v3_div(n, n, length);
+		} else {
+			n[0] = 1; n[1] = 0; n[2] = 0;
+		}
+	}
+}
+
+/* Triangle::surfaceArea (src/libcore/triangle.cpp:49-55) */
+static float tri_surface_area(const float *pos, const uint32_t *tri) {
+	float sideA[3], sideB[3], c[3];
+	v3_sub(sideA, pos + 3 * (size_t) tri[1], pos + 3 * (size_t) tri[0]);
+	v3_sub(sideB, pos + 3 * (size_t) tri[2], pos + 3 * (size_t) tri[0]);
+	v3_cross(c, sideA, sideB);
+	return 0.5f * v3_length(c);
+}
+
+/* DiscretePDF::build (include/mitsuba/core/pdf.h:82-95); pdf may be NULL */
+static float discrete_pdf_build(const float *values, uint32_t n, float *cdf, float *pdf) {
+	cdf[0] = 0.0f;
+	for (uint32_t i = 1; i < n + 1; ++i)
+		cdf[i] = cdf[i-1] + values[i-1];
+	float originalSum = cdf[n];
+	for (uint32_t i = 0; i < n; ++i) {
+		cdf[i] /= originalSum;
+		if (pdf) pdf[i] = values[i] / originalSum;
+	}
+	cdf[n] = 1.0f;
+	return originalSum;
+}
+
+int orc_flatten(const mtsgpu_scene_desc *d, const mtsgpu_kd_params *kdp, orc_flat_scene **out) {
+	orc_flat_scene *fs = (orc_flat_scene *) calloc(1, sizeof(orc_flat_scene));
+	uint32_t nShapes = d->n_meshes, nVerts = 0, nTris = 0;
+	for (uint32_t s = 0; s < nShapes; ++s) { nVerts += d->meshes[s].n_verts; nTris += d->meshes[s].n_tris; }
+	fs->vtx_pos = (float *) malloc(sizeof(float) * 3 * ((size_t) nVerts + 1));
+	fs->vtx_nrm = (float *) calloc(3 * ((size_t) nVerts + 1), sizeof(float));
+	fs->tri_idx = (uint32_t *) malloc(sizeof(uint32_t) * 3 * ((size_t) nTris + 1));
+	fs->shape_tri_offset = (uint32_t *) malloc(sizeof(uint32_t) * (nShapes + 1));
+	fs->shape_flags = (uint32_t *) calloc(nShapes + 1, sizeof(uint32_t));
+	fs->shape_bsdf = (int32_t *) malloc(sizeof(int32_t) * (nShapes + 1));
+	fs->shape_lum = (int32_t *) malloc(sizeof(int32_t) * (nShapes + 1));
+	fs->triaccel = (uint32_t *) calloc(12 * ((size_t) nTris + 1), sizeof(uint32_t));
+
+	fs->bsdf_type = (uint32_t *) malloc(sizeof(uint32_t) * (d->n_bsdfs + 1));
+	fs->bsdf_params = (float *) malloc(sizeof(float) * MTSGPU_BSDF_NPARAMS * (d->n_bsdfs + 1));
+	memcpy(fs->bsdf_type, d->bsdf_type, sizeof(uint32_t) * d->n_bsdfs);
+	memcpy(fs->bsdf_params, d->bsdf_params, sizeof(float) * MTSGPU_BSDF_NPARAMS * d->n_bsdfs);
+
+	uint32_t nLums = d->n_lums;
+	fs->lum_type = (uint32_t *) malloc(sizeof(uint32_t) * (nLums + 1));
+	fs->lum_params = (float *) calloc(MTSGPU_LUM_NPARAMS * (nLums + 1), sizeof(float));
+	fs->lum_shape = (int32_t *) malloc(sizeof(int32_t) * (nLums + 1));
+	fs->lum_inv_area = (float *) calloc(nLums + 1, sizeof(float));
+	fs->lum_cdf_offset = (uint32_t *) calloc(nLums + 2, sizeof(uint32_t));
+	fs->lum_sel_cdf = (float *) calloc(nLums + 2, sizeof(float));
+	fs->lum_sel_pdf = (float *) calloc(nLums + 1, sizeof(float));
+	memcpy(fs->lum_type, d->lum_type, sizeof(uint32_t) * nLums);
+	memcpy(fs->lum_params, d->lum_params, sizeof(float) * MTSGPU_LUM_NPARAMS * nLums);
+	for (uint32_t l = 0; l < nLums; ++l) fs->lum_shape[l] = -1;
+
+	/* geometry: ShapeKDTree::addShape order, m_shapeMap prefix sums (skdtree.cpp:43-65) */
+	uint32_t vbase = 0, tbase = 0;
+	for (uint32_t s = 0; s < nShapes; ++s) {
+		const mtsgpu_mesh *m = &d->meshes[s];
+		fs->shape_tri_offset[s] = tbase;
+		fs->shape_bsdf[s] = m->bsdf;
+		fs->shape_lum[s] = m->lum;
+		memcpy(fs->vtx_pos + 3 * (size_t) vbase, m->positions, sizeof(float) * 3 * (size_t) m->n_verts);
+		if (!m->face_normals) {
+			fs->shape_flags[s] |= MTSGPU_SHAPE_HAS_NORMALS;
+			if (m->normals)
+				memcpy(fs->vtx_nrm + 3 * (size_t) vbase, m->normals, sizeof(float) * 3 * (size_t) m->n_verts);
+			else
+				compute_normals(m->positions, m->n_verts, m->triangles, m->n_tris, fs->vtx_nrm + 3 * (size_t) vbase);
+		}
+		for (uint32_t t = 0; t < m->n_tris; ++t)
+			for (int k = 0; k < 3; ++k)
+				fs->tri_idx[3 * ((size_t) tbase + t) + k] = m->triangles[3 * (size_t) t + k] + vbase;
+		if (m->lum >= 0 && (uint32_t) m->lum < nLums)
+			fs->lum_shape[m->lum] = (int32_t) s;
+		vbase += m->n_verts; tbase += m->n_tris;
+	}
+	fs->shape_tri_offset[nShapes] = tbase;
+
+	/* kd-tree over all triangles + TriAccel table (skdtree.cpp:62-101) */
+	orc_kd_build(fs->vtx_pos, fs->tri_idx, nTris, kdp, &fs->kd);
+	for (uint32_t s = 0; s < nShapes; ++s) {
+		for (uint32_t t = fs->shape_tri_offset[s]; t < fs->shape_tri_offset[s+1]; ++t) {
+			const uint32_t *tri = fs->tri_idx + 3 * (size_t) t;
+			uint32_t *ta = fs->triaccel + 12 * (size_t) t;
+			orc_triaccel_load(fs->vtx_pos + 3 * (size_t) tri[0], fs->vtx_pos + 3 * (size_t) tri[1],
+			                  fs->vtx_pos + 3 * (size_t) tri[2], ta);
+			ta[10] = s;
+			ta[11] = t - fs->shape_tri_offset[s];
+		}
+	}
+
+	/* scene bounding sphere: AABB::getBSphere of the enlarged box (aabb.cpp:44-47) */
+	float center[3], tmp[3];
+	v3_add(tmp, fs->kd.aabb_max, fs->kd.aabb_min);
+	v3_scale(center, tmp, 0.5f);
+	v3_sub(tmp, center, fs->kd.aabb_max);
+	float radius = v3_length(tmp);
+
+	/* luminaires */
+	uint32_t cdfTotal = 0;
+	for (uint32_t l = 0; l < nLums; ++l) {
+		fs->lum_cdf_offset[l] = cdfTotal;
+		if (fs->lum_type[l] == MTSGPU_LUM_AREA && fs->lum_shape[l] >= 0) {
+			uint32_t s = (uint32_t) fs->lum_shape[l];
+			cdfTotal += fs->shape_tri_offset[s+1] - fs->shape_tri_offset[s] + 1;
+		}
+	}
+	fs->lum_cdf_offset[nLums] = cdfTotal;
+	fs->lum_tri_cdf = (float *) calloc((size_t) cdfTotal + 1, sizeof(float));
+	int32_t background = -1;
+	for (uint32_t l = 0; l < nLums; ++l) {
+		float *P = fs->lum_params + MTSGPU_LUM_NPARAMS * (size_t) l;
+		if (fs->lum_type[l] == MTSGPU_LUM_AREA) {
+			if (fs->lum_shape[l] < 0) { orc_flat_scene_free(fs); return MTSGPU_EINVAL; }
+			/* TriMesh::configure (trimesh.cpp:279-283) */
+			uint32_t s = (uint32_t) fs->lum_shape[l];
+			uint32_t t0 = fs->shape_tri_offset[s], n = fs->shape_tri_offset[s+1] - t0;
+			float *areas = (float *) malloc(sizeof(float) * ((size_t) n + 1));
+			for (uint32_t t = 0; t < n; ++t)
+				areas[t] = tri_surface_area(fs->vtx_pos, fs->tri_idx + 3 * ((size_t) t0 + t));
+			float surfaceArea = discrete_pdf_build(areas, n, fs->lum_tri_cdf + fs->lum_cdf_offset[l], NULL);
+			fs->lum_inv_area[l] = 1.0f / surfaceArea;
+			free(areas);
+		} else if (fs->lum_type[l] == MTSGPU_LUM_CONSTANT) {
+			/* ConstantLuminaire::preprocess (src/luminaires/constant.cpp:49-63) */
+			float bc[3] = { center[0], center[1], center[2] }, br = radius;
+			br *= 1.01f;
+			if (d->has_camera) {
+				float oldr = br, dv[3];
+				v3_sub(dv, d->camera_pos, bc);
+				br = fmaxf_(br, v3_length(dv));
+				if (oldr != br)
+					br *= 1.01f;
+			}
+			P[3] = bc[0]; P[4] = bc[1]; P[5] = bc[2]; P[6] = br;
+			background = (int32_t) l;
+		}
+	}
+	/* Scene::initialize luminaire PDF (scene.cpp:320-330): weight 1.0 each */
+	if (nLums > 0) {
+		float *w = (float *) malloc(sizeof(float) * nLums);
+		for (uint32_t l = 0; l < nLums; ++l) w[l] = 1.0f;
+		fs->sc.lum_sel_sum = discrete_pdf_build(w, nLums, fs->lum_sel_cdf, fs->lum_sel_pdf);
+		free(w);
+	}
+
+	mtsgpu_scene *sc = &fs->sc;
+	sc->abi_version = MTSGPU_ABI_VERSION;
+	sc->n_shapes = nShapes; sc->n_tris = nTris; sc->n_verts = nVerts;
+	sc->vtx_pos = fs->vtx_pos; sc->vtx_nrm = fs->vtx_nrm; sc->tri_idx = fs->tri_idx;
+	sc->shape_tri_offset = fs->shape_tri_offset; sc->shape_bsdf = fs->shape_bsdf;
+	sc->shape_lum = fs->shape_lum; sc->shape_flags = fs->shape_flags;
+	sc->n_nodes = fs->kd.n_nodes; sc->n_indices = fs->kd.n_indices;
+	sc->kd_nodes = fs->kd.nodes; sc->kd_indices = fs->kd.indices; sc->triaccel = fs->triaccel;
+	for (int a = 0; a < 3; ++a) { sc->aabb_min[a] = fs->kd.aabb_min[a]; sc->aabb_max[a] = fs->kd.aabb_max[a]; }
+	sc->n_bsdfs = d->n_bsdfs; sc->bsdf_type = fs->bsdf_type; sc->bsdf_params = fs->bsdf_params;
+	sc->n_lums = nLums; sc->lum_type = fs->lum_type; sc->lum_params = fs->lum_params;
+	sc->lum_shape = fs->lum_shape; sc->lum_inv_area = fs->lum_inv_area;
+	sc->lum_cdf_offset = fs->lum_cdf_offset; sc->lum_tri_cdf = fs->lum_tri_cdf;
+	sc->lum_sel_cdf = fs->lum_sel_cdf; sc->lum_sel_pdf = fs->lum_sel_pdf;
+	sc->background_lum = background;
+	*out = fs;
+	return 0;
+}
+
+const mtsgpu_scene *orc_flat_scene_get(const orc_flat_scene *fs) { return &fs->sc; }
+
+int orc_flat_scene_kdstats(const orc_flat_scene *fs, double *out6) {
+	for (int i = 0; i < 6; ++i) out6[i] = fs->kd.stats[i];
+	return 0;
+}
+
+void orc_flat_scene_free(orc_flat_scene *fs) {
+	if (!fs) return;
+	orc_kd_free(&fs->kd);
+	free(fs->vtx_pos); free(fs->vtx_nrm); free(fs->tri_idx); free(fs->shape_tri_offset);
+	free(fs->shape_flags); free(fs->shape_bsdf); free(fs->shape_lum); free(fs->triaccel);
+	free(fs->bsdf_type); free(fs->bsdf_params); free(fs->lum_type); free(fs->lum_params);
+	free(fs->lum_shape); free(fs->lum_inv_area); free(fs->lum_cdf_offset); free(fs->lum_tri_cdf);
+	free(fs->lum_sel_cdf); free(fs->lum_sel_pdf);
+	free(fs);
+}
+
+/* ========================================================================== */
+/* Camera: Transform algebra (src/libcore/transform.cpp, matrix.inl:140-190)  */
+/* ========================================================================== */
+typedef struct { float m[4][4], inv[4][4]; } xform_t;
+
+static void mat_mul(float r[4][4], const float a[4][4], const float b[4][4]) {
+	float t[4][4];
+	for (int i = 0; i < 4; ++i)
+		for (int j = 0; j < 4; ++j) {
+			float sum = 0;
+			for (int k = 0; k < 4; ++k)
+				sum += a[i][k] * b[k][j];
+			t[i][j] = sum;
+		}
+	memcpy(r, t, sizeof(t));
+}
+
+/* Matrix::invert, Gauss-Jordan with full pivoting (matrix.inl:140-190) */
+static int mat_invert(const float src[4][4], float target[4][4]) {
+	int indxc[4], indxr[4], ipiv[4] = { 0, 0, 0, 0 };
+	memcpy(target, src, sizeof(float) * 16);
+	for (int i = 0; i < 4; i++) {
+		int irow = -1, icol = -1;
+		float big = 0;
+		for (int j = 0; j < 4; j++) {
+			if (ipiv[j] != 1) {
+				for (int k = 0; k < 4; k++) {
+					if (ipiv[k] == 0) {
+						if (fabsf(target[j][k]) >= big) {
+							big = fabsf(target[j][k]);
+							irow = j; icol = k;
+						}
+					} else if (ipiv[k] > 1) {
+						return 0;
+					}
+				}
+			}
+		}
+		++ipiv[icol];
+		if (irow != icol)
+			for (int k = 0; k < 4; ++k) { float t = target[irow][k]; target[irow][k] = target[icol][k]; target[icol][k] = t; }
+		indxr[i] = irow; indxc[i] = icol;
+		if (target[icol][icol] == 0)
+			return 0;
+		float pivinv = 1.f / target[icol][icol];
+		target[icol][icol] = 1.f;
+		for (int j = 0; j < 4; j++)
+			target[icol][j] *= pivinv;
+		for (int j = 0; j < 4; j++) {
+			if (j != icol) {
+				float save = target[j][icol];
+				target[j][icol] = 0;
+				for (int k = 0; k < 4; k++)
+					target[j][k] -= target[icol][k]*save;
+			}
+		}
+	}
+	for (int j = 3; j >= 0; j--) {
+		if (indxr[j] != indxc[j])
+			for (int k = 0; k < 4; k++) { float t = target[k][indxr[j]]; target[k][indxr[j]] = target[k][indxc[j]]; target[k][indxc[j]] = t; }
+	}
+	return 1;
+}
+
+static void xf_from_matrix(xform_t *x, const float m[4][4]) { memcpy(x->m, m, sizeof(x->m)); mat_invert(m, x->inv); }
+/* Transform::operator* (transform.cpp:28-31) */
+static void xf_mul(xform_t *r, const xform_t *a, const xform_t *b) {
+	xform_t t;
+	mat_mul(t.m, a->m, b->m);
+	mat_mul(t.inv, b->inv, a->inv);
+	*r = t;
+}
+static void xf_inverse(xform_t *r, const xform_t *a) { xform_t t; memcpy(t.m, a->inv, sizeof(t.m)); memcpy(t.inv, a->m, sizeof(t.m)); *r = t; }
+/* transform.cpp:33-63 */
+static void xf_translate(xform_t *x, float vx, float vy, float vz) {
+	float m[4][4] = { {1,0,0,vx}, {0,1,0,vy}, {0,0,1,vz}, {0,0,0,1} };
+	float i[4][4] = { {1,0,0,-vx}, {0,1,0,-vy}, {0,0,1,-vz}, {0,0,0,1} };
+	memcpy(x->m, m, sizeof(m)); memcpy(x->inv, i, sizeof(i));
+}
+static void xf_scale(xform_t *x, float vx, float vy, float vz) {
+	float m[4][4] = { {vx,0,0,0}, {0,vy,0,0}, {0,0,vz,0}, {0,0,0,1} };
+	float i[4][4] = { {1.0f/vx,0,0,0}, {0,1.0f/vy,0,0}, {0,0,1.0f/vz,0}, {0,0,0,1} };
+	memcpy(x->m, m, sizeof(m)); memcpy(x->inv, i, sizeof(i));
+}
+
+int orc_make_camera(const float origin[3], const float target[3], const float up[3],
+                    float fov_deg, int width, int height, mtsgpu_camera *out) {
+	/* Transform::lookAt (transform.cpp:174-190) */
+	float dirct[3], right[3], newUp[3], t[3];
+	v3_sub(t, target, origin); v3_normalize(dirct, t);
+	v3_cross(t, dirct, up); v3_normalize(right, t);
+	v3_cross(newUp, right, dirct);
+	float c2w[4][4] = {
+		{ right[0], newUp[0], dirct[0], origin[0] },
+		{ right[1], newUp[1], dirct[1], origin[1] },
+		{ right[2], newUp[2], dirct[2], origin[2] },
+		{ 0, 0, 0, 1 } };
+	/* ProjectiveCamera defaults (camera.cpp:121-123) */
+	const float nearClip = 1e-2f, farClip = 1e4f;
+	float aspect = (float) width / (float) height;
+	/* PerspectiveCameraImpl::configure (perspective.cpp:43-71), mapSmallerSide = true */
+	xform_t s1, s2, tr, screenToRaster, tmp;
+	if (aspect >= 1.0f) {
+		xf_scale(&s1, (float) width, (float) height, 1.0f);
+		xf_scale(&s2, 1/(2*aspect), -0.5f, 1.0f);
+		xf_translate(&tr, aspect, -1.0f, 0);
+	} else {
+		xf_scale(&s1, (float) width, (float) height, 1.0f);
+		xf_scale(&s2, 0.5f, -0.5f * aspect, 1.0f);
+		xf_translate(&tr, 1.0f, -1 / aspect, 0);
+	}
+	xf_mul(&tmp, &s1, &s2);
+	xf_mul(&screenToRaster, &tmp, &tr);
+	/* Transform::perspective (transform.cpp:100-124); degToRad = v * (M_PI / 180.0f) */
+	float recip = 1.0f / (farClip - nearClip);
+	float trafo[4][4] = { {1,0,0,0}, {0,1,0,0}, {0,0,farClip * recip, -nearClip * farClip * recip}, {0,0,1,0} };
+	float cot = 1.0f / tanf((fov_deg / 2.0f) * (ORC_PI / 180.0f));
+	xform_t persp, sc, cameraToScreen, a, b, rasterToCamera;
+	xf_from_matrix(&persp, trafo);
+	xf_scale(&sc, cot, cot, 1.0f);
+	xf_mul(&cameraToScreen, &sc, &persp);
+	xf_inverse(&a, &cameraToScreen);
+	xf_inverse(&b, &screenToRaster);
+	xf_mul(&rasterToCamera, &a, &b);
+	memcpy(out->raster_to_camera, rasterToCamera.m, sizeof(float) * 16);
+	memcpy(out->camera_to_world, c2w, sizeof(float) * 16);
+	out->near_clip = nearClip; out->far_clip = farClip;
+	out->width = width; out->height = height;
+	return 0;
+}
