@@ -1,3 +1,263 @@
 """mitsuba-renderer_amd: MI355X-native path-tracing hot path behind Mitsuba 0.2.1's
-integrator interface.  Host-side mirror (ctypes over the C ABI in include/mtsgpu.h)."""
+integrator interface.
+
+Host-side mirror of the reference's objects for this path, over the C ABI of
+include/mtsgpu.h (libmtsgpu.so, built by csrc/Makefile):
+
+    Scene          <- Scene + ShapeKDTree after Scene::initialize()   (src/librender/scene.cpp:291-332)
+    PerspectiveCamera  <- PerspectiveCameraImpl                      (src/cameras/perspective.cpp)
+    MIPathTracer   <- the `path` integrator plugin                   (src/integrators/path/path.cpp)
+
+There is no CPU fallback: every compute call raises if libmtsgpu.so or a gfx950
+device is missing.  (The CPU oracle lives in oracle/ and is test infrastructure.)"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
 from . import abi, scenes  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtsgpu.so")
+
+EXPORTS = [
+    "mtsgpu_create", "mtsgpu_destroy", "mtsgpu_last_error", "mtsgpu_abi_version", "mtsgpu_set_stream",
+    "mtsgpu_upload_scene", "mtsgpu_set_camera", "mtsgpu_set_integrator", "mtsgpu_set_sampler",
+    "mtsgpu_set_tiles", "mtsgpu_set_film_buffer", "mtsgpu_set_options", "mtsgpu_render", "mtsgpu_sync",
+    "mtsgpu_read_film", "mtsgpu_clear_film", "mtsgpu_get_stats", "mtsgpu_trace_rays", "mtsgpu_ld_tables",
+    "mtsgpu_li_samples", "mtsgpu_flatten", "mtsgpu_flat_scene_get", "mtsgpu_flat_scene_free",
+    "mtsgpu_flat_scene_kdstats", "mtsgpu_make_camera",
+]
+
+
+class MtsGpuError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libmtsgpu.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-j4"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libmtsgpu.so; fails loudly when it is missing (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MtsGpuError("libmtsgpu.so not built: run __graft_entry__.build() or `make -C mitsuba-renderer_amd/csrc`")
+    L = C.CDLL(LIB_PATH)
+    vp, f32p, u32p = C.c_void_p, abi.f32p, abi.u32p
+    L.mtsgpu_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.mtsgpu_destroy.argtypes = [vp]; L.mtsgpu_destroy.restype = None
+    L.mtsgpu_last_error.argtypes = [vp]; L.mtsgpu_last_error.restype = C.c_char_p
+    L.mtsgpu_abi_version.argtypes = []
+    L.mtsgpu_set_stream.argtypes = [vp, vp]
+    L.mtsgpu_upload_scene.argtypes = [vp, C.POINTER(abi.Scene)]
+    L.mtsgpu_set_camera.argtypes = [vp, C.POINTER(abi.Camera)]
+    L.mtsgpu_set_integrator.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.mtsgpu_set_sampler.argtypes = [vp, C.c_int, C.c_uint32, C.c_int, C.c_uint64]
+    L.mtsgpu_set_tiles.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.mtsgpu_set_film_buffer.argtypes = [vp, vp]
+    L.mtsgpu_set_options.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
+    L.mtsgpu_render.argtypes = [vp, C.POINTER(C.c_int)]
+    L.mtsgpu_sync.argtypes = [vp]
+    L.mtsgpu_read_film.argtypes = [vp, f32p]
+    L.mtsgpu_clear_film.argtypes = [vp]
+    L.mtsgpu_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+    L.mtsgpu_trace_rays.argtypes = [vp, f32p, C.c_uint32, C.c_int, u32p]
+    L.mtsgpu_ld_tables.argtypes = [vp, C.c_uint32, f32p, f32p]
+    L.mtsgpu_li_samples.argtypes = [vp, u32p, C.c_uint32, f32p]
+    L.mtsgpu_flatten.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.KdParams), C.POINTER(vp)]
+    L.mtsgpu_flat_scene_get.argtypes = [vp]; L.mtsgpu_flat_scene_get.restype = C.POINTER(abi.Scene)
+    L.mtsgpu_flat_scene_free.argtypes = [vp]; L.mtsgpu_flat_scene_free.restype = None
+    L.mtsgpu_flat_scene_kdstats.argtypes = [vp, C.POINTER(C.c_double)]
+    L.mtsgpu_make_camera.argtypes = [f32p, f32p, f32p, C.c_float, C.c_int, C.c_int, C.POINTER(abi.Camera)]
+    _lib = L
+    return L
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Scene:
+    """A flattened, render-ready scene: what Scene::initialize() leaves behind
+    (kd-tree, TriAccel table, vertex normals, luminaire CDFs), built by mtsgpu_flatten()."""
+
+    def __init__(self, description, kd_params=None):
+        self.description = description
+        self._desc, self._keep = description.to_ctypes()
+        self._h = C.c_void_p()
+        kp = kd_params if kd_params is not None else abi.KdParams()
+        rc = lib().mtsgpu_flatten(C.byref(self._desc), C.byref(kp), C.byref(self._h))
+        if rc != 0:
+            raise MtsGpuError("mtsgpu_flatten: %s" % lib().mtsgpu_last_error(None).decode())
+        self.ptr = lib().mtsgpu_flat_scene_get(self._h)
+
+    @property
+    def sc(self):
+        return self.ptr.contents
+
+    def arrays(self):
+        return abi.scene_arrays(self.sc)
+
+    def kdstats(self):
+        out = (C.c_double * 6)()
+        lib().mtsgpu_flat_scene_kdstats(self._h, out)
+        return dict(zip(["inner", "leaf", "indices", "exp_traversals", "exp_leaves", "exp_prims"], list(out)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and _lib is not None:
+            _lib.mtsgpu_flat_scene_free(h)
+            self._h = None
+
+
+class PerspectiveCamera:
+    """`perspective` camera plugin: lookAt toWorld transform, fov along the smaller side, pinhole."""
+
+    def __init__(self, origin, target, up, fov, width, height):
+        self.c = abi.Camera()
+        rc = lib().mtsgpu_make_camera(abi.ptr(_f(origin), abi.f32p), abi.ptr(_f(target), abi.f32p), abi.ptr(_f(up), abi.f32p),
+                                      C.c_float(fov), int(width), int(height), C.byref(self.c))
+        if rc != 0:
+            raise MtsGpuError("mtsgpu_make_camera: %s" % lib().mtsgpu_last_error(None).decode())
+
+    @classmethod
+    def for_description(cls, desc, width, height):
+        c = desc.camera
+        return cls(c["origin"], c["target"], c["up"], c["fov"], width, height)
+
+    @property
+    def width(self):
+        return self.c.width
+
+    @property
+    def height(self):
+        return self.c.height
+
+
+class MIPathTracer:
+    """The `path` integrator (MIPathTracer : MonteCarloIntegrator) on one MI355X.
+
+    Properties as in src/librender/integrator.cpp:272-292: maxDepth (-1 = unbounded),
+    rrDepth (10), strictNormals (false).  The call order mirrors the host's:
+    configure() -> preprocess(scene, camera, sampler...) -> render() [-> cancel()]."""
+
+    def __init__(self, maxDepth=-1, rrDepth=10, strictNormals=False, device=0):
+        self.maxDepth, self.rrDepth, self.strictNormals = int(maxDepth), int(rrDepth), bool(strictNormals)
+        self._ctx = C.c_void_p()
+        self._cancel = C.c_int(0)
+        self._film_keep = None
+        rc = lib().mtsgpu_create(int(device), C.byref(self._ctx))
+        if rc != 0:
+            raise MtsGpuError("mtsgpu_create: %s" % lib().mtsgpu_last_error(None).decode())
+        self.camera = None
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise MtsGpuError("%s: %s (code %d)" % (what, lib().mtsgpu_last_error(self._ctx).decode(), rc))
+
+    def configure(self):
+        self._chk(lib().mtsgpu_set_integrator(self._ctx, self.maxDepth, self.rrDepth, int(self.strictNormals)), "set_integrator")
+        return self
+
+    def preprocess(self, scene, camera, sampler="independent", sampleCount=4, depth=3, seed=0x5EED):
+        """Scene::preprocess -> Integrator::preprocess: upload the flattened scene, camera and sampler."""
+        self.configure()
+        sp = scene.ptr if isinstance(scene, Scene) else scene
+        self._chk(lib().mtsgpu_upload_scene(self._ctx, sp), "upload_scene")
+        self.camera = camera
+        self._chk(lib().mtsgpu_set_camera(self._ctx, C.byref(camera.c if hasattr(camera, "c") else camera)), "set_camera")
+        kind = {"independent": abi.SAMPLER_INDEPENDENT_KEYED, "ldsampler": abi.SAMPLER_LD_KEYED}[sampler] if isinstance(sampler, str) else int(sampler)
+        self._chk(lib().mtsgpu_set_sampler(self._ctx, kind, int(sampleCount), int(depth), int(seed)), "set_sampler")
+        return True
+
+    def set_tiles(self, block_size=32, part=0, n_parts=1):
+        self._chk(lib().mtsgpu_set_tiles(self._ctx, block_size, part, n_parts), "set_tiles")
+
+    def set_options(self, max_paths=0, count_traversal=False, time_kernels=False):
+        self._chk(lib().mtsgpu_set_options(self._ctx, int(max_paths), int(count_traversal), int(time_kernels)), "set_options")
+
+    def set_stream(self, hip_stream):
+        self._chk(lib().mtsgpu_set_stream(self._ctx, C.c_void_p(hip_stream)), "set_stream")
+
+    def set_film_buffer(self, device_ptr, keepalive=None):
+        self._film_keep = keepalive
+        self._chk(lib().mtsgpu_set_film_buffer(self._ctx, C.c_void_p(device_ptr)), "set_film_buffer")
+
+    def clear_film(self):
+        self._chk(lib().mtsgpu_clear_film(self._ctx), "clear_film")
+
+    def render(self):
+        """SampleIntegrator::render: returns True, or False when cancelled (integrator.cpp:87-120)."""
+        self._cancel.value = 0
+        rc = lib().mtsgpu_render(self._ctx, C.byref(self._cancel))
+        if rc == -4:
+            return False
+        self._chk(rc, "render")
+        return True
+
+    def cancel(self):
+        self._cancel.value = 1
+
+    def sync(self):
+        self._chk(lib().mtsgpu_sync(self._ctx), "sync")
+
+    def film(self):
+        """[H][W][5] float32: spectrum rgb sum, alpha sum, weight sum (ImageBlock layout)"""
+        cam = self.camera.c if hasattr(self.camera, "c") else self.camera
+        out = np.zeros((cam.height, cam.width, 5), dtype=np.float32)
+        self._chk(lib().mtsgpu_read_film(self._ctx, abi.ptr(out, abi.f32p)), "read_film")
+        return out
+
+    def stats(self):
+        st = abi.Stats()
+        self._chk(lib().mtsgpu_get_stats(self._ctx, C.byref(st)), "get_stats")
+        return st.as_dict()
+
+    # --- kernels exposed for parity tests --------------------------------------
+    def trace_rays(self, rays, shadow=False):
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        hits = np.zeros((r.shape[0], 4), dtype=np.uint32)
+        self._chk(lib().mtsgpu_trace_rays(self._ctx, abi.ptr(r, abi.f32p), r.shape[0], int(shadow), abi.ptr(hits, abi.u32p)), "trace_rays")
+        return hits
+
+    def ld_tables(self, pixel_key, spp, depth):
+        t1 = np.zeros((depth, spp), dtype=np.float32)
+        t2 = np.zeros((depth, spp, 2), dtype=np.float32)
+        self._chk(lib().mtsgpu_ld_tables(self._ctx, int(pixel_key), abi.ptr(t1, abi.f32p), abi.ptr(t2, abi.f32p)), "ld_tables")
+        return t1, t2
+
+    def li_samples(self, pix_samples):
+        ps = np.ascontiguousarray(pix_samples, dtype=np.uint32).reshape(-1, 3)
+        out = np.zeros((ps.shape[0], 8), dtype=np.float32)
+        self._chk(lib().mtsgpu_li_samples(self._ctx, abi.ptr(ps, abi.u32p), ps.shape[0], abi.ptr(out, abi.f32p)), "li_samples")
+        return out
+
+    def close(self):
+        if self._ctx and _lib is not None:
+            _lib.mtsgpu_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def develop(film):
+    """Film::develop: pixel = spectrum * (1 / weight) (src/films/mfilm.cpp:108-116)"""
+    w = film[..., 4:5]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = np.where(w > 0, np.float32(1.0) / w, np.float32(0)).astype(np.float32)
+    return (film[..., :3] * inv).astype(np.float32)

@@ -1,0 +1,652 @@
+// api.cpp -- the C ABI of libmtsgpu (include/mtsgpu.h): context, HBM residency of the
+// flattened scene, and the host loop that drives the wavefront stages per bounce.
+// There is no CPU fallback: every compute entry point needs a gfx950 device.
+#include "host.h"
+#include "kernels.h"
+#include "devmath.h"
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+using namespace mg;
+
+namespace {
+thread_local std::string g_lastError;
+}
+
+struct mtsgpu_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool ownStream = false;
+	std::string error;
+
+	// scene
+	bool haveScene = false;
+	DScene dsc{};
+	std::vector<void *> sceneAllocs;
+	uint32_t nTris = 0;
+
+	// configuration
+	bool haveCamera = false;
+	mtsgpu_camera cam{};
+	int maxDepth = -1, rrDepth = 10, strictNormals = 0;
+	int samplerKind = MTSGPU_SAMPLER_INDEPENDENT_KEYED;
+	uint32_t spp = 4; int ldDepth = 3; uint64_t seed = 0;
+	int blockSize = 32, part = 0, nParts = 1;
+	uint64_t maxPaths = 0; bool countTraversal = false, timeKernels = false;
+
+	// film
+	float *film = nullptr; bool ownFilm = false; size_t filmPixels = 0;
+
+	// per-pass buffers
+	size_t pathCap = 0;
+	DPaths paths{};
+	DQueues q{};
+	uint32_t *queueA = nullptr, *queueB = nullptr;
+	uint32_t *pixelList = nullptr; size_t pixelListCap = 0;
+	uint32_t *ldScr = nullptr; uint16_t *ldPerm = nullptr; size_t ldScrCap = 0, ldPermCap = 0;
+	uint32_t *explicitSamples = nullptr; size_t explicitCap = 0;
+	uint32_t *hostCounters = nullptr;       // pinned
+	std::vector<void *> pathAllocs;
+
+	// stats
+	mtsgpu_stats stats{};
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> traceEvents, shadeEvents;
+	size_t traceEvUsed = 0, shadeEvUsed = 0;
+};
+
+namespace {
+
+int fail(mtsgpu_ctx *ctx, int code, const char *fmt, ...) {
+	char buf[512];
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+	g_lastError = buf;
+	if (ctx) ctx->error = buf;
+	return code;
+}
+
+#define HIPCHK(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+	return fail(ctx, MTSGPU_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+template <typename T> int devAlloc(mtsgpu_ctx *ctx, T **p, size_t count, std::vector<void *> &owner) {
+	void *raw = nullptr;
+	HIPCHK(ctx, hipMalloc(&raw, std::max<size_t>(count, 1) * sizeof(T)));
+	owner.push_back(raw);
+	*p = static_cast<T *>(raw);
+	return 0;
+}
+
+template <typename T> int upload(mtsgpu_ctx *ctx, const T **dst, const T *src, size_t count) {
+	T *p = nullptr;
+	int rc = devAlloc(ctx, &p, count, ctx->sceneAllocs);
+	if (rc) return rc;
+	if (count) HIPCHK(ctx, hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+	*dst = p;
+	return 0;
+}
+
+void freeAll(std::vector<void *> &v) { for (void *p : v) (void) hipFree(p); v.clear(); }
+
+uint32_t roundToPow2(uint32_t v) { uint32_t r = 1; while (r < v) r <<= 1; return r; }
+
+uint32_t effectiveSpp(const mtsgpu_ctx *c) {
+	return c->samplerKind == MTSGPU_SAMPLER_LD_KEYED ? roundToPow2(c->spp) : c->spp;   // ldsampler.cpp:52-57
+}
+
+int ensurePaths(mtsgpu_ctx *c, size_t cap) {
+	if (cap <= c->pathCap)
+		return 0;
+	freeAll(c->pathAllocs);
+	c->pathCap = 0;
+	cap = (cap + 255) & ~(size_t) 255;
+	auto &o = c->pathAllocs;
+	int rc = 0;
+	rc |= devAlloc(c, &c->paths.ray_o, cap, o); rc |= devAlloc(c, &c->paths.ray_d, cap, o);
+	rc |= devAlloc(c, &c->paths.hit, cap, o); rc |= devAlloc(c, &c->paths.thr, cap, o);
+	rc |= devAlloc(c, &c->paths.Li, cap, o); rc |= devAlloc(c, &c->paths.bsdf, cap, o);
+	rc |= devAlloc(c, &c->paths.nee, cap, o); rc |= devAlloc(c, &c->paths.sh_o, cap, o);
+	rc |= devAlloc(c, &c->paths.sh_d, cap, o); rc |= devAlloc(c, &c->paths.rng, cap, o);
+	rc |= devAlloc(c, &c->paths.spos, cap, o); rc |= devAlloc(c, &c->paths.pix, cap, o);
+	rc |= devAlloc(c, &c->paths.smp, cap, o);
+	for (int b = 0; b < kNumBins; ++b) rc |= devAlloc(c, &c->q.bins[b], cap, o);
+	rc |= devAlloc(c, &c->queueA, cap, o); rc |= devAlloc(c, &c->queueB, cap, o);
+	rc |= devAlloc(c, &c->q.shadow, cap, o);
+	rc |= devAlloc(c, &c->q.counters, 16, o);
+	rc |= devAlloc(c, &c->q.trace_counts, 4, o);
+	rc |= devAlloc(c, &c->q.spill, cap * trace_spill_levels(), o);
+	if (rc) return rc;
+	c->q.spill_stride = (uint32_t) cap;
+	HIPCHK(c, hipMemset(c->q.trace_counts, 0, 4 * sizeof(unsigned long long)));
+	c->pathCap = cap;
+	return 0;
+}
+
+template <typename T> int ensureBuf(mtsgpu_ctx *c, T **p, size_t *cap, size_t need) {
+	if (need <= *cap) return 0;
+	if (*p) (void) hipFree(*p);
+	*p = nullptr; *cap = 0;
+	void *raw = nullptr;
+	HIPCHK(c, hipMalloc(&raw, need * sizeof(T)));
+	*p = static_cast<T *>(raw); *cap = need;
+	return 0;
+}
+
+DConfig makeConfig(const mtsgpu_ctx *c, bool slotPerPath) {
+	DConfig cfg{};
+	std::memcpy(cfg.r2c, c->cam.raster_to_camera, sizeof(cfg.r2c));
+	std::memcpy(cfg.c2w, c->cam.camera_to_world, sizeof(cfg.c2w));
+	cfg.near_clip = c->cam.near_clip; cfg.far_clip = c->cam.far_clip;
+	cfg.width = c->cam.width; cfg.height = c->cam.height;
+	cfg.max_depth = c->maxDepth; cfg.rr_depth = c->rrDepth; cfg.strict_normals = c->strictNormals;
+	cfg.sampler_kind = c->samplerKind;
+	cfg.spp = effectiveSpp(c); cfg.ld_depth = c->ldDepth; cfg.seed = c->seed;
+	cfg.slot_per_path = slotPerPath ? 1 : 0;
+	cfg.ld_scr = c->ldScr; cfg.ld_perm = c->ldPerm;
+	return cfg;
+}
+
+hipEvent_t *nextEventPair(mtsgpu_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used) {
+	if (used == pool.size()) {
+		hipEvent_t a, b;
+		if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+		pool.emplace_back(a, b);
+	}
+	return &pool[used++].first;
+}
+
+// One wavefront pass: all bounces of the paths already generated into queueA[0..nPaths)
+int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile const int *cancel) {
+	uint32_t nQ = nPaths;
+	uint32_t *cur = c->queueA, *nxt = c->queueB;
+	hipStream_t s = c->stream;
+	while (nQ > 0) {
+		if (cancel && *cancel)
+			return fail(c, MTSGPU_ECANCEL, "render cancelled");
+		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, 8 * sizeof(uint32_t), s));
+		c->q.next = nxt;
+		// closest hit + material sort
+		hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
+		if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
+		launch_trace(s, 0, c->countTraversal, true, c->dsc, c->paths, c->q, cur, nQ);
+		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
+		HIPCHK(c, hipGetLastError());
+		c->stats.rays_closest += nQ; c->stats.trace_launches++;
+		HIPCHK(c, hipMemcpyAsync(c->hostCounters, c->q.counters, kNumBins * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		HIPCHK(c, hipStreamSynchronize(s));
+		// shade, one launch per BSDF type
+		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
+		if (sev) HIPCHK(c, hipEventRecord(sev[0], s));
+		uint32_t binCount[kNumBins];
+		for (int b = 0; b < kNumBins; ++b) binCount[b] = c->hostCounters[b];
+		for (int b = 0; b < kNumBins; ++b)
+			launch_shade(s, b, c->dsc, c->paths, cfg, c->q, binCount[b]);
+		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
+		HIPCHK(c, hipGetLastError());
+		HIPCHK(c, hipMemcpyAsync(c->hostCounters, c->q.counters + kNumBins, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		HIPCHK(c, hipStreamSynchronize(s));
+		const uint32_t nNext = c->hostCounters[0], nShadow = c->hostCounters[1];
+		// shadow rays of this bounce (adds the direct-light term before the next bounce adds its own)
+		if (nShadow) {
+			hipEvent_t *ev2 = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
+			if (ev2) HIPCHK(c, hipEventRecord(ev2[0], s));
+			launch_trace(s, 1, c->countTraversal, false, c->dsc, c->paths, c->q, c->q.shadow, nShadow);
+			if (ev2) HIPCHK(c, hipEventRecord(ev2[1], s));
+			HIPCHK(c, hipGetLastError());
+			c->stats.rays_shadow += nShadow; c->stats.trace_launches++;
+		}
+		std::swap(cur, nxt);
+		nQ = nNext;
+	}
+	return 0;
+}
+
+int checkReady(mtsgpu_ctx *c) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	if (!c->haveScene) return fail(c, MTSGPU_ESTATE, "no scene uploaded");
+	if (!c->haveCamera) return fail(c, MTSGPU_ESTATE, "no camera set");
+	if (hipSetDevice(c->device) != hipSuccess) return fail(c, MTSGPU_EHIP, "hipSetDevice failed");
+	return 0;
+}
+
+void collectTimings(mtsgpu_ctx *c) {
+	float ms;
+	for (size_t i = 0; i < c->traceEvUsed; ++i)
+		if (hipEventElapsedTime(&ms, c->traceEvents[i].first, c->traceEvents[i].second) == hipSuccess) c->stats.trace_ms += ms;
+	for (size_t i = 0; i < c->shadeEvUsed; ++i)
+		if (hipEventElapsedTime(&ms, c->shadeEvents[i].first, c->shadeEvents[i].second) == hipSuccess) c->stats.shade_ms += ms;
+	c->traceEvUsed = c->shadeEvUsed = 0;
+}
+
+int fetchTraceCounts(mtsgpu_ctx *c) {
+	unsigned long long h[4];
+	HIPCHK(c, hipMemcpy(h, c->q.trace_counts, sizeof(h), hipMemcpyDeviceToHost));
+	c->stats.n_inner = h[0]; c->stats.n_leaf = h[1]; c->stats.n_idx = h[2]; c->stats.n_tri_tested = h[3];
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int mtsgpu_abi_version(void) { return MTSGPU_ABI_VERSION; }
+
+const char *mtsgpu_last_error(const mtsgpu_ctx *ctx) { return ctx ? ctx->error.c_str() : g_lastError.c_str(); }
+
+int mtsgpu_create(int device, mtsgpu_ctx **out) {
+	if (!out) return fail(nullptr, MTSGPU_EINVAL, "out is null");
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+		return fail(nullptr, MTSGPU_ENODEV, "no HIP device visible; libmtsgpu has no CPU fallback");
+	if (device < 0 || device >= n)
+		return fail(nullptr, MTSGPU_EINVAL, "device %d out of range (%d visible)", device, n);
+	hipDeviceProp_t prop;
+	HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
+	if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		return fail(nullptr, MTSGPU_ENODEV, "device %d is %s; libmtsgpu is built for gfx950 only", device, prop.gcnArchName);
+	HIPCHK(nullptr, hipSetDevice(device));
+	mtsgpu_ctx *c = new mtsgpu_ctx();
+	c->device = device;
+	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(nullptr, MTSGPU_EHIP, "hipStreamCreate failed"); }
+	c->ownStream = true;
+	if (hipHostMalloc((void **) &c->hostCounters, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+		(void) hipStreamDestroy(c->stream); delete c; return fail(nullptr, MTSGPU_EHIP, "hipHostMalloc failed");
+	}
+	*out = c;
+	return 0;
+}
+
+void mtsgpu_destroy(mtsgpu_ctx *c) {
+	if (!c) return;
+	(void) hipSetDevice(c->device);
+	(void) hipDeviceSynchronize();
+	freeAll(c->sceneAllocs); freeAll(c->pathAllocs);
+	if (c->ownFilm && c->film) (void) hipFree(c->film);
+	if (c->pixelList) (void) hipFree(c->pixelList);
+	if (c->ldScr) (void) hipFree(c->ldScr);
+	if (c->ldPerm) (void) hipFree(c->ldPerm);
+	if (c->explicitSamples) (void) hipFree(c->explicitSamples);
+	if (c->hostCounters) (void) hipHostFree(c->hostCounters);
+	for (auto &e : c->traceEvents) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+	for (auto &e : c->shadeEvents) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+	if (c->ownStream && c->stream) (void) hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int mtsgpu_set_stream(mtsgpu_ctx *c, void *hip_stream) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	if (c->ownStream && c->stream) { (void) hipStreamSynchronize(c->stream); (void) hipStreamDestroy(c->stream); }
+	if (hip_stream) { c->stream = (hipStream_t) hip_stream; c->ownStream = false; }
+	else { HIPCHK(c, hipStreamCreate(&c->stream)); c->ownStream = true; }
+	return 0;
+}
+
+int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
+	if (!c || !sc) return fail(c, MTSGPU_EINVAL, "null argument");
+	if (sc->abi_version != MTSGPU_ABI_VERSION) return fail(c, MTSGPU_EINVAL, "scene ABI version %u != %d", sc->abi_version, MTSGPU_ABI_VERSION);
+	if (sc->n_nodes == 0 || !sc->kd_nodes) return fail(c, MTSGPU_EINVAL, "scene has no kd-tree");
+	if (sc->n_lums == 0) return fail(c, MTSGPU_EINVAL, "scene has no luminaire (Scene::initialize would add a constant one, scene.cpp:310-318)");
+	HIPCHK(c, hipSetDevice(c->device));
+	// --- validate everything the kernels index with (an out-of-range index would fault the GPU) ---
+	for (uint32_t i = 0; i < sc->n_nodes; ++i) {
+		const uint32_t a = sc->kd_nodes[2 * (size_t) i], b = sc->kd_nodes[2 * (size_t) i + 1];
+		if (a & 0x80000000u) {
+			if ((a & 0x7FFFFFFFu) > b || b > sc->n_indices) return fail(c, MTSGPU_EINVAL, "kd leaf %u: index range out of bounds", i);
+		} else {
+			if (a & 0x40000000u) return fail(c, MTSGPU_EINVAL, "kd node %u: indirection nodes are not supported (gkdtree.h:1116-1126 removes them)", i);
+			const uint64_t left = (uint64_t) i + ((a & 0x3FFFFFFCu) >> 2);
+			if ((a & 3u) == 3u || left <= i || left + 1 >= sc->n_nodes) return fail(c, MTSGPU_EINVAL, "kd node %u: bad axis/child offset", i);
+		}
+	}
+	for (uint32_t i = 0; i < sc->n_indices; ++i)
+		if (sc->kd_indices[i] >= sc->n_tris) return fail(c, MTSGPU_EINVAL, "kd index %u out of range", i);
+	for (size_t i = 0; i < 3 * (size_t) sc->n_tris; ++i)
+		if (sc->tri_idx[i] >= sc->n_verts) return fail(c, MTSGPU_EINVAL, "triangle vertex index out of range");
+	for (uint32_t s = 0; s < sc->n_shapes; ++s) {
+		if (sc->shape_bsdf[s] >= (int32_t) sc->n_bsdfs || sc->shape_lum[s] >= (int32_t) sc->n_lums) return fail(c, MTSGPU_EINVAL, "shape %u: bad BSDF/luminaire index", s);
+		if (sc->shape_tri_offset[s] > sc->shape_tri_offset[s + 1]) return fail(c, MTSGPU_EINVAL, "shape_tri_offset not monotone");
+		if (sc->shape_lum[s] >= 0 && (sc->lum_type[sc->shape_lum[s]] != MTSGPU_LUM_AREA || sc->lum_shape[sc->shape_lum[s]] != (int32_t) s))
+			return fail(c, MTSGPU_EINVAL, "shape %u: luminaire link is inconsistent", s);
+	}
+	if (sc->shape_tri_offset[sc->n_shapes] != sc->n_tris) return fail(c, MTSGPU_EINVAL, "shape_tri_offset does not cover all triangles");
+	for (uint32_t t = 0; t < sc->n_tris; ++t)
+		if (sc->triaccel[12 * (size_t) t + 10] >= sc->n_shapes) return fail(c, MTSGPU_EINVAL, "TriAccel %u: shape index out of range", t);
+	for (uint32_t b = 0; b < sc->n_bsdfs; ++b)
+		if (sc->bsdf_type[b] >= MTSGPU_BSDF_NTYPES) return fail(c, MTSGPU_EINVAL, "BSDF %u: unknown type", b);
+	for (uint32_t l = 0; l < sc->n_lums; ++l) {
+		if (sc->lum_type[l] == MTSGPU_LUM_AREA) {
+			const int32_t s = sc->lum_shape[l];
+			if (s < 0 || s >= (int32_t) sc->n_shapes) return fail(c, MTSGPU_EINVAL, "luminaire %u: bad shape", l);
+			const uint32_t n = sc->shape_tri_offset[s + 1] - sc->shape_tri_offset[s];
+			if (sc->lum_cdf_offset[l + 1] - sc->lum_cdf_offset[l] != n + 1) return fail(c, MTSGPU_EINVAL, "luminaire %u: CDF size mismatch", l);
+		} else if (sc->lum_type[l] != MTSGPU_LUM_CONSTANT) {
+			return fail(c, MTSGPU_EINVAL, "luminaire %u: unknown type", l);
+		}
+	}
+	if (sc->background_lum >= (int32_t) sc->n_lums) return fail(c, MTSGPU_EINVAL, "background luminaire out of range");
+
+	freeAll(c->sceneAllocs);
+	c->haveScene = false;
+	DScene d{};
+	int rc = 0;
+	rc |= upload(c, (const uint32_t **) &d.nodes, sc->kd_nodes, 2 * (size_t) sc->n_nodes);
+	rc |= upload(c, &d.indices, sc->kd_indices, sc->n_indices);
+	{
+		// device copy of the TriAccel table; bit 31 of the shape dword marks non-occluders
+		// (Shape::isOccluder == has a BSDF, shape.h:324) so that shadow rays need no extra gather
+		std::vector<uint32_t> ta(sc->triaccel, sc->triaccel + 12 * (size_t) sc->n_tris);
+		for (uint32_t t = 0; t < sc->n_tris; ++t)
+			if (sc->shape_bsdf[ta[12 * (size_t) t + 10]] < 0) ta[12 * (size_t) t + 10] |= 0x80000000u;
+		rc |= upload(c, (const uint32_t **) &d.triaccel, ta.data(), ta.size());
+	}
+	rc |= upload(c, &d.vtx_pos, sc->vtx_pos, 3 * (size_t) sc->n_verts);
+	rc |= upload(c, &d.vtx_nrm, sc->vtx_nrm, 3 * (size_t) sc->n_verts);
+	rc |= upload(c, &d.tri_idx, sc->tri_idx, 3 * (size_t) sc->n_tris);
+	rc |= upload(c, &d.shape_bsdf, sc->shape_bsdf, sc->n_shapes);
+	rc |= upload(c, &d.shape_lum, sc->shape_lum, sc->n_shapes);
+	rc |= upload(c, &d.shape_flags, sc->shape_flags, sc->n_shapes);
+	rc |= upload(c, &d.shape_tri_offset, sc->shape_tri_offset, (size_t) sc->n_shapes + 1);
+	rc |= upload(c, &d.bsdf_type, sc->bsdf_type, sc->n_bsdfs);
+	rc |= upload(c, &d.bsdf_params, sc->bsdf_params, (size_t) MTSGPU_BSDF_NPARAMS * sc->n_bsdfs);
+	rc |= upload(c, &d.lum_type, sc->lum_type, sc->n_lums);
+	rc |= upload(c, &d.lum_params, sc->lum_params, (size_t) MTSGPU_LUM_NPARAMS * sc->n_lums);
+	rc |= upload(c, &d.lum_shape, sc->lum_shape, sc->n_lums);
+	rc |= upload(c, &d.lum_inv_area, sc->lum_inv_area, sc->n_lums);
+	rc |= upload(c, &d.lum_cdf_offset, sc->lum_cdf_offset, (size_t) sc->n_lums + 1);
+	rc |= upload(c, &d.lum_tri_cdf, sc->lum_tri_cdf, sc->lum_cdf_offset[sc->n_lums]);
+	rc |= upload(c, &d.lum_sel_cdf, sc->lum_sel_cdf, (size_t) sc->n_lums + 1);
+	rc |= upload(c, &d.lum_sel_pdf, sc->lum_sel_pdf, sc->n_lums);
+	if (rc) { freeAll(c->sceneAllocs); return rc; }
+	d.lum_sel_sum = sc->lum_sel_sum; d.background_lum = sc->background_lum;
+	d.n_lums = sc->n_lums; d.n_nodes = sc->n_nodes; d.n_tris = sc->n_tris; d.n_shapes = sc->n_shapes;
+	for (int a = 0; a < 3; ++a) { d.aabb_min[a] = sc->aabb_min[a]; d.aabb_max[a] = sc->aabb_max[a]; }
+	c->dsc = d; c->nTris = sc->n_tris;
+	c->haveScene = true;
+	return 0;
+}
+
+int mtsgpu_set_camera(mtsgpu_ctx *c, const mtsgpu_camera *cam) {
+	if (!c || !cam) return fail(c, MTSGPU_EINVAL, "null argument");
+	if (cam->width <= 0 || cam->height <= 0 || (uint64_t) cam->width * (uint64_t) cam->height > 0x7FFFFFFFull)
+		return fail(c, MTSGPU_EINVAL, "bad film size %dx%d", cam->width, cam->height);
+	c->cam = *cam; c->haveCamera = true;
+	return 0;
+}
+
+int mtsgpu_set_integrator(mtsgpu_ctx *c, int max_depth, int rr_depth, int strict_normals) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	if (rr_depth <= 0) return fail(c, MTSGPU_EINVAL, "rrDepth == 0 breaks the computation of alpha values! (integrator.cpp:291)");
+	c->maxDepth = max_depth; c->rrDepth = rr_depth; c->strictNormals = strict_normals ? 1 : 0;
+	return 0;
+}
+
+int mtsgpu_set_sampler(mtsgpu_ctx *c, int kind, uint32_t spp, int ld_depth, uint64_t seed) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	if (kind != MTSGPU_SAMPLER_INDEPENDENT_KEYED && kind != MTSGPU_SAMPLER_LD_KEYED) return fail(c, MTSGPU_EINVAL, "unknown sampler kind %d", kind);
+	if (spp == 0) return fail(c, MTSGPU_EINVAL, "sampleCount must be > 0");
+	if (kind == MTSGPU_SAMPLER_LD_KEYED && (roundToPow2(spp) > 65536u || ld_depth < 1 || ld_depth > 64))
+		return fail(c, MTSGPU_EINVAL, "ldsampler: sampleCount <= 65536 and 1 <= depth <= 64 required");
+	c->samplerKind = kind; c->spp = spp; c->ldDepth = ld_depth > 0 ? ld_depth : 3; c->seed = seed;
+	return 0;
+}
+
+int mtsgpu_set_tiles(mtsgpu_ctx *c, int block_size, int part, int n_parts) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	if (block_size <= 0 || n_parts <= 0 || part < 0 || part >= n_parts) return fail(c, MTSGPU_EINVAL, "bad tile sharding %d/%d/%d", block_size, part, n_parts);
+	c->blockSize = block_size; c->part = part; c->nParts = n_parts;
+	return 0;
+}
+
+int mtsgpu_set_film_buffer(mtsgpu_ctx *c, void *device_ptr) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	if (c->ownFilm && c->film) (void) hipFree(c->film);
+	c->film = (float *) device_ptr; c->ownFilm = false; c->filmPixels = 0;
+	return 0;
+}
+
+int mtsgpu_set_options(mtsgpu_ctx *c, uint64_t max_paths, int count_traversal, int time_kernels) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	c->maxPaths = max_paths; c->countTraversal = count_traversal != 0; c->timeKernels = time_kernels != 0;
+	return 0;
+}
+
+static int ensureFilm(mtsgpu_ctx *c) {
+	const size_t px = (size_t) c->cam.width * c->cam.height;
+	if (c->film && !c->ownFilm) return 0;
+	if (c->film && c->filmPixels == px) return 0;
+	if (c->film) (void) hipFree(c->film);
+	c->film = nullptr;
+	HIPCHK(c, hipMalloc((void **) &c->film, px * 5 * sizeof(float)));
+	HIPCHK(c, hipMemset(c->film, 0, px * 5 * sizeof(float)));
+	c->ownFilm = true; c->filmPixels = px;
+	return 0;
+}
+
+int mtsgpu_clear_film(mtsgpu_ctx *c) {
+	int rc = checkReady(c); if (rc) return rc;
+	rc = ensureFilm(c); if (rc) return rc;
+	HIPCHK(c, hipMemsetAsync(c->film, 0, (size_t) c->cam.width * c->cam.height * 5 * sizeof(float), c->stream));
+	return 0;
+}
+
+int mtsgpu_sync(mtsgpu_ctx *c) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
+	int rc = checkReady(c); if (rc) return rc;
+	rc = ensureFilm(c); if (rc) return rc;
+	const int W = c->cam.width, H = c->cam.height, bs = c->blockSize;
+	const uint32_t spp = effectiveSpp(c);
+	// ImageBlock work units (imageproc.cpp:43-78) owned by this context: tile t -> part t % n_parts
+	std::vector<uint32_t> pixels;
+	const int tx = (W + bs - 1) / bs, ty = (H + bs - 1) / bs;
+	for (int t = 0; t < tx * ty; ++t) {
+		if (t % c->nParts != c->part) continue;
+		const int x0 = (t % tx) * bs, y0 = (t / tx) * bs;
+		for (int y = y0; y < std::min(y0 + bs, H); ++y)
+			for (int x = x0; x < std::min(x0 + bs, W); ++x)
+				pixels.push_back((uint32_t) y * (uint32_t) W + (uint32_t) x);
+	}
+	std::memset(&c->stats, 0, sizeof(c->stats));
+	c->traceEvUsed = c->shadeEvUsed = 0;
+	if (pixels.empty()) return 0;
+	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, pixels.size()); if (rc) return rc;
+	HIPCHK(c, hipMemcpyAsync(c->pixelList, pixels.data(), pixels.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+
+	const uint64_t maxPaths = c->maxPaths ? c->maxPaths : (4ull << 20);
+	const size_t slotsPerPass = (size_t) std::max<uint64_t>(1, std::min<uint64_t>(pixels.size(), maxPaths / spp));
+	if ((uint64_t) slotsPerPass * spp > 0x7FFFFFFFull) return fail(c, MTSGPU_EINVAL, "pass too large");
+	rc = ensurePaths(c, slotsPerPass * spp); if (rc) return rc;
+	if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED) {
+		rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, slotsPerPass * 3 * c->ldDepth); if (rc) return rc;
+		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, slotsPerPass * 2 * c->ldDepth * spp); if (rc) return rc;
+	}
+	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 4 * sizeof(unsigned long long), c->stream));
+	const DConfig cfg = makeConfig(c, false);
+
+	hipEvent_t t0, t1;
+	HIPCHK(c, hipEventCreate(&t0)); HIPCHK(c, hipEventCreate(&t1));
+	HIPCHK(c, hipEventRecord(t0, c->stream));
+	for (size_t base = 0; base < pixels.size(); base += slotsPerPass) {
+		const uint32_t nSlots = (uint32_t) std::min(slotsPerPass, pixels.size() - base);
+		const uint32_t nPaths = nSlots * spp;
+		if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED)
+			launch_ld_tables(c->stream, cfg, c->pixelList + base, nSlots, c->ldScr, c->ldPerm);
+		launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList + base, nSlots, nullptr, nPaths, c->queueA);
+		HIPCHK(c, hipGetLastError());
+		rc = runBounces(c, cfg, nPaths, cancel);
+		if (rc) { (void) hipEventDestroy(t0); (void) hipEventDestroy(t1); return rc; }
+		launch_accumulate(c->stream, c->paths, cfg, nSlots, spp, c->film);
+		HIPCHK(c, hipGetLastError());
+		c->stats.camera_samples += nPaths;
+	}
+	HIPCHK(c, hipEventRecord(t1, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	float ms = 0;
+	HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
+	c->stats.total_ms = ms;
+	(void) hipEventDestroy(t0); (void) hipEventDestroy(t1);
+	collectTimings(c);
+	if (c->countTraversal) { rc = fetchTraceCounts(c); if (rc) return rc; }
+	return 0;
+}
+
+int mtsgpu_read_film(mtsgpu_ctx *c, float *rgbaw) {
+	int rc = checkReady(c); if (rc) return rc;
+	if (!rgbaw) return fail(c, MTSGPU_EINVAL, "null output");
+	rc = ensureFilm(c); if (rc) return rc;
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	HIPCHK(c, hipMemcpy(rgbaw, c->film, (size_t) c->cam.width * c->cam.height * 5 * sizeof(float), hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int mtsgpu_get_stats(mtsgpu_ctx *c, mtsgpu_stats *out) {
+	if (!c || !out) return fail(c, MTSGPU_EINVAL, "null argument");
+	*out = c->stats;
+	return 0;
+}
+
+int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, uint32_t *hits) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	if (!c->haveScene) return fail(c, MTSGPU_ESTATE, "no scene uploaded");
+	if (!rays || !hits) return fail(c, MTSGPU_EINVAL, "null argument");
+	HIPCHK(c, hipSetDevice(c->device));
+	std::memset(&c->stats, 0, sizeof(c->stats));
+	c->traceEvUsed = c->shadeEvUsed = 0;
+	if (n == 0) return 0;
+	int rc = ensurePaths(c, n); if (rc) return rc;
+	std::vector<float> o(4 * (size_t) n), d(4 * (size_t) n);
+	for (size_t i = 0; i < n; ++i) {
+		std::memcpy(&o[4 * i], rays + 8 * i, 16);
+		std::memcpy(&d[4 * i], rays + 8 * i + 4, 16);
+	}
+	HIPCHK(c, hipMemcpyAsync(c->paths.ray_o, o.data(), o.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->paths.ray_d, d.data(), d.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+	launch_iota(c->stream, c->queueA, n);
+	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 4 * sizeof(unsigned long long), c->stream));
+	hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
+	if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
+	launch_trace(c->stream, shadow ? 2 : 0, c->countTraversal, false, c->dsc, c->paths, c->q, c->queueA, n);
+	if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
+	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipMemcpyAsync(hits, c->paths.hit, (size_t) n * 16, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->stats.trace_launches = 1;
+	if (shadow) c->stats.rays_shadow = n; else c->stats.rays_closest = n;
+	collectTimings(c);
+	if (c->countTraversal) { rc = fetchTraceCounts(c); if (rc) return rc; }
+	return 0;
+}
+
+int mtsgpu_ld_tables(mtsgpu_ctx *c, uint32_t pixel_key, float *out1d, float *out2d) {
+	if (!c || !out1d || !out2d) return fail(c, MTSGPU_EINVAL, "null argument");
+	if (c->samplerKind != MTSGPU_SAMPLER_LD_KEYED) return fail(c, MTSGPU_ESTATE, "sampler is not the low-discrepancy sampler");
+	HIPCHK(c, hipSetDevice(c->device));
+	const uint32_t spp = effectiveSpp(c);
+	const int depth = c->ldDepth;
+	int rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, (size_t) 3 * depth); if (rc) return rc;
+	rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, (size_t) 2 * depth * spp); if (rc) return rc;
+	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, 1); if (rc) return rc;
+	HIPCHK(c, hipMemcpyAsync(c->pixelList, &pixel_key, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	DConfig cfg{};
+	cfg.spp = spp; cfg.ld_depth = depth; cfg.seed = c->seed; cfg.sampler_kind = 1;
+	launch_ld_tables(c->stream, cfg, c->pixelList, 1, c->ldScr, c->ldPerm);
+	HIPCHK(c, hipGetLastError());
+	std::vector<uint32_t> scr((size_t) 3 * depth);
+	std::vector<uint16_t> perm((size_t) 2 * depth * spp);
+	HIPCHK(c, hipMemcpyAsync(scr.data(), c->ldScr, scr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(perm.data(), c->ldPerm, perm.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	// the u32 -> f32 step of ldsampler.cpp:111,117 on the device-generated integer tables
+	for (int i = 0; i < depth; ++i)
+		for (uint32_t k = 0; k < spp; ++k) {
+			out1d[(size_t) i * spp + k] = u32ToUnit(vdcBits(perm[((size_t) 2 * i) * spp + k], scr[3 * i]));
+			const uint32_t p = perm[((size_t) 2 * i + 1) * spp + k];
+			out2d[((size_t) i * spp + k) * 2 + 0] = u32ToUnit(vdcBits(p, scr[3 * i + 1]));
+			out2d[((size_t) i * spp + k) * 2 + 1] = u32ToUnit(sobol2Bits(p, scr[3 * i + 2]));
+		}
+	return 0;
+}
+
+int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, float *out) {
+	int rc = checkReady(c); if (rc) return rc;
+	if (!pix_samples || !out) return fail(c, MTSGPU_EINVAL, "null argument");
+	std::memset(&c->stats, 0, sizeof(c->stats));
+	c->traceEvUsed = c->shadeEvUsed = 0;
+	if (n == 0) return 0;
+	const uint32_t spp = effectiveSpp(c);
+	std::vector<uint32_t> keys(n);
+	for (uint32_t i = 0; i < n; ++i) {
+		const uint32_t x = pix_samples[3 * (size_t) i], y = pix_samples[3 * (size_t) i + 1], j = pix_samples[3 * (size_t) i + 2];
+		if (x >= (uint32_t) c->cam.width || y >= (uint32_t) c->cam.height || j >= spp)
+			return fail(c, MTSGPU_EINVAL, "sample %u: pixel or sample index out of range", i);
+		keys[i] = y * (uint32_t) c->cam.width + x;
+	}
+	rc = ensurePaths(c, n); if (rc) return rc;
+	rc = ensureBuf(c, &c->explicitSamples, &c->explicitCap, 3 * (size_t) n); if (rc) return rc;
+	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, n); if (rc) return rc;
+	HIPCHK(c, hipMemcpyAsync(c->explicitSamples, pix_samples, 3 * (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipMemcpyAsync(c->pixelList, keys.data(), (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED) {
+		rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, (size_t) n * 3 * c->ldDepth); if (rc) return rc;
+		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, (size_t) n * 2 * c->ldDepth * spp); if (rc) return rc;
+	}
+	const DConfig cfg = makeConfig(c, true);
+	if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED)
+		launch_ld_tables(c->stream, cfg, c->pixelList, n, c->ldScr, c->ldPerm);
+	launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList, n, c->explicitSamples, n, c->queueA);
+	HIPCHK(c, hipGetLastError());
+	rc = runBounces(c, cfg, n, nullptr); if (rc) return rc;
+	std::vector<float> Li(4 * (size_t) n), thr(4 * (size_t) n), spos(2 * (size_t) n);
+	HIPCHK(c, hipMemcpyAsync(Li.data(), c->paths.Li, Li.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(thr.data(), c->paths.thr, thr.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync(spos.data(), c->paths.spos, spos.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	for (size_t i = 0; i < n; ++i) {
+		uint32_t flags; int depth;
+		std::memcpy(&flags, &Li[4 * i + 3], 4); std::memcpy(&depth, &thr[4 * i + 3], 4);
+		float *o = out + 8 * i;
+		o[0] = Li[4 * i]; o[1] = Li[4 * i + 1]; o[2] = Li[4 * i + 2]; o[3] = (flags & F_ALPHA) ? 1.0f : 0.0f;
+		o[4] = spos[2 * i]; o[5] = spos[2 * i + 1]; o[6] = (float) depth; o[7] = 0.0f;
+	}
+	collectTimings(c);
+	return 0;
+}
+
+// --- host-side flattening ------------------------------------------------------
+struct mtsgpu_flat_scene { FlatScene fs; };
+
+int mtsgpu_flatten(const mtsgpu_scene_desc *desc, const mtsgpu_kd_params *kd, mtsgpu_flat_scene **out) {
+	if (!desc || !out) return fail(nullptr, MTSGPU_EINVAL, "null argument");
+	*out = nullptr;
+	try {
+		std::unique_ptr<mtsgpu_flat_scene> p(new mtsgpu_flat_scene());
+		flattenScene(*desc, kd, p->fs);
+		*out = p.release();
+	} catch (const std::exception &e) {
+		return fail(nullptr, MTSGPU_EINVAL, "%s", e.what());
+	}
+	return 0;
+}
+
+const mtsgpu_scene *mtsgpu_flat_scene_get(const mtsgpu_flat_scene *fs) { return fs ? &fs->fs.sc : nullptr; }
+void mtsgpu_flat_scene_free(mtsgpu_flat_scene *fs) { delete fs; }
+
+int mtsgpu_flat_scene_kdstats(const mtsgpu_flat_scene *fs, double *out6) {
+	if (!fs || !out6) return fail(nullptr, MTSGPU_EINVAL, "null argument");
+	for (int i = 0; i < 6; ++i) out6[i] = fs->fs.kd.stats[i];
+	return 0;
+}
+
+int mtsgpu_make_camera(const float origin[3], const float target[3], const float up[3],
+                       float fov_deg, int width, int height, mtsgpu_camera *out) {
+	if (!origin || !target || !up || !out || width <= 0 || height <= 0) return fail(nullptr, MTSGPU_EINVAL, "bad camera arguments");
+	makeCamera(origin, target, up, fov_deg, width, height, *out);
+	return 0;
+}
+
+} // extern "C"

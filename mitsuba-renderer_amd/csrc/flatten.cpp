@@ -1,0 +1,319 @@
+// flatten.cpp -- host side of the boundary: turns plain meshes + property blocks into
+// the HBM layout of mtsgpu_scene, i.e. what Scene::initialize / TriMesh::configure /
+// ShapeKDTree::build / PerspectiveCameraImpl::configure leave behind in the reference.
+#include "host.h"
+#include "devmath.h"
+#include <cmath>
+#include <cstring>
+
+namespace mg {
+namespace {
+
+inline V3 ld3(const float *p) { return V3(p[0], p[1], p[2]); }
+inline void st3(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+// unitAngle (include/mitsuba/core/util.h:343-348)
+float unitAngle(V3 u, V3 v) {
+	if (dot(u, v) < 0)
+		return kPi - 2 * std::asin(length(v + u) / 2);
+	return 2 * std::asin(length(v - u) / 2);
+}
+
+// TriMesh::computeNormals, angle-weighted branch (src/librender/trimesh.cpp:497-539)
+void computeVertexNormals(const float *pos, uint32_t nVerts, const uint32_t *tris, uint32_t nTris, float *nrm) {
+	std::memset(nrm, 0, sizeof(float) * 3 * (size_t) nVerts);
+	for (uint32_t t = 0; t < nTris; ++t) {
+		const uint32_t *idx = tris + 3 * (size_t) t;
+		V3 n(0.0f, 0.0f, 0.0f);
+		for (int i = 0; i < 3; ++i) {
+			const V3 v0 = ld3(pos + 3 * (size_t) idx[i]);
+			const V3 v1 = ld3(pos + 3 * (size_t) idx[(i + 1) % 3]);
+			const V3 v2 = ld3(pos + 3 * (size_t) idx[(i + 2) % 3]);
+			const V3 sideA = v1 - v0, sideB = v2 - v0;
+			if (i == 0) {
+				n = cross(sideA, sideB);
+				const float len = length(n);
+				if (len == 0)
+					break;
+				n = divs(n, len);
+			}
+			const float angle = unitAngle(normalize(sideA), normalize(sideB));
+			float *dst = nrm + 3 * (size_t) idx[i];
+			dst[0] += n.x * angle; dst[1] += n.y * angle; dst[2] += n.z * angle;
+		}
+	}
+	for (uint32_t v = 0; v < nVerts; ++v) {
+		float *p = nrm + 3 * (size_t) v;
+		const V3 n = ld3(p);
+		const float len = length(n);
+		if (len != 0) st3(p, divs(n, len));
+		else st3(p, V3(1, 0, 0));
+	}
+}
+
+// DiscretePDF::build (include/mitsuba/core/pdf.h:82-95)
+float buildCdf(const std::vector<float> &values, float *cdf, float *pdf) {
+	const size_t n = values.size();
+	cdf[0] = 0.0f;
+	for (size_t i = 1; i <= n; ++i)
+		cdf[i] = cdf[i - 1] + values[i - 1];
+	const float originalSum = cdf[n];
+	for (size_t i = 0; i < n; ++i) {
+		cdf[i] /= originalSum;
+		if (pdf) pdf[i] = values[i] / originalSum;
+	}
+	cdf[n] = 1.0f;
+	return originalSum;
+}
+
+} // namespace
+
+void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatScene &fs) {
+	const uint32_t nShapes = d.n_meshes, nLums = d.n_lums;
+	size_t nVerts = 0, nTris = 0;
+	for (uint32_t s = 0; s < nShapes; ++s) { nVerts += d.meshes[s].n_verts; nTris += d.meshes[s].n_tris; }
+	if (nTris >= 0x7FFFFFFFull || nVerts >= 0xFFFFFFFFull)
+		throw std::runtime_error("flatten: too many primitives");
+	fs.vtxPos.assign(3 * nVerts + 3, 0.0f);
+	fs.vtxNrm.assign(3 * nVerts + 3, 0.0f);
+	fs.triIdx.assign(3 * nTris + 3, 0u);
+	fs.shapeTriOffset.assign(nShapes + 1, 0u);
+	fs.shapeFlags.assign(nShapes + 1, 0u);
+	fs.shapeBsdf.assign(nShapes + 1, -1);
+	fs.shapeLum.assign(nShapes + 1, -1);
+	fs.triaccel.assign(12 * nTris + 12, 0u);
+	fs.bsdfType.assign(d.bsdf_type, d.bsdf_type + d.n_bsdfs); fs.bsdfType.push_back(0);
+	fs.bsdfParams.assign(d.bsdf_params, d.bsdf_params + (size_t) MTSGPU_BSDF_NPARAMS * d.n_bsdfs);
+	fs.bsdfParams.resize(fs.bsdfParams.size() + MTSGPU_BSDF_NPARAMS, 0.0f);
+	fs.lumType.assign(d.lum_type, d.lum_type + nLums); fs.lumType.push_back(0);
+	fs.lumParams.assign(d.lum_params, d.lum_params + (size_t) MTSGPU_LUM_NPARAMS * nLums);
+	fs.lumParams.resize(fs.lumParams.size() + MTSGPU_LUM_NPARAMS, 0.0f);
+	fs.lumShape.assign(nLums + 1, -1);
+	fs.lumInvArea.assign(nLums + 1, 0.0f);
+	fs.lumCdfOffset.assign(nLums + 2, 0u);
+	fs.lumSelCdf.assign(nLums + 2, 0.0f);
+	fs.lumSelPdf.assign(nLums + 1, 0.0f);
+
+	// ShapeKDTree::addShape order; primitive ids = prefix sums of triangle counts (skdtree.cpp:43-65)
+	uint32_t vbase = 0, tbase = 0;
+	for (uint32_t s = 0; s < nShapes; ++s) {
+		const mtsgpu_mesh &m = d.meshes[s];
+		if (m.bsdf >= (int32_t) d.n_bsdfs || m.lum >= (int32_t) nLums)
+			throw std::runtime_error("flatten: mesh references a missing BSDF/luminaire");
+		fs.shapeTriOffset[s] = tbase;
+		fs.shapeBsdf[s] = m.bsdf;
+		fs.shapeLum[s] = m.lum;
+		std::memcpy(&fs.vtxPos[3 * (size_t) vbase], m.positions, sizeof(float) * 3 * (size_t) m.n_verts);
+		if (!m.face_normals) {
+			fs.shapeFlags[s] |= MTSGPU_SHAPE_HAS_NORMALS;
+			if (m.normals)
+				std::memcpy(&fs.vtxNrm[3 * (size_t) vbase], m.normals, sizeof(float) * 3 * (size_t) m.n_verts);
+			else
+				computeVertexNormals(m.positions, m.n_verts, m.triangles, m.n_tris, &fs.vtxNrm[3 * (size_t) vbase]);
+		}
+		for (size_t k = 0; k < 3 * (size_t) m.n_tris; ++k) {
+			if (m.triangles[k] >= m.n_verts)
+				throw std::runtime_error("flatten: triangle index out of range");
+			fs.triIdx[3 * (size_t) tbase + k] = m.triangles[k] + vbase;
+		}
+		if (m.lum >= 0) {
+			if (fs.lumShape[m.lum] >= 0 || fs.lumType[m.lum] != MTSGPU_LUM_AREA)
+				throw std::runtime_error("flatten: area luminaire must be attached to exactly one mesh");
+			fs.lumShape[m.lum] = (int32_t) s;
+		}
+		vbase += m.n_verts; tbase += m.n_tris;
+	}
+	fs.shapeTriOffset[nShapes] = tbase;
+
+	// kd-tree + TriAccel table (ShapeKDTree::build, skdtree.cpp:62-101)
+	buildKdTree(fs.vtxPos.data(), fs.triIdx.data(), tbase, kp, fs.kd);
+	for (uint32_t s = 0; s < nShapes; ++s)
+		for (uint32_t t = fs.shapeTriOffset[s]; t < fs.shapeTriOffset[s + 1]; ++t) {
+			const uint32_t *tri = &fs.triIdx[3 * (size_t) t];
+			uint32_t *ta = &fs.triaccel[12 * (size_t) t];
+			triAccelLoad(ld3(&fs.vtxPos[3 * (size_t) tri[0]]), ld3(&fs.vtxPos[3 * (size_t) tri[1]]), ld3(&fs.vtxPos[3 * (size_t) tri[2]]), ta);
+			ta[10] = s;
+			ta[11] = t - fs.shapeTriOffset[s];
+		}
+
+	// AABB::getBSphere of the enlarged tree box (aabb.cpp:44-47)
+	const V3 bmin = ld3(fs.kd.aabbMin), bmax = ld3(fs.kd.aabbMax);
+	const V3 center = (bmax + bmin) * 0.5f;
+	const float radius = length(center - bmax);
+
+	// per-emitter triangle CDFs (TriMesh::configure, trimesh.cpp:279-283)
+	uint32_t cdfTotal = 0;
+	for (uint32_t l = 0; l < nLums; ++l) {
+		fs.lumCdfOffset[l] = cdfTotal;
+		if (fs.lumType[l] == MTSGPU_LUM_AREA) {
+			if (fs.lumShape[l] < 0)
+				throw std::runtime_error("flatten: area luminaire without a mesh");
+			const uint32_t s = (uint32_t) fs.lumShape[l];
+			cdfTotal += fs.shapeTriOffset[s + 1] - fs.shapeTriOffset[s] + 1;
+		}
+	}
+	fs.lumCdfOffset[nLums] = cdfTotal;
+	fs.lumTriCdf.assign((size_t) cdfTotal + 1, 0.0f);
+	int32_t background = -1;
+	for (uint32_t l = 0; l < nLums; ++l) {
+		float *P = &fs.lumParams[(size_t) MTSGPU_LUM_NPARAMS * l];
+		if (fs.lumType[l] == MTSGPU_LUM_AREA) {
+			const uint32_t s = (uint32_t) fs.lumShape[l];
+			const uint32_t t0 = fs.shapeTriOffset[s], n = fs.shapeTriOffset[s + 1] - t0;
+			std::vector<float> areas(n);
+			for (uint32_t t = 0; t < n; ++t) {
+				// Triangle::surfaceArea (triangle.cpp:49-55)
+				const uint32_t *tri = &fs.triIdx[3 * ((size_t) t0 + t)];
+				const V3 p0 = ld3(&fs.vtxPos[3 * (size_t) tri[0]]);
+				const V3 sideA = ld3(&fs.vtxPos[3 * (size_t) tri[1]]) - p0, sideB = ld3(&fs.vtxPos[3 * (size_t) tri[2]]) - p0;
+				areas[t] = 0.5f * length(cross(sideA, sideB));
+			}
+			const float surfaceArea = buildCdf(areas, &fs.lumTriCdf[fs.lumCdfOffset[l]], nullptr);
+			fs.lumInvArea[l] = 1.0f / surfaceArea;
+		} else if (fs.lumType[l] == MTSGPU_LUM_CONSTANT) {
+			// ConstantLuminaire::preprocess (src/luminaires/constant.cpp:49-63)
+			float br = radius;
+			br *= 1.01f;
+			if (d.has_camera) {
+				const float old = br;
+				br = std::max(br, length(ld3(d.camera_pos) - center));
+				if (old != br)
+					br *= 1.01f;
+			}
+			P[3] = center.x; P[4] = center.y; P[5] = center.z; P[6] = br;
+			background = (int32_t) l;
+		} else {
+			throw std::runtime_error("flatten: unknown luminaire type");
+		}
+	}
+	// Scene::initialize: luminaire selection PDF, weight getSamplingWeight() = 1 (scene.cpp:320-330)
+	float selSum = 0.0f;
+	if (nLums > 0) {
+		std::vector<float> w(nLums, 1.0f);
+		selSum = buildCdf(w, fs.lumSelCdf.data(), fs.lumSelPdf.data());
+	}
+
+	mtsgpu_scene &sc = fs.sc;
+	std::memset(&sc, 0, sizeof(sc));
+	sc.abi_version = MTSGPU_ABI_VERSION;
+	sc.n_shapes = nShapes; sc.n_tris = tbase; sc.n_verts = vbase;
+	sc.vtx_pos = fs.vtxPos.data(); sc.vtx_nrm = fs.vtxNrm.data(); sc.tri_idx = fs.triIdx.data();
+	sc.shape_tri_offset = fs.shapeTriOffset.data(); sc.shape_bsdf = fs.shapeBsdf.data();
+	sc.shape_lum = fs.shapeLum.data(); sc.shape_flags = fs.shapeFlags.data();
+	sc.n_nodes = (uint32_t) (fs.kd.nodes.size() / 2); sc.n_indices = (uint32_t) fs.kd.indices.size();
+	if (fs.kd.indices.empty()) fs.kd.indices.push_back(0);
+	sc.kd_nodes = fs.kd.nodes.data(); sc.kd_indices = fs.kd.indices.data(); sc.triaccel = fs.triaccel.data();
+	for (int a = 0; a < 3; ++a) { sc.aabb_min[a] = fs.kd.aabbMin[a]; sc.aabb_max[a] = fs.kd.aabbMax[a]; }
+	sc.n_bsdfs = d.n_bsdfs; sc.bsdf_type = fs.bsdfType.data(); sc.bsdf_params = fs.bsdfParams.data();
+	sc.n_lums = nLums; sc.lum_type = fs.lumType.data(); sc.lum_params = fs.lumParams.data();
+	sc.lum_shape = fs.lumShape.data(); sc.lum_inv_area = fs.lumInvArea.data();
+	sc.lum_cdf_offset = fs.lumCdfOffset.data(); sc.lum_tri_cdf = fs.lumTriCdf.data();
+	sc.lum_sel_cdf = fs.lumSelCdf.data(); sc.lum_sel_pdf = fs.lumSelPdf.data();
+	sc.lum_sel_sum = selSum;
+	sc.background_lum = background;
+}
+
+// ---------------------------------------------------------------------------
+// Camera: Transform algebra of src/libcore/transform.cpp with the generic
+// Gauss-Jordan Matrix::invert (include/mitsuba/core/matrix.inl:140-190)
+// ---------------------------------------------------------------------------
+namespace {
+
+struct M4 { float m[4][4]; };
+struct Xf { M4 fwd, inv; };
+
+M4 mul(const M4 &a, const M4 &b) {
+	M4 r;
+	for (int i = 0; i < 4; ++i)
+		for (int j = 0; j < 4; ++j) {
+			float sum = 0;
+			for (int k = 0; k < 4; ++k)
+				sum += a.m[i][k] * b.m[k][j];
+			r.m[i][j] = sum;
+		}
+	return r;
+}
+
+bool invert(const M4 &src, M4 &t) {
+	int indxc[4], indxr[4], ipiv[4] = { 0, 0, 0, 0 };
+	t = src;
+	for (int i = 0; i < 4; i++) {
+		int irow = -1, icol = -1;
+		float big = 0;
+		for (int j = 0; j < 4; j++) {
+			if (ipiv[j] == 1) continue;
+			for (int k = 0; k < 4; k++) {
+				if (ipiv[k] == 0) {
+					if (std::abs(t.m[j][k]) >= big) { big = std::abs(t.m[j][k]); irow = j; icol = k; }
+				} else if (ipiv[k] > 1) {
+					return false;
+				}
+			}
+		}
+		++ipiv[icol];
+		if (irow != icol)
+			for (int k = 0; k < 4; ++k) std::swap(t.m[irow][k], t.m[icol][k]);
+		indxr[i] = irow; indxc[i] = icol;
+		if (t.m[icol][icol] == 0)
+			return false;
+		const float pivinv = 1.f / t.m[icol][icol];
+		t.m[icol][icol] = 1.f;
+		for (int j = 0; j < 4; j++) t.m[icol][j] *= pivinv;
+		for (int j = 0; j < 4; j++) {
+			if (j == icol) continue;
+			const float save = t.m[j][icol];
+			t.m[j][icol] = 0;
+			for (int k = 0; k < 4; k++) t.m[j][k] -= t.m[icol][k] * save;
+		}
+	}
+	for (int j = 3; j >= 0; j--)
+		if (indxr[j] != indxc[j])
+			for (int k = 0; k < 4; k++) std::swap(t.m[k][indxr[j]], t.m[k][indxc[j]]);
+	return true;
+}
+
+Xf operator*(const Xf &a, const Xf &b) { return Xf{ mul(a.fwd, b.fwd), mul(b.inv, a.inv) }; }   // transform.cpp:28-31
+Xf inverse(const Xf &a) { return Xf{ a.inv, a.fwd }; }
+Xf translate(float x, float y, float z) {                                                       // transform.cpp:33-47
+	return Xf{ M4{ { { 1, 0, 0, x }, { 0, 1, 0, y }, { 0, 0, 1, z }, { 0, 0, 0, 1 } } },
+	           M4{ { { 1, 0, 0, -x }, { 0, 1, 0, -y }, { 0, 0, 1, -z }, { 0, 0, 0, 1 } } } };
+}
+Xf scale(float x, float y, float z) {                                                           // transform.cpp:49-63
+	return Xf{ M4{ { { x, 0, 0, 0 }, { 0, y, 0, 0 }, { 0, 0, z, 0 }, { 0, 0, 0, 1 } } },
+	           M4{ { { 1.0f / x, 0, 0, 0 }, { 0, 1.0f / y, 0, 0 }, { 0, 0, 1.0f / z, 0 }, { 0, 0, 0, 1 } } } };
+}
+
+} // namespace
+
+void makeCamera(const float origin[3], const float target[3], const float up[3], float fovDeg, int width, int height,
+                mtsgpu_camera &out) {
+	// Transform::lookAt (transform.cpp:174-190): columns right, newUp, dir, p
+	const V3 p = ld3(origin);
+	const V3 dir = normalize(ld3(target) - p);
+	const V3 right = normalize(cross(dir, ld3(up)));
+	const V3 newUp = cross(right, dir);
+	const float c2w[16] = { right.x, newUp.x, dir.x, p.x,  right.y, newUp.y, dir.y, p.y,
+	                        right.z, newUp.z, dir.z, p.z,  0, 0, 0, 1 };
+	const float nearClip = 1e-2f, farClip = 1e4f;                                               // camera.cpp:121-123
+	const float aspect = (float) width / (float) height;
+	// PerspectiveCameraImpl::configure (perspective.cpp:43-71), mapSmallerSide = true
+	Xf screenToRaster;
+	if (aspect >= 1.0f)
+		screenToRaster = scale((float) width, (float) height, 1.0f) * scale(1 / (2 * aspect), -0.5f, 1.0f) * translate(aspect, -1.0f, 0);
+	else
+		screenToRaster = scale((float) width, (float) height, 1.0f) * scale(0.5f, -0.5f * aspect, 1.0f) * translate(1.0f, -1 / aspect, 0);
+	// Transform::perspective (transform.cpp:100-124)
+	const float recip = 1.0f / (farClip - nearClip);
+	Xf persp;
+	persp.fwd = M4{ { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, farClip * recip, -nearClip * farClip * recip }, { 0, 0, 1, 0 } } };
+	invert(persp.fwd, persp.inv);
+	const float cot = 1.0f / std::tan((fovDeg / 2.0f) * (kPi / 180.0f));
+	const Xf cameraToScreen = scale(cot, cot, 1.0f) * persp;
+	const Xf rasterToCamera = inverse(cameraToScreen) * inverse(screenToRaster);
+	std::memcpy(out.raster_to_camera, rasterToCamera.fwd.m, sizeof(float) * 16);
+	std::memcpy(out.camera_to_world, c2w, sizeof(float) * 16);
+	out.near_clip = nearClip; out.far_clip = farClip;
+	out.width = width; out.height = height;
+}
+
+} // namespace mg

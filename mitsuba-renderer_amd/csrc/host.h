@@ -1,0 +1,35 @@
+// host.h -- host-side pieces of libmtsgpu shared between translation units.
+#pragma once
+#include "../../include/mtsgpu.h"
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mg {
+
+struct KdTree {
+	std::vector<uint32_t> nodes;      // 2 dwords per node
+	std::vector<uint32_t> indices;
+	float aabbMin[3] = { 0, 0, 0 }, aabbMax[3] = { 0, 0, 0 };
+	double stats[6] = { 0, 0, 0, 0, 0, 0 };
+};
+
+void buildKdTree(const float *vtx, const uint32_t *tri, uint32_t nTris, const mtsgpu_kd_params *kp, KdTree &out);
+bool clippedTriangleBox(const float *p0, const float *p1, const float *p2, const float *bmin, const float *bmax,
+                        float *omin, float *omax);
+
+// Owns every array a mtsgpu_scene points to
+struct FlatScene {
+	mtsgpu_scene sc;
+	KdTree kd;
+	std::vector<float> vtxPos, vtxNrm, bsdfParams, lumParams, lumInvArea, lumTriCdf, lumSelCdf, lumSelPdf;
+	std::vector<uint32_t> triIdx, shapeTriOffset, shapeFlags, triaccel, bsdfType, lumType, lumCdfOffset;
+	std::vector<int32_t> shapeBsdf, shapeLum, lumShape;
+};
+
+void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatScene &fs);
+void makeCamera(const float origin[3], const float target[3], const float up[3], float fovDeg, int width, int height,
+                mtsgpu_camera &out);
+
+} // namespace mg

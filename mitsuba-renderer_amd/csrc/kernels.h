@@ -1,0 +1,102 @@
+// kernels.h -- device-side data layout and launch wrappers of the wavefront path tracer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mg {
+
+constexpr int kNumBins = 5;           // 4 BSDF types + "terminal" (miss / no BSDF)
+constexpr int kTraceBlock = 256;
+constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
+
+// Scene in HBM (all pointers are device pointers); see DESIGN.md section 3
+struct DScene {
+	const uint2    *nodes;        // KDNode, 8 B
+	const uint32_t *indices;
+	const uint4    *triaccel;     // 3 x 16 B per primitive; dword 10 bit31 = "not an occluder"
+	const float    *vtx_pos, *vtx_nrm;
+	const uint32_t *tri_idx;
+	const int32_t  *shape_bsdf, *shape_lum;
+	const uint32_t *shape_flags, *shape_tri_offset;
+	const uint32_t *bsdf_type;
+	const float    *bsdf_params;
+	const uint32_t *lum_type;
+	const float    *lum_params;
+	const int32_t  *lum_shape;
+	const float    *lum_inv_area;
+	const uint32_t *lum_cdf_offset;
+	const float    *lum_tri_cdf, *lum_sel_cdf, *lum_sel_pdf;
+	float lum_sel_sum;
+	int32_t background_lum;
+	uint32_t n_lums, n_nodes, n_tris, n_shapes;
+	float aabb_min[3], aabb_max[3];
+};
+
+// Per-path state, SoA, indexed by path id (paths never move; queues hold ids)
+struct DPaths {
+	float4 *ray_o;   // o.xyz, mint
+	float4 *ray_d;   // d.xyz, maxt
+	uint4  *hit;     // t bits, u bits, v bits, prim (kNoPrim = miss)
+	float4 *thr;     // throughput rgb, w = depth (int bits)
+	float4 *Li;      // Li rgb, w = flags (uint bits)
+	float4 *bsdf;    // bsdfVal/pdf rgb, w = bsdfPdf
+	float4 *nee;     // pending direct-light contribution rgb
+	float4 *sh_o;    // shadow ray origin p1
+	float4 *sh_d;    // shadow ray direction p2 - p1 (unnormalised)
+	uint2  *rng;     // keyed overflow stream state
+	float2 *spos;    // raster position of the camera sample
+	uint32_t *pix;   // pixel key y*W+x
+	uint32_t *smp;   // sample index within the pixel
+};
+
+// flags in Li.w
+enum : uint32_t {
+	F_EMITTED = 1u,       // rRec.type & EEmittedRadiance
+	F_FIRST   = 2u,       // camera ray not yet processed
+	F_ALPHA   = 4u,       // rRec.alpha == 1
+	F_D1_SHIFT = 8, F_D2_SHIFT = 16, F_ST_SHIFT = 24
+};
+
+struct DConfig {
+	float r2c[16], c2w[16];       // rasterToCamera, cameraToWorld (row major)
+	float near_clip, far_clip;
+	int32_t width, height;
+	int32_t max_depth, rr_depth, strict_normals;
+	int32_t sampler_kind;
+	uint32_t spp; int32_t ld_depth;
+	uint64_t seed;
+	int32_t slot_per_path;        // 1: one sampler slot per path (explicit sample lists)
+	const uint32_t *ld_scr;       // [slot][3*ld_depth]
+	const uint16_t *ld_perm;      // [slot][2*ld_depth][spp]
+};
+
+struct DQueues {
+	uint32_t *bins[kNumBins];     // per-material queues written by the closest-hit kernel
+	uint32_t *next;               // paths that continue (input of the next closest-hit launch)
+	uint32_t *shadow;             // paths with a pending shadow ray
+	uint32_t *counters;           // [0..4] bins, [5] next, [6] shadow
+	unsigned long long *trace_counts;  // n_inner, n_leaf, n_idx, n_tri_tested (u64 x 4)
+	uint32_t *spill;              // traversal stack overflow: [level][thread]
+	uint32_t spill_stride;
+};
+
+// --- launchers (kernels.hip) -------------------------------------------------
+void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_keys, uint32_t n_slots,
+                      uint32_t *scr, uint16_t *perm);
+void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg,
+                     const uint32_t *pixel_list, uint32_t n_slots, const uint32_t *explicit_samples,
+                     uint32_t n_paths, uint32_t *queue);
+// mode 0: closest hit over ps.ray_* (writes ps.hit, bins ids by material)
+// mode 1: shadow rays over ps.sh_* (adds ps.nee to ps.Li when unoccluded)
+// mode 2: any-hit over ps.ray_* (writes ps.hit.w = occluded) -- test/benchmark API
+void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
+                  const DQueues &q, const uint32_t *queue, uint32_t n);
+void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
+                  const DQueues &q, uint32_t n);
+void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,
+                       uint32_t spp_per_slot, float *film);
+void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, size_t n);
+void launch_iota(hipStream_t s, uint32_t *p, uint32_t n);
+size_t trace_spill_levels();
+
+} // namespace mg

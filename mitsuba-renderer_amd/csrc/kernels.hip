@@ -1,0 +1,1061 @@
+// kernels.hip -- gfx950 kernels of the wavefront path tracer.
+//
+// One path per lane; paths never move in memory, per-bounce queues of path ids
+// are compacted and material-sorted with wave ballots + prefix popcounts.
+// Stage order per bounce (MIPathTracer::Li, src/integrators/path/path.cpp:47-216):
+//   k_trace<closest>  ->  k_shade<bsdf type>  ->  k_trace<shadow>  ->  (next bounce)
+#include "kernels.h"
+#include "devmath.h"
+
+namespace mg {
+
+// ===========================================================================
+// small helpers
+// ===========================================================================
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// Wave-aggregated append: every lane with pred gets a unique slot; one atomic per wave.
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t *counter) {
+	const unsigned long long mask = __ballot(pred);
+	if (mask == 0ull)
+		return 0u;
+	const uint32_t lane = lane_id();
+	const uint32_t rank = (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+	const int leader = __ffsll((long long) mask) - 1;
+	uint32_t base = 0;
+	if ((int) lane == leader)
+		base = atomicAdd(counter, (uint32_t) __popcll(mask));
+	base = __shfl(base, leader);
+	return base + rank;
+}
+
+__device__ __forceinline__ float sel3(float x, float y, float z, int axis) {
+	return axis == 0 ? x : (axis == 1 ? y : z);
+}
+
+__global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
+	size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) p[i] = v;
+}
+__global__ void k_iota(uint32_t *p, uint32_t n) {
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) p[i] = i;
+}
+
+// ===========================================================================
+// K0: LowDiscrepancySampler::generate() per pixel (src/samplers/ldsampler.cpp:125-158)
+// with the keyed stream in place of Random.  One lane per pixel slot; the
+// Sattolo-style shuffle of Random::shuffle (random.h:145-148) is sequential.
+// The tables hold the permutation; values are f(perm[j]) at lookup time.
+// ===========================================================================
+__global__ void k_ld_tables(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_slots,
+                            uint32_t *scr, uint16_t *perm) {
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= n_slots)
+		return;
+	const uint32_t spp = cfg.spp;
+	const int depth = cfg.ld_depth;
+	uint64_t st = keyedInit(cfg.seed, pixel_keys[slot], 0);
+	uint32_t *s = scr + (size_t) slot * 3 * depth;
+	uint16_t *pbase = perm + (size_t) slot * 2 * depth * spp;
+	for (int i = 0; i < depth; ++i) {
+		// generate1D
+		uint16_t *p = pbase + (size_t) (2 * i) * spp;
+		s[i * 3 + 0] = (uint32_t) (keyedNext(st) & 0xFFFFFFFFull);
+		for (uint32_t k = 0; k < spp; ++k) p[k] = (uint16_t) k;
+		for (uint32_t it = spp - 1; it > 0; --it) {
+			uint32_t other = (uint32_t) keyedNextSize(st, it);
+			uint16_t a = p[it], b = p[other];
+			p[it] = b; p[other] = a;
+		}
+		// generate2D: one 64-bit draw, dword[0] = low half, dword[1] = high half
+		p = pbase + (size_t) (2 * i + 1) * spp;
+		uint64_t q = keyedNext(st);
+		s[i * 3 + 1] = (uint32_t) (q & 0xFFFFFFFFull);
+		s[i * 3 + 2] = (uint32_t) (q >> 32);
+		for (uint32_t k = 0; k < spp; ++k) p[k] = (uint16_t) k;
+		for (uint32_t it = spp - 1; it > 0; --it) {
+			uint32_t other = (uint32_t) keyedNextSize(st, it);
+			uint16_t a = p[it], b = p[other];
+			p[it] = b; p[other] = a;
+		}
+	}
+}
+
+// ===========================================================================
+// Sampler::next1D / next2D (independent.cpp:72-81, ldsampler.cpp:172-186)
+// ===========================================================================
+struct PathSampler {
+	uint64_t stream;
+	uint32_t slot, j;
+	uint32_t d1, d2;
+};
+
+__device__ __forceinline__ float sampler_next1d(const DConfig &cfg, PathSampler &s) {
+	if (cfg.sampler_kind == 1 && (int) s.d1 < cfg.ld_depth) {
+		const int i = (int) s.d1++;
+		const uint32_t k = cfg.ld_perm[((size_t) s.slot * 2 * cfg.ld_depth + 2 * i) * cfg.spp + s.j];
+		return u32ToUnit(vdcBits(k, cfg.ld_scr[(size_t) s.slot * 3 * cfg.ld_depth + i * 3 + 0]));
+	}
+	return ulongToFloat(keyedNext(s.stream));
+}
+
+__device__ __forceinline__ void sampler_next2d(const DConfig &cfg, PathSampler &s, float &x, float &y) {
+	if (cfg.sampler_kind == 1 && (int) s.d2 < cfg.ld_depth) {
+		const int i = (int) s.d2++;
+		const uint32_t k = cfg.ld_perm[((size_t) s.slot * 2 * cfg.ld_depth + 2 * i + 1) * cfg.spp + s.j];
+		const uint32_t *scr = cfg.ld_scr + (size_t) s.slot * 3 * cfg.ld_depth + i * 3;
+		x = u32ToUnit(vdcBits(k, scr[1]));
+		y = u32ToUnit(sobol2Bits(k, scr[2]));
+		return;
+	}
+	// x first, then y (independent.cpp:76-81)
+	x = ulongToFloat(keyedNext(s.stream));
+	y = ulongToFloat(keyedNext(s.stream));
+}
+
+// ===========================================================================
+// K1: camera samples (integrator.cpp:154-166, perspective.cpp:77-112)
+// ===========================================================================
+__global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pixel_list, uint32_t n_slots,
+                           const uint32_t *explicit_samples, uint32_t n_paths, uint32_t *queue) {
+	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= n_paths)
+		return;
+	uint32_t slot, j, pixel;
+	if (explicit_samples) {
+		slot = id;
+		pixel = explicit_samples[3 * (size_t) id + 1] * (uint32_t) cfg.width + explicit_samples[3 * (size_t) id];
+		j = explicit_samples[3 * (size_t) id + 2];
+	} else {
+		slot = id / cfg.spp;
+		j = id - slot * cfg.spp;
+		pixel = pixel_list[slot];
+	}
+	const uint32_t px = pixel % (uint32_t) cfg.width, py = pixel / (uint32_t) cfg.width;
+
+	PathSampler smp;
+	smp.stream = keyedInit(cfg.seed, pixel, 1 + (uint64_t) j);
+	smp.slot = slot; smp.j = j; smp.d1 = 0; smp.d2 = 0;
+	float sx, sy;
+	sampler_next2d(cfg, smp, sx, sy);
+	sx += (float) px; sy += (float) py;
+
+	// m_rasterToCamera(Point(sx, sy, 0)) with the homogeneous divide (transform.h:133-149)
+	const float *m = cfg.r2c;
+	float ix = m[0] * sx + m[1] * sy + m[2] * 0.0f + m[3];
+	float iy = m[4] * sx + m[5] * sy + m[6] * 0.0f + m[7];
+	float iz = m[8] * sx + m[9] * sy + m[10] * 0.0f + m[11];
+	float iw = m[12] * sx + m[13] * sy + m[14] * 0.0f + m[15];
+	V3 ic(ix, iy, iz);
+	if (iw != 1.0f)
+		ic = divs(ic, iw);
+	V3 ld = normalize(ic);
+	float invZ = 1.0f / ld.z;
+	float mint = cfg.near_clip * invZ, maxt = cfg.far_clip * invZ;
+	// m_cameraToWorld(localRay, ray) (transform.h:219-235)
+	const float *w = cfg.c2w;
+	V3 o(w[0] * 0.0f + w[1] * 0.0f + w[2] * 0.0f + w[3],
+	     w[4] * 0.0f + w[5] * 0.0f + w[6] * 0.0f + w[7],
+	     w[8] * 0.0f + w[9] * 0.0f + w[10] * 0.0f + w[11]);
+	float ow = w[12] * 0.0f + w[13] * 0.0f + w[14] * 0.0f + w[15];
+	if (ow != 1.0f)
+		o = divs(o, ow);
+	V3 d(w[0] * ld.x + w[1] * ld.y + w[2] * ld.z,
+	     w[4] * ld.x + w[5] * ld.y + w[6] * ld.z,
+	     w[8] * ld.x + w[9] * ld.y + w[10] * ld.z);
+
+	ps.ray_o[id] = make_float4(o.x, o.y, o.z, mint);
+	ps.ray_d[id] = make_float4(d.x, d.y, d.z, maxt);
+	ps.thr[id] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(1));   // depth = 1 (integrator.h:186-191)
+	const uint32_t flags = F_EMITTED | F_FIRST | (smp.d1 << F_D1_SHIFT) | (smp.d2 << F_D2_SHIFT);
+	ps.Li[id] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(flags));
+	ps.rng[id] = make_uint2((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32));
+	ps.spos[id] = make_float2(sx, sy);
+	ps.pix[id] = pixel;
+	ps.smp[id] = j;
+	queue[id] = id;
+}
+
+// ===========================================================================
+// K2/K4: kd-tree traversal.
+// ShapeKDTree::rayIntersect (src/librender/skdtree.cpp:108-132, :180-199) +
+// rayIntersectHavran<shadow> (include/mitsuba/render/sahkdtree3.h:170-300) +
+// TriAccel::rayIntersect (include/mitsuba/render/triaccel.h:98-159).
+//
+// Havran's stack of exit points is a LIFO once the entry point is kept in
+// registers.  An exit point is (far child, t, axis, split)
+// and all four are functions of (parent node, ray), so the stack stores ONE dword
+// per level: parent index * 2 + "far child is the right one".  The top exit
+// point lives in registers; deeper levels sit in LDS ([level][lane], conflict
+// free), levels beyond kStackLDS spill to HBM.  The 8-entry hashed mailbox
+// (sahkdtree3.h:130-144) is kept (LDS) because it decides equal-t ties.
+// ===========================================================================
+constexpr int kStackLDS = 24;
+constexpr int kSpillLevels = 32;      // 24 + 32 >= MTS_KD_MAXDEPTH (48) + 2
+constexpr uint32_t kSentinel = 0xFFFFFFFFu;
+constexpr uint32_t kNullNode = 0xFFFFFFFFu;
+
+size_t trace_spill_levels() { return kSpillLevels; }
+
+template <int MODE, bool COUNT, bool BIN>
+__global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, DPaths ps, DQueues q,
+                                                       const uint32_t *queue, uint32_t n) {
+	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
+	__shared__ uint32_t s_mbox[8][kTraceBlock];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t gtid = blockIdx.x * kTraceBlock + tid;
+	const bool active = gtid < n;
+	const uint32_t id = active ? queue[gtid] : 0u;
+
+	float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, rmint = 0, rmaxt = 0;
+	if (active) {
+		float4 a, b;
+		if (MODE == 1) {
+			a = ps.sh_o[id]; b = ps.sh_d[id];
+			rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
+		} else {
+			a = ps.ray_o[id]; b = ps.ray_d[id];
+			rmint = a.w; rmaxt = b.w;
+		}
+		ox = a.x; oy = a.y; oz = a.z; dx = b.x; dy = b.y; dz = b.z;
+	}
+	// Ray::dRcp (ray.h:63-74)
+	const float rx = 1.0f / dx, ry = 1.0f / dy, rz = 1.0f / dz;
+
+	// --- AABB::rayIntersect (aabb.h:349-382) + adaptive epsilon (skdtree.cpp:114-122) ---
+	bool go = active;
+	float mint = -MG_INF, maxt = MG_INF;
+	#pragma unroll
+	for (int i = 0; i < 3; ++i) {
+		const float direction = sel3(dx, dy, dz, i), origin = sel3(ox, oy, oz, i);
+		const float minVal = sc.aabb_min[i], maxVal = sc.aabb_max[i];
+		if (direction == 0) {
+			if (origin < minVal || origin > maxVal) go = false;
+		} else {
+			const float rc = sel3(rx, ry, rz, i);
+			float t1 = (minVal - origin) * rc, t2 = (maxVal - origin) * rc;
+			if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
+			mint = smax(mint, t1);
+			maxt = smin(maxt, t2);
+			if (mint > maxt) go = false;
+		}
+	}
+	{
+		float rayMinT = rmint;
+		if (rayMinT == kEpsilon) {
+			float m = smax(smax(fabsf(ox), fabsf(oy)), fabsf(oz));
+			if (MODE == 0) m = smax(m, kEpsilon);    // only the (ray, its) variant has the inner max
+			rayMinT *= m;
+		}
+		if (rayMinT > mint) mint = rayMinT;
+		if (rmaxt < maxt) maxt = rmaxt;
+		if (!(maxt > mint)) go = false;
+	}
+
+	float best_t = MG_INF, best_u = 0, best_v = 0;
+	uint32_t best_prim = kNoPrim, best_shape = 0;
+	bool found = false;
+	uint32_t c_inner = 0, c_leaf = 0, c_idx = 0, c_tri = 0;
+
+	if (go) {
+		#pragma unroll
+		for (int i = 0; i < 8; ++i) s_mbox[i][tid] = 0xFFFFFFFFu;
+
+		// entry point (stack[enPt]) and current exit point (stack[exPt]) in registers
+		float en_t = mint, en_split = 0.0f; int en_axis = 3;
+		const float tmax0 = maxt;
+		float ex_t = maxt, ex_split = 0.0f; int ex_axis = 3;
+		uint32_t ex_node = kNullNode, ex_ref = kSentinel;
+		int sp = 0;
+		uint32_t cur = 0;
+
+		while (true) {
+			uint2 nd = sc.nodes[cur];
+			while (!(nd.x & 0x80000000u)) {
+				const float split = __uint_as_float(nd.y);
+				const int axis = (int) (nd.x & 3u);
+				const uint32_t left = cur + ((nd.x & 0x3FFFFFFCu) >> 2);
+				if (COUNT) c_inner++;
+				const float oa = sel3(ox, oy, oz, axis), da = sel3(dx, dy, dz, axis);
+				// stack[].p[axis]: ray(t) with the pushed axis overwritten by its split (sahkdtree3.h:248-249)
+				const float pen = (axis == en_axis) ? en_split : (oa + en_t * da);
+				const float pex = (axis == ex_axis) ? ex_split : (oa + ex_t * da);
+				uint32_t farRight;
+				if (pen <= split) {
+					if (pex <= split) { cur = left; nd = sc.nodes[cur]; continue; }         // N1-N3, P5, Z2, Z3
+					if (pen == split) { cur = left + 1; nd = sc.nodes[cur]; continue; }     // Z1
+					farRight = 1u;                                                          // N4
+				} else {
+					if (split < pex) { cur = left + 1; nd = sc.nodes[cur]; continue; }      // P1-P3, N5
+					farRight = 0u;                                                          // P4
+				}
+				const float distToSplit = (split - oa) * sel3(rx, ry, rz, axis);
+				// push the current exit point's reference, make (cur, far) the new exit point
+				if (sp < kStackLDS) s_stack[sp][tid] = ex_ref;
+				else q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref;
+				++sp;
+				ex_ref = (cur << 1) | farRight;
+				ex_t = distToSplit; ex_axis = axis; ex_split = split;
+				ex_node = left + farRight;
+				cur = left + (1u - farRight);
+				nd = sc.nodes[cur];
+			}
+
+			// --- leaf: test the primitives (sahkdtree3.h:262-288, skdtree.h:244-336) ---
+			if (COUNT) c_leaf++;
+			bool hitShadow = false;
+			for (uint32_t e = nd.x & 0x7FFFFFFFu, last = nd.y; e != last; ++e) {
+				const uint32_t prim = sc.indices[e];
+				if (COUNT) c_idx++;
+				if (s_mbox[prim & 7u][tid] == prim)
+					continue;
+				if (COUNT) c_tri++;
+				const uint4 *ta = sc.triaccel + 3 * (size_t) prim;
+				const uint4 A = ta[0], B = ta[1], C = ta[2];
+				const float n_u = __uint_as_float(A.y), n_v = __uint_as_float(A.z), n_d = __uint_as_float(A.w);
+				const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
+				const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
+				const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
+				float o_u, o_v, o_k, d_u, d_v, d_k;
+				bool ok = true;
+				if (A.x == 0u) { o_u = oy; o_v = oz; o_k = ox; d_u = dy; d_v = dz; d_k = dx; }
+				else if (A.x == 1u) { o_u = oz; o_v = ox; o_k = oy; d_u = dz; d_v = dx; d_k = dy; }
+				else if (A.x == 2u) { o_u = ox; o_v = oy; o_k = oz; d_u = dx; d_v = dy; d_k = dz; }
+				else { ok = false; o_u = o_v = o_k = d_u = d_v = d_k = 0.0f; }
+				if (MODE != 0 && (C.z & 0x80000000u)) ok = false;    // shape->isOccluder() (skdtree.h:318-333)
+				if (ok) {
+					const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
+					const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
+					if (!(t < mint || t > maxt)) {
+						const float hu = o_u + t * d_u - a_u;
+						const float hv = o_v + t * d_v - a_v;
+						const float u = hv * b_nu + hu * b_nv;
+						const float v = hu * c_nu + hv * c_nv;
+						if (u >= 0 && v >= 0 && u + v <= 1.0f) {
+							if (MODE != 0) { hitShadow = true; break; }
+							maxt = t;          // a later hit with equal t replaces this one (t > maxt rejects)
+							best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = C.z & 0x7FFFFFFFu;
+							found = true;
+						}
+					}
+				}
+				s_mbox[prim & 7u][tid] = prim;
+			}
+			if (hitShadow) { found = true; break; }
+
+			if (ex_t > maxt)
+				break;
+			// --- pop: the exit point becomes the entry point ---
+			en_t = ex_t; en_axis = ex_axis; en_split = ex_split;
+			cur = ex_node;
+			if (cur == kNullNode)
+				break;
+			--sp;
+			const uint32_t ref = (sp < kStackLDS) ? s_stack[sp][tid]
+			                                      : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
+			if (ref == kSentinel) {
+				ex_t = tmax0; ex_axis = 3; ex_split = 0.0f; ex_node = kNullNode; ex_ref = kSentinel;
+			} else {
+				const uint32_t parent = ref >> 1;
+				const uint2 pn = sc.nodes[parent];
+				const int axis = (int) (pn.x & 3u);
+				const float split = __uint_as_float(pn.y);
+				ex_node = parent + ((pn.x & 0x3FFFFFFCu) >> 2) + (ref & 1u);
+				ex_t = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
+				ex_axis = axis; ex_split = split; ex_ref = ref;
+			}
+		}
+	}
+
+	// --- epilogue ---
+	if (MODE == 0) {
+		int bin = -1;
+		if (active) {
+			ps.hit[id] = make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim);
+			if (BIN) {
+				bin = kNumBins - 1;
+				if (found) {
+					const int b = sc.shape_bsdf[best_shape];
+					if (b >= 0) bin = (int) sc.bsdf_type[b];
+				}
+			}
+		}
+		if (BIN) {
+			// material sort: one ballot + prefix popcount per bin, one atomic per wave and bin
+			#pragma unroll
+			for (int b = 0; b < kNumBins; ++b) {
+				const bool mine = (bin == b);
+				const uint32_t pos = wave_append(mine, &q.counters[b]);
+				if (mine) q.bins[b][pos] = id;
+			}
+		}
+	} else if (MODE == 1) {
+		// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
+		if (active && !found) {
+			float4 L = ps.Li[id];
+			const float4 c = ps.nee[id];
+			L.x += c.x; L.y += c.y; L.z += c.z;
+			ps.Li[id] = L;
+		}
+	} else {
+		if (active)
+			ps.hit[id] = make_uint4(0u, 0u, 0u, found ? 1u : 0u);
+	}
+
+	if (COUNT) {
+		// wave reduction, then one atomic per wave and counter
+		unsigned long long v[4] = { c_inner, c_leaf, c_idx, c_tri };
+		#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			unsigned long long x = v[k];
+			for (int off = 32; off > 0; off >>= 1)
+				x += __shfl_down(x, off);
+			if (lane_id() == 0)
+				atomicAdd(&q.trace_counts[k], x);
+		}
+	}
+}
+
+// ===========================================================================
+// Intersection record, luminaires, BSDFs
+// ===========================================================================
+struct Its {
+	V3 p, geoN, shS, shT, shN, wi;
+	uint32_t shape;
+};
+
+// fillIntersectionRecord<true> (include/mitsuba/render/skdtree.h:352-432)
+__device__ __forceinline__ void fill_its(const DScene &sc, V3 rayD, uint32_t prim, float u, float v, Its &its) {
+	const uint32_t i0 = sc.tri_idx[3 * (size_t) prim], i1 = sc.tri_idx[3 * (size_t) prim + 1], i2 = sc.tri_idx[3 * (size_t) prim + 2];
+	const float *P = sc.vtx_pos;
+	const V3 p0(P[3 * (size_t) i0], P[3 * (size_t) i0 + 1], P[3 * (size_t) i0 + 2]);
+	const V3 p1(P[3 * (size_t) i1], P[3 * (size_t) i1 + 1], P[3 * (size_t) i1 + 2]);
+	const V3 p2(P[3 * (size_t) i2], P[3 * (size_t) i2 + 1], P[3 * (size_t) i2 + 2]);
+	const float bx = 1 - u - v, by = u, bz = v;
+	its.p = V3(p0.x * bx + p1.x * by + p2.x * bz, p0.y * bx + p1.y * by + p2.y * bz, p0.z * bx + p1.z * by + p2.z * bz);
+	V3 faceNormal = cross(p1 - p0, p2 - p0);
+	const float len = length(faceNormal);
+	if (!isZero(faceNormal))
+		faceNormal = divs(faceNormal, len);
+	its.geoN = faceNormal;
+	its.shape = sc.triaccel[3 * (size_t) prim + 2].z & 0x7FFFFFFFu;
+	if (sc.shape_flags[its.shape] & 1u) {
+		const float *N = sc.vtx_nrm;
+		const V3 n0(N[3 * (size_t) i0], N[3 * (size_t) i0 + 1], N[3 * (size_t) i0 + 2]);
+		const V3 n1(N[3 * (size_t) i1], N[3 * (size_t) i1 + 1], N[3 * (size_t) i1 + 2]);
+		const V3 n2(N[3 * (size_t) i2], N[3 * (size_t) i2 + 1], N[3 * (size_t) i2 + 2]);
+		its.shN = normalize(V3(n0.x * bx + n1.x * by + n2.x * bz, n0.y * bx + n1.y * by + n2.y * bz, n0.z * bx + n1.z * by + n2.z * bz));
+	} else {
+		its.shN = its.geoN;
+	}
+	coordinateSystem(its.shN, its.shS, its.shT);
+	const V3 md = -rayD;
+	its.wi = V3(dot(md, its.shS), dot(md, its.shT), dot(md, its.shN));
+}
+
+struct LRec { V3 p, n, d, value; float pdf; int lum; };
+
+// DiscretePDF::sample / sampleReuse (include/mitsuba/core/pdf.h:102-133)
+__device__ __forceinline__ int dpdf_sample_reuse(const float *cdf, uint32_t n, float &sampleValue) {
+	uint32_t lo = 0, count = n + 1;       // std::lower_bound over n + 1 knots
+	while (count > 0) {
+		const uint32_t step = count / 2, it = lo + step;
+		if (cdf[it] < sampleValue) { lo = it + 1; count -= step + 1; }
+		else count = step;
+	}
+	int index = (int) lo - 1;
+	if (index < 0) index = 0;
+	if (index > (int) n - 1) index = (int) n - 1;
+	sampleValue = (sampleValue - cdf[index]) / (cdf[index + 1] - cdf[index]);
+	return index;
+}
+
+// BSphere::rayIntersect (include/mitsuba/core/bsphere.h:85-118)
+__device__ __forceinline__ bool bsphere_ray_intersect(V3 center, float radius, V3 o, V3 d, float &nearHit, float &farHit) {
+	const V3 originToCenter = center - o;
+	const float distToRayClosest = dot(originToCenter, d);
+	const float tmp1 = dot(originToCenter, originToCenter) - radius * radius;
+	if (tmp1 <= 0.0f) {
+		nearHit = farHit = sqrtf(distToRayClosest * distToRayClosest - tmp1) + distToRayClosest;
+		return true;
+	}
+	if (distToRayClosest < 0.0f)
+		return false;
+	const float sqrOriginToCenterLength = dot(originToCenter, originToCenter);
+	const float sqrHalfChordDist = radius * radius - sqrOriginToCenterLength + distToRayClosest * distToRayClosest;
+	if (sqrHalfChordDist < 0)
+		return false;
+	const float hitDistance = sqrtf(sqrHalfChordDist);
+	nearHit = distToRayClosest - hitDistance;
+	farHit = distToRayClosest + hitDistance;
+	if (nearHit == 0)
+		nearHit = farHit;
+	return true;
+}
+
+// Scene::sampleLuminaire without the visibility test (scene.cpp:396-415):
+// returns true when a shadow ray has to be traced; value is already divided by pdf.
+__device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s0, float s1, LRec &lRec) {
+	float sx = s0, sy = s1;
+	const int l = dpdf_sample_reuse(sc.lum_sel_cdf, sc.n_lums, sx);
+	const float lumPdf = sc.lum_sel_pdf[l];
+	const float *LP = sc.lum_params + 8 * (size_t) l;
+	if (sc.lum_type[l] == 0u) {
+		// AreaLuminaire::sample (area.cpp:68-79) -> Shape::sampleSolidAngle (shape.cpp:65-75)
+		// -> TriMesh::sampleArea (trimesh.cpp:297-302) -> Triangle::sample (triangle.cpp:23-47)
+		const uint32_t s = (uint32_t) sc.lum_shape[l];
+		const uint32_t t0 = sc.shape_tri_offset[s], nT = sc.shape_tri_offset[s + 1] - t0;
+		const int index = dpdf_sample_reuse(sc.lum_tri_cdf + sc.lum_cdf_offset[l], nT, sy);
+		const size_t tri = (size_t) t0 + (uint32_t) index;
+		const uint32_t i0 = sc.tri_idx[3 * tri], i1 = sc.tri_idx[3 * tri + 1], i2 = sc.tri_idx[3 * tri + 2];
+		const float *P = sc.vtx_pos;
+		const V3 p0(P[3 * (size_t) i0], P[3 * (size_t) i0 + 1], P[3 * (size_t) i0 + 2]);
+		const V3 p1(P[3 * (size_t) i1], P[3 * (size_t) i1 + 1], P[3 * (size_t) i1 + 2]);
+		const V3 p2(P[3 * (size_t) i2], P[3 * (size_t) i2 + 1], P[3 * (size_t) i2 + 2]);
+		float bx, by;
+		squareToTriangle(sx, sy, bx, by);
+		const V3 sideA = p1 - p0, sideB = p2 - p0;
+		lRec.p = V3(p0.x + (sideA.x * bx) + (sideB.x * by), p0.y + (sideA.y * bx) + (sideB.y * by), p0.z + (sideA.z * bx) + (sideB.z * by));
+		if (sc.shape_flags[s] & 1u) {
+			const float *N = sc.vtx_nrm;
+			const V3 n0(N[3 * (size_t) i0], N[3 * (size_t) i0 + 1], N[3 * (size_t) i0 + 2]);
+			const V3 n1(N[3 * (size_t) i1], N[3 * (size_t) i1 + 1], N[3 * (size_t) i1 + 2]);
+			const V3 n2(N[3 * (size_t) i2], N[3 * (size_t) i2 + 1], N[3 * (size_t) i2 + 2]);
+			const float b0 = 1.0f - bx - by;
+			lRec.n = normalize(V3(n0.x * b0 + n1.x * bx + n2.x * by, n0.y * b0 + n1.y * bx + n2.y * by, n0.z * b0 + n1.z * bx + n2.z * by));
+		} else {
+			lRec.n = normalize(cross(sideA, sideB));
+		}
+		const float pdfArea = sc.lum_inv_area[l];
+		const V3 lumToPoint = p - lRec.p;
+		const float distSquared = dot(lumToPoint, lumToPoint), dp = dot(lumToPoint, lRec.n);
+		lRec.pdf = (dp > 0) ? (pdfArea * distSquared * sqrtf(distSquared) / dp) : 0.0f;
+		lRec.d = p - lRec.p;
+		if (lRec.pdf > 0 && dot(lRec.d, lRec.n) > 0) {
+			lRec.value = V3(LP[0], LP[1], LP[2]);
+			lRec.d = normalize(lRec.d);
+		} else {
+			lRec.pdf = 0;
+		}
+	} else {
+		// ConstantLuminaire::sample (constant.cpp:73-87)
+		const V3 d = squareToSphere(sx, sy);
+		const V3 center(LP[3], LP[4], LP[5]);
+		const float radius = LP[6];
+		float nearHit, farHit;
+		if (length(p - center) <= radius && bsphere_ray_intersect(center, radius, p, d, nearHit, farHit)) {
+			lRec.p = V3(p.x + d.x * nearHit, p.y + d.y * nearHit, p.z + d.z * nearHit);
+			lRec.pdf = 1.0f / (4 * kPi);
+			lRec.n = normalize(center - lRec.p);
+			lRec.d = -d;
+			lRec.value = V3(LP[0], LP[1], LP[2]);
+		} else {
+			lRec.pdf = 0.0f;
+		}
+	}
+	if (lRec.pdf != 0) {
+		lRec.pdf *= lumPdf;
+		const float recip = 1.0f / lRec.pdf;
+		lRec.value = lRec.value * recip;
+		lRec.lum = l;
+		return true;
+	}
+	return false;
+}
+
+// Scene::pdfLuminaire (scene.cpp:381-394); Shape::pdfSolidAngle (shape.cpp:77-83); constant.cpp:89-91
+__device__ __forceinline__ float pdf_luminaire(const DScene &sc, V3 p, int lum, V3 lp, V3 ln) {
+	const float fraction = 1.0f / sc.lum_sel_sum;
+	float pdf;
+	if (sc.lum_type[lum] == 0u) {
+		const V3 lumToPoint = p - lp;
+		const float distSquared = dot(lumToPoint, lumToPoint);
+		const float invDP = smax(0.0f, sqrtf(distSquared) / dot(lumToPoint, ln));
+		pdf = sc.lum_inv_area[lum] * distSquared * invDP;
+	} else {
+		pdf = 1.0f / (4 * kPi);
+	}
+	return pdf * fraction;
+}
+
+// --- BSDF building blocks (roughmetal.cpp:75-117 == microfacet.cpp:95-136) ---
+enum : uint32_t { T_DIFFUSE_REFL = 0x1, T_DELTA_REFL = 0x4, T_DELTA_TRANS = 0x8, T_GLOSSY_REFL = 0x10,
+                  T_DELTA = 0xC, T_TRANSMISSION = 0x2A };
+
+__device__ __forceinline__ float frame_tan_theta(V3 v) {      // frame.h:98-103
+	const float temp = 1 - v.z * v.z;
+	if (temp <= 0.0f) return 0.0f;
+	return sqrtf(temp) / v.z;
+}
+__device__ __forceinline__ float beckmann_d(float alphaB, V3 m) {
+	const float ex = frame_tan_theta(m) / alphaB;
+	return dexp(-(ex * ex)) / (kPi * alphaB * alphaB * dpow4(m.z));
+}
+__device__ __forceinline__ V3 sample_beckmann_d(float alphaB, float sx, float sy) {
+	const float thetaM = datan(sqrtf(-alphaB * alphaB * dlog(1.0f - sx)));
+	const float phiM = (2.0f * kPi) * sy;
+	float st, ct, sp, cp;
+	dsincos(thetaM, st, ct); dsincos(phiM, sp, cp);
+	return V3(st * cp, st * sp, ct);                           // sphericalDirection (util.cpp:543-550)
+}
+__device__ __forceinline__ float smith_g1(float alphaB, V3 v, V3 m) {
+	if (dot(v, m) * v.z <= 0) return 0.0f;
+	const float tanTheta = frame_tan_theta(v);
+	if (tanTheta == 0.0f) return 1.0f;
+	const float a = 1.0f / (alphaB * tanTheta);
+	const float aSqr = a * a;
+	if (a >= 1.6f) return 1.0f;
+	return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+}
+__device__ __forceinline__ V3 mf_reflect(V3 wi, V3 n) {
+	const float s = 2.0f * dot(n, wi);
+	return V3(n.x * s - wi.x, n.y * s - wi.y, n.z * s - wi.z);
+}
+
+template <int BT> struct Bsdf;
+
+// Lambertian (src/bsdfs/lambertian.cpp:95-126)
+template <> struct Bsdf<0> {
+	static __device__ __forceinline__ V3 f(const float *P, V3 wi, V3 wo) {
+		if (wi.z <= 0 || wo.z <= 0) return V3(0, 0, 0);
+		return V3(P[0] * kInvPi, P[1] * kInvPi, P[2] * kInvPi);
+	}
+	static __device__ __forceinline__ float pdf(const float *P, V3 wi, V3 wo) {
+		if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+		return wo.z * kInvPi;
+	}
+	static __device__ __forceinline__ V3 sample(const float *P, V3 wi, float sx, float sy, V3 &wo, float &pdf, uint32_t &st) {
+		pdf = 0; st = 0; wo = V3(0, 0, 0);
+		if (wi.z <= 0) return V3(0, 0, 0);
+		wo = squareToHemispherePSA(sx, sy);
+		st = T_DIFFUSE_REFL;
+		pdf = wo.z * kInvPi;
+		return V3(P[0] * kInvPi, P[1] * kInvPi, P[2] * kInvPi);
+	}
+};
+
+// Dielectric (src/bsdfs/dielectric.cpp:101-107, :200-261): f = pdf = 0, delta sampling
+template <> struct Bsdf<1> {
+	static __device__ __forceinline__ V3 f(const float *, V3, V3) { return V3(0, 0, 0); }
+	static __device__ __forceinline__ float pdf(const float *, V3, V3) { return 0.0f; }
+	static __device__ __forceinline__ V3 sample(const float *P, V3 wi, float sx, float sy, V3 &wo, float &pdf, uint32_t &st) {
+		const float cosThetaI = wi.z;
+		float etaI = P[1], etaT = P[0];
+		const bool entering = cosThetaI > 0.0f;
+		if (!entering) { const float t = etaI; etaI = etaT; etaT = t; }
+		const float eta = etaI / etaT, sinThetaTSqr = eta * eta * (1.0f - wi.z * wi.z);
+		float Fr, cosThetaT = 0;
+		if (sinThetaTSqr >= 1.0f) {
+			Fr = 1.0f;
+		} else {
+			cosThetaT = sqrtf(1.0f - sinThetaTSqr);
+			Fr = fresnelDielectric(fabsf(cosThetaI), cosThetaT, etaI, etaT);
+			if (entering) cosThetaT = -cosThetaT;
+		}
+		if (sx <= Fr) {
+			st = T_DELTA_REFL;
+			wo = V3(-wi.x, -wi.y, wi.z);
+			pdf = Fr * fabsf(wo.z);
+			return V3(P[2] * Fr, P[3] * Fr, P[4] * Fr);
+		} else {
+			st = T_DELTA_TRANS;
+			wo = V3(-eta * wi.x, -eta * wi.y, cosThetaT);
+			pdf = (1 - Fr) * fabsf(wo.z);
+			return V3(P[5] * (1 - Fr) * (eta * eta), P[6] * (1 - Fr) * (eta * eta), P[7] * (1 - Fr) * (eta * eta));
+		}
+	}
+};
+
+// RoughMetal (src/bsdfs/roughmetal.cpp:119-167) through BSDF::sample(bRec, pdf, s) (bsdf.cpp:37-48)
+template <> struct Bsdf<2> {
+	static __device__ __forceinline__ V3 f(const float *P, V3 wi, V3 wo) {
+		if (wi.z <= 0 || wo.z <= 0) return V3(0, 0, 0);
+		const V3 Hr = normalize(wi + wo);
+		const float c = dot(wi, Hr);
+		const V3 F(fresnelConductor1(c, P[1], P[4]), fresnelConductor1(c, P[2], P[5]), fresnelConductor1(c, P[3], P[6]));
+		const float D = beckmann_d(P[0], Hr);
+		const float G = smith_g1(P[0], wi, Hr) * smith_g1(P[0], wo, Hr);
+		const float k = D * G / (4.0f * wi.z * wo.z);
+		return V3(P[7] * (F.x * k), P[8] * (F.y * k), P[9] * (F.z * k));
+	}
+	static __device__ __forceinline__ float pdf(const float *P, V3 wi, V3 wo) {
+		if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+		const V3 Hr = normalize(wi + wo);
+		const float dwhr_dwo = 1.0f / (4.0f * fabsf(dot(wo, Hr)));
+		return beckmann_d(P[0], Hr) * Hr.z * dwhr_dwo;
+	}
+	static __device__ __forceinline__ V3 sample(const float *P, V3 wi, float sx, float sy, V3 &wo, float &pdfv, uint32_t &st) {
+		pdfv = 0; st = 0; wo = V3(0, 0, 0);
+		if (wi.z <= 0) return V3(0, 0, 0);
+		const V3 m = sample_beckmann_d(P[0], sx, sy);
+		wo = mf_reflect(wi, m);
+		st = T_GLOSSY_REFL;
+		if (wo.z <= 0) return V3(0, 0, 0);
+		const V3 fv = f(P, wi, wo);
+		const float p = pdf(P, wi, wo);
+		const V3 qv = fv * (1.0f / p);          // sample() = f / pdf; zero -> pdf 0, value 0
+		if (isZero(qv)) return V3(0, 0, 0);
+		pdfv = p;
+		return fv;
+	}
+};
+
+// Microfacet (src/bsdfs/microfacet.cpp:151-269) through BSDF::sample(bRec, pdf, s)
+template <> struct Bsdf<3> {
+	static __device__ __forceinline__ V3 f(const float *P, V3 wi, V3 wo) {
+		if (wi.z <= 0 || wo.z <= 0) return V3(0, 0, 0);
+		const float alphaB = P[0], kd = P[1], ks = P[2], intIOR = P[3], extIOR = P[4];
+		const V3 Hr = normalize(wi + wo);
+		const float F = fresnel(dot(wi, Hr), extIOR, intIOR);
+		const float D = beckmann_d(alphaB, Hr);
+		const float G = smith_g1(alphaB, wi, Hr) * smith_g1(alphaB, wo, Hr);
+		const float specRef = D * G / (4.0f * wi.z * wo.z);
+		const float fk = F * ks;
+		V3 r(0.0f + (P[8] * specRef) * fk, 0.0f + (P[9] * specRef) * fk, 0.0f + (P[10] * specRef) * fk);
+		const float dk = kInvPi * (1 - F) * kd;
+		r.x += P[5] * dk; r.y += P[6] * dk; r.z += P[7] * dk;
+		return r;
+	}
+	static __device__ __forceinline__ float pdf_spec(const float *P, V3 wi, V3 wo) {
+		const V3 Hr = normalize(wi + wo);
+		return beckmann_d(P[0], Hr) * Hr.z / (4.0f * fabsf(dot(wo, Hr)));
+	}
+	static __device__ __forceinline__ float pdf(const float *P, V3 wi, V3 wo) {
+		if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+		const float kd = P[1], ks = P[2], intIOR = P[3], extIOR = P[4];
+		float fr = fresnel(wi.z, extIOR, intIOR);
+		fr = smin(smax(fr, 0.05f), 0.95f);
+		const float diffuseSamplingWeight = (1 - fr) * kd;
+		const float specularSamplingWeight = fr * ks;
+		const float normalization = 1 / (diffuseSamplingWeight + specularSamplingWeight);
+		return (specularSamplingWeight * pdf_spec(P, wi, wo) + diffuseSamplingWeight * (wo.z * kInvPi)) * normalization;
+	}
+	static __device__ __forceinline__ V3 sample(const float *P, V3 wi, float sx, float sy, V3 &wo, float &pdfv, uint32_t &st) {
+		pdfv = 0; st = 0; wo = V3(0, 0, 0);
+		if (wi.z <= 0) return V3(0, 0, 0);
+		const float kd = P[1], ks = P[2], intIOR = P[3], extIOR = P[4];
+		float fr = fresnel(wi.z, extIOR, intIOR);
+		fr = smin(smax(fr, 0.05f), 0.95f);
+		float diffuseSamplingWeight = (1 - fr) * kd;
+		float specularSamplingWeight = fr * ks;
+		const float normalization = 1 / (diffuseSamplingWeight + specularSamplingWeight);
+		specularSamplingWeight *= normalization;
+		diffuseSamplingWeight *= normalization;
+		V3 qv(0, 0, 0);
+		if (sx < specularSamplingWeight) {
+			sx /= specularSamplingWeight;
+			const V3 m = sample_beckmann_d(P[0], sx, sy);      // sampleSpecular (:203-218)
+			wo = mf_reflect(wi, m);
+			st = T_GLOSSY_REFL;
+			if (wo.z <= 0) return V3(0, 0, 0);
+			const float pdfValue = pdf(P, wi, wo);
+			if (pdfValue == 0) return V3(0, 0, 0);
+			qv = f(P, wi, wo) * (1.0f / pdfValue);
+		} else {
+			sx = (sx - specularSamplingWeight) / diffuseSamplingWeight;
+			wo = squareToHemispherePSA(sx, sy);                // sampleLambertian (:224-229)
+			st = T_DIFFUSE_REFL;
+			qv = f(P, wi, wo) * (1.0f / pdf(P, wi, wo));
+		}
+		if (isZero(qv)) return V3(0, 0, 0);
+		pdfv = pdf(P, wi, wo);
+		return f(P, wi, wo);
+	}
+};
+
+// "terminal" bin: never evaluated
+template <> struct Bsdf<4> {
+	static __device__ __forceinline__ V3 f(const float *, V3, V3) { return V3(0, 0, 0); }
+	static __device__ __forceinline__ float pdf(const float *, V3, V3) { return 0.0f; }
+	static __device__ __forceinline__ V3 sample(const float *, V3, float, float, V3 &wo, float &pdf, uint32_t &st) {
+		wo = V3(0, 0, 0); pdf = 0; st = 0; return V3(0, 0, 0);
+	}
+};
+
+__device__ __forceinline__ float mi_weight(float pdfA, float pdfB) {     // path.cpp:218-222
+	pdfA *= pdfA;
+	pdfB *= pdfB;
+	return pdfA / (pdfA + pdfB);
+}
+
+// ===========================================================================
+// K3+K5: one iteration of the loop of MIPathTracer::Li (path.cpp:61-209) for
+// all paths whose current hit has BSDF type BT.  The tail of the previous
+// iteration (emitter hit by the BSDF sample, Russian roulette, throughput
+// update; path.cpp:171-208) runs first because it needs the new hit.
+// ===========================================================================
+template <int BT>
+__global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, uint32_t n) {
+	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool active = gtid < n;
+	const uint32_t id = active ? q.bins[BT][gtid] : 0u;
+	bool continues = false, wantShadow = false;
+
+	if (active) {
+		const float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
+		const V3 rayO(ro.x, ro.y, ro.z), rayD(rd.x, rd.y, rd.z);
+		const uint4 h = ps.hit[id];
+		const bool valid = h.w != kNoPrim;
+		float4 T4 = ps.thr[id], L4 = ps.Li[id];
+		V3 thr(T4.x, T4.y, T4.z), Li(L4.x, L4.y, L4.z);
+		int depth = __float_as_int(T4.w);
+		uint32_t flags = __float_as_uint(L4.w);
+		PathSampler smp;
+		{
+			const uint2 r = ps.rng[id];
+			smp.stream = (uint64_t) r.x | ((uint64_t) r.y << 32);
+			smp.slot = cfg.slot_per_path ? id : (id / cfg.spp);
+			smp.j = ps.smp[id];
+			smp.d1 = (flags >> F_D1_SHIFT) & 0xFFu; smp.d2 = (flags >> F_D2_SHIFT) & 0xFFu;
+		}
+		Its its;
+		if (valid)
+			fill_its(sc, rayD, h.w, __uint_as_float(h.y), __uint_as_float(h.z), its);
+		const int shapeLum = valid ? sc.shape_lum[its.shape] : -1;
+
+		do {
+			if (flags & F_FIRST) {
+				// rRec.rayIntersect (records.inl:89-105): alpha = 1 on a hit
+				flags &= ~F_FIRST;
+				if (valid) flags |= F_ALPHA;
+			} else {
+				// ---- tail of the previous iteration (path.cpp:147-208) ----
+				const float4 B4 = ps.bsdf[id];
+				const V3 bsdfVal(B4.x, B4.y, B4.z);
+				const float bsdfPdf = B4.w;
+				const uint32_t sampledType = flags >> F_ST_SHIFT;
+				bool hitLuminaire = false;
+				V3 lvalue(0, 0, 0), lp(0, 0, 0), ln(0, 0, 0);
+				int llum = -1;
+				if (valid) {
+					if (shapeLum >= 0) {
+						// LuminaireSamplingRecord(its, -ray.d); value = its.Le(-ray.d) (area.cpp:62-66)
+						const float *LP = sc.lum_params + 8 * (size_t) shapeLum;
+						lp = its.p; ln = its.geoN; llum = shapeLum;
+						lvalue = (dot(-rayD, its.geoN) <= 0) ? V3(0, 0, 0) : V3(LP[0], LP[1], LP[2]);
+						hitLuminaire = true;
+					}
+				} else {
+					if (sc.background_lum >= 0) {
+						const float *LP = sc.lum_params + 8 * (size_t) sc.background_lum;
+						llum = sc.background_lum;
+						lvalue = V3(LP[0], LP[1], LP[2]);
+						hitLuminaire = true;
+					} else {
+						depth++;
+						break;
+					}
+				}
+				if (hitLuminaire) {
+					const float lumPdf = (!(sampledType & T_DELTA)) ? pdf_luminaire(sc, rayO, llum, lp, ln) : 0.0f;
+					const float weight = mi_weight(bsdfPdf, lumPdf);
+					Li.x += thr.x * lvalue.x * bsdfVal.x * weight;
+					Li.y += thr.y * lvalue.y * bsdfVal.y * weight;
+					Li.z += thr.z * lvalue.z * bsdfVal.z * weight;
+				}
+				if (!valid)
+					break;
+				flags &= ~F_EMITTED;                       // rRec.type = ERadianceNoEmission
+				if (depth >= cfg.rr_depth && !(sampledType & T_TRANSMISSION)) {
+					const float approxAlbedo = smin(0.9f, smax(smax(bsdfVal.x, bsdfVal.y), bsdfVal.z));
+					if (sampler_next1d(cfg, smp) > approxAlbedo)
+						break;
+					thr = thr * (1.0f / approxAlbedo);
+				}
+				thr = thr * bsdfVal;
+				depth++;
+				if (!(depth <= cfg.max_depth || cfg.max_depth < 0))
+					break;
+			}
+
+			// ---- head of the iteration (path.cpp:62-98) ----
+			if (!valid) {
+				if ((flags & F_EMITTED) && sc.background_lum >= 0) {
+					const float *LP = sc.lum_params + 8 * (size_t) sc.background_lum;
+					Li.x += thr.x * LP[0]; Li.y += thr.y * LP[1]; Li.z += thr.z * LP[2];
+				}
+				break;
+			}
+			if (BT == 4)
+				break;                                      // bsdf == NULL (path.cpp:72-77)
+			const int bsdfIdx = sc.shape_bsdf[its.shape];
+			const float *BP = sc.bsdf_params + 16 * (size_t) bsdfIdx;
+			if (shapeLum >= 0 && (flags & F_EMITTED)) {
+				// Li += pathThroughput * its.Le(-ray.d) (path.cpp:80-81, area.cpp:62-66)
+				const float *LP = sc.lum_params + 8 * (size_t) shapeLum;
+				const V3 le = (dot(-rayD, its.geoN) <= 0) ? V3(0.0f, 0.0f, 0.0f) : V3(LP[0], LP[1], LP[2]);
+				Li.x += thr.x * le.x; Li.y += thr.y * le.y; Li.z += thr.z * le.z;
+			}
+			if (cfg.max_depth > 0 && depth >= cfg.max_depth)
+				break;
+			const float wiDotGeoN = -dot(its.geoN, rayD), wiDotShN = its.wi.z;
+			if (wiDotGeoN * wiDotShN < 0 && cfg.strict_normals)
+				break;
+
+			// ---- luminaire sampling (path.cpp:100-126) ----
+			{
+				float s0, s1;
+				sampler_next2d(cfg, smp, s0, s1);
+				LRec lRec;
+				if (sample_luminaire(sc, its.p, s0, s1, lRec)) {
+					const V3 wo = -lRec.d;
+					const V3 woL(dot(wo, its.shS), dot(wo, its.shT), dot(wo, its.shN));
+					V3 bsdfVal = Bsdf<BT>::f(BP, its.wi, woL) * fabsf(woL.z);
+					const float woDotGeoN = dot(its.geoN, wo);
+					if (!isZero(bsdfVal) && (!cfg.strict_normals || woDotGeoN * woL.z > 0)) {
+						const float bsdfPdf = Bsdf<BT>::pdf(BP, its.wi, woL);
+						const float weight = mi_weight(lRec.pdf, bsdfPdf);
+						// added to Li by k_trace<shadow> iff the segment is unoccluded
+						ps.nee[id] = make_float4(thr.x * lRec.value.x * bsdfVal.x * weight,
+						                         thr.y * lRec.value.y * bsdfVal.y * weight,
+						                         thr.z * lRec.value.z * bsdfVal.z * weight, 0.0f);
+						const V3 sd = lRec.p - its.p;       // Ray(p1, p2 - p1) (scene.h:241-246)
+						ps.sh_o[id] = make_float4(its.p.x, its.p.y, its.p.z, 0.0f);
+						ps.sh_d[id] = make_float4(sd.x, sd.y, sd.z, 0.0f);
+						wantShadow = true;
+					}
+				}
+			}
+
+			// ---- BSDF sampling (path.cpp:128-146) ----
+			float s0, s1;
+			sampler_next2d(cfg, smp, s0, s1);
+			V3 woL; float bsdfPdf; uint32_t sampledType;
+			V3 bsdfVal = Bsdf<BT>::sample(BP, its.wi, s0, s1, woL, bsdfPdf, sampledType);
+			if (!isZero(bsdfVal))
+				bsdfVal = bsdfVal * fabsf(woL.z);          // sampleCos (bsdf.h:273-279)
+			if (isZero(bsdfVal))
+				break;
+			bsdfVal = bsdfVal * (1.0f / bsdfPdf);
+			const V3 wo(its.shS.x * woL.x + its.shT.x * woL.y + its.shN.x * woL.z,
+			            its.shS.y * woL.x + its.shT.y * woL.y + its.shN.y * woL.z,
+			            its.shS.z * woL.x + its.shT.z * woL.y + its.shN.z * woL.z);
+			const float woDotGeoN = dot(its.geoN, wo);
+			if (woDotGeoN * woL.z <= 0 && cfg.strict_normals)
+				break;
+			// ray = Ray(its.p, wo, time): mint = Epsilon, maxt = inf
+			ps.ray_o[id] = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
+			ps.ray_d[id] = make_float4(wo.x, wo.y, wo.z, MG_INF);
+			ps.bsdf[id] = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, bsdfPdf);
+			flags = (flags & 0x00FFFFFFu) | (sampledType << F_ST_SHIFT);
+			continues = true;
+		} while (false);
+
+		flags = (flags & ~((0xFFu << F_D1_SHIFT) | (0xFFu << F_D2_SHIFT))) | (smp.d1 << F_D1_SHIFT) | (smp.d2 << F_D2_SHIFT);
+		ps.thr[id] = make_float4(thr.x, thr.y, thr.z, __int_as_float(depth));
+		ps.Li[id] = make_float4(Li.x, Li.y, Li.z, __uint_as_float(flags));
+		ps.rng[id] = make_uint2((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32));
+	}
+
+	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue
+	const uint32_t pn = wave_append(continues, &q.counters[kNumBins]);
+	if (continues) q.next[pn] = id;
+	const uint32_t psh = wave_append(wantShadow, &q.counters[kNumBins + 1]);
+	if (wantShadow) q.shadow[psh] = id;
+}
+
+// ===========================================================================
+// K7: ImageBlock::putSample with the tabulated box filter
+// (include/mitsuba/render/imageblock.h:80-138, src/librender/rfilter.cpp:40-69).
+// One lane per pixel; its samples are added in sample-index order, so the film
+// is bit-reproducible and independent of how the image was sharded.
+// ===========================================================================
+__global__ void k_accumulate(DPaths ps, DConfig cfg, uint32_t n_slots, uint32_t spp, float *film) {
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= n_slots)
+		return;
+	const int W = cfg.width, H = cfg.height;
+	// TabulatedFilter of the box filter: size 0.5, factor = 15 / 0.5, table = 1 inside, 0 on the border row
+	const float fsize = 0.5f, factor = 15 / fsize;
+	for (uint32_t j = 0; j < spp; ++j) {
+		const size_t id = (size_t) slot * spp + j;
+		const float4 L = ps.Li[id];
+		const float2 sp = ps.spos[id];
+		// Spectrum::isValid (spectrum.h:285-290)
+		if (L.x != L.x || L.x < 0.0f || L.y != L.y || L.y < 0.0f || L.z != L.z || L.z < 0.0f)
+			continue;
+		const float alpha = (__float_as_uint(L.w) & F_ALPHA) ? 1.0f : 0.0f;
+		const float sx = sp.x - 0.5f - 0, sy = sp.y - 0.5f - 0;
+		int xStart = (int) ceilf(sx - fsize), xEnd = (int) floorf(sx + fsize);
+		int yStart = (int) ceilf(sy - fsize), yEnd = (int) floorf(sy + fsize);
+		xStart = max(0, xStart); yStart = max(0, yStart);
+		xEnd = min(xEnd, W - 1); yEnd = min(yEnd, H - 1);
+		for (int y = yStart; y <= yEnd; ++y) {
+			const int iy = min((int) (factor * fabsf(y - sy)), 15);
+			for (int x = xStart; x <= xEnd; ++x) {
+				const int ix = min((int) (factor * fabsf(x - sx)), 15);
+				const float weight = (ix == 15 || iy == 15) ? 0.0f : 1.0f;
+				// zero-weight taps add spec*0 in the reference: a no-op for valid spectra
+				if (weight == 0.0f)
+					continue;
+				float *px = film + 5 * ((size_t) y * W + x);
+				px[0] += L.x * weight; px[1] += L.y * weight; px[2] += L.z * weight;
+				px[3] += alpha * weight;
+				px[4] += weight;
+			}
+		}
+	}
+}
+
+// ===========================================================================
+// launchers
+// ===========================================================================
+static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned) ((n + bs - 1) / bs); }
+
+void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, size_t n) {
+	if (n) hipLaunchKernelGGL(k_fill_u32, dim3(blocks_for(n, 256)), dim3(256), 0, s, p, v, n);
+}
+void launch_iota(hipStream_t s, uint32_t *p, uint32_t n) {
+	if (n) hipLaunchKernelGGL(k_iota, dim3(blocks_for(n, 256)), dim3(256), 0, s, p, n);
+}
+
+void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_keys, uint32_t n_slots,
+                      uint32_t *scr, uint16_t *perm) {
+	if (n_slots) hipLaunchKernelGGL(k_ld_tables, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, cfg, pixel_keys, n_slots, scr, perm);
+}
+
+void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg,
+                     const uint32_t *pixel_list, uint32_t n_slots, const uint32_t *explicit_samples,
+                     uint32_t n_paths, uint32_t *queue) {
+	if (n_paths) hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths, 256)), dim3(256), 0, s, sc, ps, cfg,
+	                                pixel_list, n_slots, explicit_samples, n_paths, queue);
+}
+
+template <int MODE, bool COUNT, bool BIN>
+static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n) {
+	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks_for(n, kTraceBlock)), dim3(kTraceBlock), 0, s, sc, ps, q, queue, n);
+}
+
+void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
+                  const DQueues &q, const uint32_t *queue, uint32_t n) {
+	if (!n) return;
+	if (mode == 0) {
+		if (bin) { if (count) launch_trace_t<0, true, true>(s, sc, ps, q, queue, n); else launch_trace_t<0, false, true>(s, sc, ps, q, queue, n); }
+		else     { if (count) launch_trace_t<0, true, false>(s, sc, ps, q, queue, n); else launch_trace_t<0, false, false>(s, sc, ps, q, queue, n); }
+	} else if (mode == 1) {
+		if (count) launch_trace_t<1, true, false>(s, sc, ps, q, queue, n); else launch_trace_t<1, false, false>(s, sc, ps, q, queue, n);
+	} else {
+		if (count) launch_trace_t<2, true, false>(s, sc, ps, q, queue, n); else launch_trace_t<2, false, false>(s, sc, ps, q, queue, n);
+	}
+}
+
+void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
+                  const DQueues &q, uint32_t n) {
+	if (!n) return;
+	const dim3 g(blocks_for(n, 256)), b(256);
+	switch (bin) {
+		case 0: hipLaunchKernelGGL(k_shade<0>, g, b, 0, s, sc, ps, cfg, q, n); break;
+		case 1: hipLaunchKernelGGL(k_shade<1>, g, b, 0, s, sc, ps, cfg, q, n); break;
+		case 2: hipLaunchKernelGGL(k_shade<2>, g, b, 0, s, sc, ps, cfg, q, n); break;
+		case 3: hipLaunchKernelGGL(k_shade<3>, g, b, 0, s, sc, ps, cfg, q, n); break;
+		default: hipLaunchKernelGGL(k_shade<4>, g, b, 0, s, sc, ps, cfg, q, n); break;
+	}
+}
+
+void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,
+                       uint32_t spp_per_slot, float *film) {
+	if (n_slots) hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, ps, cfg, n_slots, spp_per_slot, film);
+}
+
+} // namespace mg

@@ -378,6 +378,10 @@ static float transition_to_nlogn(ctx_t *c, uint32_t depth, uint32_t node, const 
 	qsort(es, (size_t) (ee - es), sizeof(event_t), event_cmp);
 	float cost = build_tree(c, depth, node, nodeAABB, es, ee, actualPrimCount, badRefines);
 	free(es);
+	/* m_parallelBuild stays on above exactPrimThreshold primitives (gkdtree.h:939-940): the
+	 * subtree is built by a worker and reports -inf, "never tear down this subtree" (:1691-1692) */
+	if (c->primCount > c->exactPrimThreshold)
+		return -INFINITY;
 	return cost;
 }
 

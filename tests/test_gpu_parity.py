@@ -1,0 +1,103 @@
+"""GPU parity: the HIP path through the C ABI vs the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import chord_rays
+
+pytestmark = pytest.mark.gpu
+
+SCENES = {
+    "c1": lambda s: s.cornell_c1(),
+    "c3_small": lambda s: s.cornell_c3(grid=24, sphere_subdiv=2),
+    "c5_small": lambda s: s.cornell_c5(sphere_subdiv=2),
+}
+
+
+def _setup(mts, orc, name, W=64, H=64, sampler="independent", spp=8, max_depth=None, seed=0x5EED):
+    sd = SCENES[name](mts.scenes)
+    scene = mts.Scene(sd)
+    oscene = orc.FlatScene(sd)
+    cam = mts.PerspectiveCamera.for_description(sd, W, H)
+    ocam = orc.make_camera(sd, W, H)
+    md = sd.max_depth if max_depth is None else max_depth
+    it = mts.MIPathTracer(maxDepth=md)
+    it.preprocess(scene, cam, sampler=sampler, sampleCount=spp, seed=seed)
+    kind = {"independent": mts.abi.SAMPLER_INDEPENDENT_KEYED, "ldsampler": mts.abi.SAMPLER_LD_KEYED}[sampler]
+    op = orc.render_params(md, sampler=kind, spp=spp, seed=seed)
+    return sd, scene, oscene, cam, ocam, it, op
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_trace_closest_and_shadow(gpu_lib, mts, orc, name):
+    sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, name)
+    rays = chord_rays(20000, (0, 1, 0), 2.2, seed=7)
+    got = it.trace_rays(rays)
+    exp = orc.trace_rays(oscene.scene, rays)
+    assert np.array_equal(got, exp), "closest-hit (t,u,v,prim) differs in %d rays" % int((got != exp).any(axis=1).sum())
+    assert (exp[:, 3] != 0xFFFFFFFF).sum() > 1000
+    # shadow segments between surface points
+    seg = rays.copy()
+    seg[:, 3] = 1e-3
+    seg[:, 7] = 1 - 1e-3
+    seg[:, 4:7] *= np.float32(3.0)
+    got = it.trace_rays(seg, shadow=True)
+    exp = orc.trace_rays(oscene.scene, seg, shadow=True)
+    assert np.array_equal(got[:, 3], exp[:, 3])
+    assert 0 < exp[:, 3].sum() < len(seg)
+
+
+def test_ld_tables_bit_exact(gpu_lib, mts, orc):
+    sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "c1", sampler="ldsampler", spp=64)
+    for key in (0, 1, 4095, 123456):
+        t1, t2 = it.ld_tables(key, 64, 3)
+        e1 = np.zeros((3, 64), dtype=np.float32)
+        e2 = np.zeros((3, 64, 2), dtype=np.float32)
+        orc.lib().orc_ld_generate_keyed(0x5EED, key, 64, 3, mts.abi.ptr(e1, mts.abi.f32p), mts.abi.ptr(e2, mts.abi.f32p))
+        assert np.array_equal(t1.view(np.uint32), e1.view(np.uint32))
+        assert np.array_equal(t2.view(np.uint32), e2.view(np.uint32))
+
+
+@pytest.mark.parametrize("name,sampler", [("c1", "independent"), ("c1", "ldsampler"), ("c3_small", "ldsampler"),
+                                          ("c5_small", "independent"), ("c5_small", "ldsampler")])
+def test_li_samples_bit_exact(gpu_lib, mts, orc, name, sampler):
+    """MIPathTracer::Li per camera sample: radiance, alpha, raster position and path depth"""
+    sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, name, W=32, H=32, sampler=sampler, spp=16)
+    rng = np.random.RandomState(3)
+    ps = np.stack([rng.randint(0, 32, 4000), rng.randint(0, 32, 4000), rng.randint(0, 16, 4000)], axis=1).astype(np.uint32)
+    got = it.li_samples(ps)
+    exp = orc.li_samples(oscene.scene, ocam, op, ps)
+    bad = (got.view(np.uint32) != exp.view(np.uint32)).any(axis=1)
+    assert not bad.any(), "%d of %d samples differ; first: got %s exp %s" % (bad.sum(), len(ps), got[bad][:1], exp[bad][:1])
+    assert exp[:, :3].max() > 0
+
+
+@pytest.mark.parametrize("name,sampler,spp", [("c1", "independent", 16), ("c1", "ldsampler", 32), ("c3_small", "ldsampler", 16),
+                                              ("c5_small", "ldsampler", 16)])
+def test_film_matches_oracle(gpu_lib, mts, orc, name, sampler, spp):
+    """whole renderBlock + putSample pipeline; tolerance stated by north_star: pixel RMSE < 1e-5
+    (the target is bit-identical, which is what is asserted first and reported)"""
+    sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, name, W=48, H=40, sampler=sampler, spp=spp)
+    assert it.render()
+    film = it.film()
+    ofilm, ost = orc.render(oscene.scene, ocam, op)
+    st = it.stats()
+    assert st["camera_samples"] == 48 * 40 * spp
+    assert st["rays_closest"] == ost.rays_closest
+    img, oimg = mts.develop(film), orc.develop(ofilm)
+    rmse = float(np.sqrt(np.mean((img.astype(np.float64) - oimg.astype(np.float64)) ** 2)))
+    assert rmse < 1e-5, "pixel RMSE %g" % rmse
+    assert np.array_equal(film.view(np.uint32), ofilm.view(np.uint32)), "film not bit-identical (RMSE %g)" % rmse
+
+
+def test_tile_sharding_is_exact(gpu_lib, mts, orc):
+    """ImageBlock sharding: the union of the parts equals the unsharded film bit for bit"""
+    sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "c1", W=80, H=72, sampler="ldsampler", spp=8)
+    assert it.render()
+    full = it.film()
+    acc = np.zeros_like(full)
+    for part in range(3):
+        it.clear_film()
+        it.set_tiles(32, part, 3)
+        assert it.render()
+        acc += it.film()
+    assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
