@@ -16,7 +16,7 @@ import subprocess
 
 import numpy as np
 
-from . import abi, scenes  # noqa: F401
+from . import abi, scenes, filmreduce  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtsgpu.so")
