@@ -331,14 +331,23 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	DScene d{};
 	int rc = 0;
 	rc |= upload(c, (const uint32_t **) &d.nodes, sc->kd_nodes, 2 * (size_t) sc->n_nodes);
-	rc |= upload(c, &d.indices, sc->kd_indices, sc->n_indices);
 	{
-		// device copy of the TriAccel table; bit 31 of the shape dword marks non-occluders
-		// (Shape::isOccluder == has a BSDF, shape.h:324) so that shadow rays need no extra gather
-		std::vector<uint32_t> ta(sc->triaccel, sc->triaccel + 12 * (size_t) sc->n_tris);
-		for (uint32_t t = 0; t < sc->n_tris; ++t)
-			if (sc->shape_bsdf[ta[12 * (size_t) t + 10]] < 0) ta[12 * (size_t) t + 10] |= 0x80000000u;
-		rc |= upload(c, (const uint32_t **) &d.triaccel, ta.data(), ta.size());
+		// TriAccel records re-laid out in leaf order (one contiguous run per leaf, no index
+		// indirection on the device); bit 31 of the shape dword marks non-occluders
+		// (Shape::isOccluder == has a BSDF, shape.h:324), dword 11 carries the global primitive id
+		std::vector<uint32_t> ta(12 * (size_t) sc->n_indices + 12, 0u);
+		for (uint32_t e = 0; e < sc->n_indices; ++e) {
+			const uint32_t prim = sc->kd_indices[e];
+			uint32_t *dst = &ta[12 * (size_t) e];
+			std::memcpy(dst, sc->triaccel + 12 * (size_t) prim, 48);
+			if (sc->shape_bsdf[dst[10]] < 0) dst[10] |= 0x80000000u;
+			dst[11] = prim;
+		}
+		rc |= upload(c, (const uint32_t **) &d.leaf_ta, ta.data(), ta.size());
+		std::vector<uint32_t> triShape(sc->n_tris + 1, 0u);
+		for (uint32_t s = 0; s < sc->n_shapes; ++s)
+			for (uint32_t t = sc->shape_tri_offset[s]; t < sc->shape_tri_offset[s + 1]; ++t) triShape[t] = s;
+		rc |= upload(c, &d.tri_shape, triShape.data(), triShape.size());
 	}
 	rc |= upload(c, &d.vtx_pos, sc->vtx_pos, 3 * (size_t) sc->n_verts);
 	rc |= upload(c, &d.vtx_nrm, sc->vtx_nrm, 3 * (size_t) sc->n_verts);
@@ -457,7 +466,7 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, pixels.size()); if (rc) return rc;
 	HIPCHK(c, hipMemcpyAsync(c->pixelList, pixels.data(), pixels.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 
-	const uint64_t maxPaths = c->maxPaths ? c->maxPaths : (4ull << 20);
+	const uint64_t maxPaths = c->maxPaths ? c->maxPaths : (72ull << 20);
 	const size_t slotsPerPass = (size_t) std::max<uint64_t>(1, std::min<uint64_t>(pixels.size(), maxPaths / spp));
 	if ((uint64_t) slotsPerPass * spp > 0x7FFFFFFFull) return fail(c, MTSGPU_EINVAL, "pass too large");
 	rc = ensurePaths(c, slotsPerPass * spp); if (rc) return rc;

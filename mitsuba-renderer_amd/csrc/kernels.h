@@ -12,8 +12,11 @@ constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 // Scene in HBM (all pointers are device pointers); see DESIGN.md section 3
 struct DScene {
 	const uint2    *nodes;        // KDNode, 8 B
-	const uint32_t *indices;
-	const uint4    *triaccel;     // 3 x 16 B per primitive; dword 10 bit31 = "not an occluder"
+	// TriAccel records in LEAF ORDER: entry e of the kd-tree index list holds the 48-byte
+	// TriAccel of primitive kd_indices[e] (dword 10 = shape | bit31 "not an occluder",
+	// dword 11 = global primitive id), so a leaf's primitives are one contiguous run
+	const uint4    *leaf_ta;
+	const uint32_t *tri_shape;    // [n_tris] shape index of every primitive
 	const float    *vtx_pos, *vtx_nrm;
 	const uint32_t *tri_idx;
 	const int32_t  *shape_bsdf, *shape_lum;

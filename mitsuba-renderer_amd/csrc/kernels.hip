@@ -305,42 +305,57 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, DPaths ps, DQu
 			// --- leaf: test the primitives (sahkdtree3.h:262-288, skdtree.h:244-336) ---
 			if (COUNT) c_leaf++;
 			bool hitShadow = false;
-			for (uint32_t e = nd.x & 0x7FFFFFFFu, last = nd.y; e != last; ++e) {
-				const uint32_t prim = sc.indices[e];
-				if (COUNT) c_idx++;
-				if (s_mbox[prim & 7u][tid] == prim)
-					continue;
-				if (COUNT) c_tri++;
-				const uint4 *ta = sc.triaccel + 3 * (size_t) prim;
-				const uint4 A = ta[0], B = ta[1], C = ta[2];
-				const float n_u = __uint_as_float(A.y), n_v = __uint_as_float(A.z), n_d = __uint_as_float(A.w);
-				const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
-				const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
-				const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
-				float o_u, o_v, o_k, d_u, d_v, d_k;
-				bool ok = true;
-				if (A.x == 0u) { o_u = oy; o_v = oz; o_k = ox; d_u = dy; d_v = dz; d_k = dx; }
-				else if (A.x == 1u) { o_u = oz; o_v = ox; o_k = oy; d_u = dz; d_v = dx; d_k = dy; }
-				else if (A.x == 2u) { o_u = ox; o_v = oy; o_k = oz; d_u = dx; d_v = dy; d_k = dz; }
-				else { ok = false; o_u = o_v = o_k = d_u = d_v = d_k = 0.0f; }
-				if (MODE != 0 && (C.z & 0x80000000u)) ok = false;    // shape->isOccluder() (skdtree.h:318-333)
-				if (ok) {
-					const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
-					const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
-					if (!(t < mint || t > maxt)) {
-						const float hu = o_u + t * d_u - a_u;
-						const float hv = o_v + t * d_v - a_v;
-						const float u = hv * b_nu + hu * b_nv;
-						const float v = hu * c_nu + hv * c_nv;
-						if (u >= 0 && v >= 0 && u + v <= 1.0f) {
-							if (MODE != 0) { hitShadow = true; break; }
-							maxt = t;          // a later hit with equal t replaces this one (t > maxt rejects)
-							best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = C.z & 0x7FFFFFFFu;
-							found = true;
-						}
-					}
+			{
+				uint32_t e = nd.x & 0x7FFFFFFFu;
+				const uint32_t last = nd.y;
+				uint4 A, B, C;
+				if (e != last) {
+					const uint4 *ta = sc.leaf_ta + 3 * (size_t) e;
+					A = ta[0]; B = ta[1]; C = ta[2];
 				}
-				s_mbox[prim & 7u][tid] = prim;
+				while (e != last) {
+					// software pipeline: the next record is in flight while this one is tested
+					uint4 An = A, Bn = B, Cn = C;
+					if (e + 1 != last) {
+						const uint4 *tn = sc.leaf_ta + 3 * (size_t) (e + 1);
+						An = tn[0]; Bn = tn[1]; Cn = tn[2];
+					}
+					const uint32_t prim = C.w;
+					if (COUNT) c_idx++;
+					if (s_mbox[prim & 7u][tid] != prim) {
+						if (COUNT) c_tri++;
+						const float n_u = __uint_as_float(A.y), n_v = __uint_as_float(A.z), n_d = __uint_as_float(A.w);
+						const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
+						const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
+						const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
+						float o_u, o_v, o_k, d_u, d_v, d_k;
+						bool ok = true;
+						if (A.x == 0u) { o_u = oy; o_v = oz; o_k = ox; d_u = dy; d_v = dz; d_k = dx; }
+						else if (A.x == 1u) { o_u = oz; o_v = ox; o_k = oy; d_u = dz; d_v = dx; d_k = dy; }
+						else if (A.x == 2u) { o_u = ox; o_v = oy; o_k = oz; d_u = dx; d_v = dy; d_k = dz; }
+						else { ok = false; o_u = o_v = o_k = d_u = d_v = d_k = 0.0f; }
+						if (MODE != 0 && (C.z & 0x80000000u)) ok = false;    // shape->isOccluder() (skdtree.h:318-333)
+						if (ok) {
+							const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
+							const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
+							if (!(t < mint || t > maxt)) {
+								const float hu = o_u + t * d_u - a_u;
+								const float hv = o_v + t * d_v - a_v;
+								const float u = hv * b_nu + hu * b_nv;
+								const float v = hu * c_nu + hv * c_nv;
+								if (u >= 0 && v >= 0 && u + v <= 1.0f) {
+									if (MODE != 0) { hitShadow = true; break; }
+									maxt = t;      // a later hit with equal t replaces this one (t > maxt rejects)
+									best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = C.z & 0x7FFFFFFFu;
+									found = true;
+								}
+							}
+						}
+						s_mbox[prim & 7u][tid] = prim;
+					}
+					A = An; B = Bn; C = Cn;
+					++e;
+				}
 			}
 			if (hitShadow) { found = true; break; }
 
@@ -439,7 +454,7 @@ __device__ __forceinline__ void fill_its(const DScene &sc, V3 rayD, uint32_t pri
 	if (!isZero(faceNormal))
 		faceNormal = divs(faceNormal, len);
 	its.geoN = faceNormal;
-	its.shape = sc.triaccel[3 * (size_t) prim + 2].z & 0x7FFFFFFFu;
+	its.shape = sc.tri_shape[prim];
 	if (sc.shape_flags[its.shape] & 1u) {
 		const float *N = sc.vtx_nrm;
 		const V3 n0(N[3 * (size_t) i0], N[3 * (size_t) i0 + 1], N[3 * (size_t) i0 + 2]);
