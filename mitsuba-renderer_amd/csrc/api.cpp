@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 using namespace mg;
 
@@ -114,9 +115,10 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	rc |= devAlloc(c, &c->q.shadow, cap, o);
 	rc |= devAlloc(c, &c->q.counters, 16, o);
 	rc |= devAlloc(c, &c->q.trace_counts, 4, o);
-	rc |= devAlloc(c, &c->q.spill, cap * trace_spill_levels(), o);
+	rc |= devAlloc(c, &c->q.spill, (size_t) kTraceGridBlocks * kTraceBlock * trace_spill_levels(), o);
 	if (rc) return rc;
-	c->q.spill_stride = (uint32_t) cap;
+	c->q.spill_stride = kTraceGridBlocks * kTraceBlock;
+	c->q.fetch_threshold = getenv("MTSGPU_FETCH_THRESHOLD") ? atoi(getenv("MTSGPU_FETCH_THRESHOLD")) : 0;
 	HIPCHK(c, hipMemset(c->q.trace_counts, 0, 4 * sizeof(unsigned long long)));
 	c->pathCap = cap;
 	return 0;
@@ -163,7 +165,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 	while (nQ > 0) {
 		if (cancel && *cancel)
 			return fail(c, MTSGPU_ECANCEL, "render cancelled");
-		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, 8 * sizeof(uint32_t), s));
+		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, 16 * sizeof(uint32_t), s));
 		c->q.next = nxt;
 		// closest hit + material sort
 		hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
@@ -536,6 +538,7 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 	HIPCHK(c, hipMemcpyAsync(c->paths.ray_o, o.data(), o.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipMemcpyAsync(c->paths.ray_d, d.data(), d.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
 	launch_iota(c->stream, c->queueA, n);
+	HIPCHK(c, hipMemsetAsync(c->q.counters, 0, 16 * sizeof(uint32_t), c->stream));
 	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 4 * sizeof(unsigned long long), c->stream));
 	hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
 	if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));

@@ -7,6 +7,7 @@ namespace mg {
 
 constexpr int kNumBins = 5;           // 4 BSDF types + "terminal" (miss / no BSDF)
 constexpr int kTraceBlock = 256;
+constexpr unsigned kTraceGridBlocks = 256 * 5;   // persistent traversal grid: 256 CUs x resident workgroups
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 
 // Scene in HBM (all pointers are device pointers); see DESIGN.md section 3
@@ -77,10 +78,11 @@ struct DQueues {
 	uint32_t *bins[kNumBins];     // per-material queues written by the closest-hit kernel
 	uint32_t *next;               // paths that continue (input of the next closest-hit launch)
 	uint32_t *shadow;             // paths with a pending shadow ray
-	uint32_t *counters;           // [0..4] bins, [5] next, [6] shadow
+	uint32_t *counters;           // [0..4] bins, [5] next, [6] shadow, [7] closest-hit work head, [8] shadow work head
 	unsigned long long *trace_counts;  // n_inner, n_leaf, n_idx, n_tri_tested (u64 x 4)
 	uint32_t *spill;              // traversal stack overflow: [level][thread]
 	uint32_t spill_stride;
+	int32_t fetch_threshold;      // refill a wave's idle lanes when fewer than this many still traverse
 };
 
 // --- launchers (kernels.hip) -------------------------------------------------

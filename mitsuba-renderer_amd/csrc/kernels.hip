@@ -6,6 +6,7 @@
 //   k_trace<closest>  ->  k_shade<bsdf type>  ->  k_trace<shadow>  ->  (next bounce)
 #include "kernels.h"
 #include "devmath.h"
+#include <algorithm>
 
 namespace mg {
 
@@ -198,224 +199,264 @@ constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 
 size_t trace_spill_levels() { return kSpillLevels; }
 
+// Persistent waves with dynamic ray fetch: a wave keeps traversing while at least
+// kFetchThreshold of its 64 lanes still hold a ray; below that the idle lanes write their
+// results and pull the next rays from the queue (one atomic per wave), so divergent ray
+// lengths do not leave most of a wave's memory requests unissued.
+
 template <int MODE, bool COUNT, bool BIN>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, DPaths ps, DQueues q,
-                                                       const uint32_t *queue, uint32_t n) {
+                                                       const uint32_t *queue, uint32_t n, uint32_t *work_head) {
 	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
 	__shared__ uint32_t s_mbox[8][kTraceBlock];
 	const uint32_t tid = threadIdx.x;
-	const uint32_t gtid = blockIdx.x * kTraceBlock + tid;
-	const bool active = gtid < n;
-	const uint32_t id = active ? queue[gtid] : 0u;
+	const uint32_t gtid = blockIdx.x * kTraceBlock + tid;     // spill slot of this lane
+	const uint32_t lane = lane_id();
 
-	float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, rmint = 0, rmaxt = 0;
-	if (active) {
-		float4 a, b;
-		if (MODE == 1) {
-			a = ps.sh_o[id]; b = ps.sh_d[id];
-			rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
-		} else {
-			a = ps.ray_o[id]; b = ps.ray_d[id];
-			rmint = a.w; rmaxt = b.w;
-		}
-		ox = a.x; oy = a.y; oz = a.z; dx = b.x; dy = b.y; dz = b.z;
-	}
-	// Ray::dRcp (ray.h:63-74)
-	const float rx = 1.0f / dx, ry = 1.0f / dy, rz = 1.0f / dz;
-
-	// --- AABB::rayIntersect (aabb.h:349-382) + adaptive epsilon (skdtree.cpp:114-122) ---
-	bool go = active;
-	float mint = -MG_INF, maxt = MG_INF;
-	#pragma unroll
-	for (int i = 0; i < 3; ++i) {
-		const float direction = sel3(dx, dy, dz, i), origin = sel3(ox, oy, oz, i);
-		const float minVal = sc.aabb_min[i], maxVal = sc.aabb_max[i];
-		if (direction == 0) {
-			if (origin < minVal || origin > maxVal) go = false;
-		} else {
-			const float rc = sel3(rx, ry, rz, i);
-			float t1 = (minVal - origin) * rc, t2 = (maxVal - origin) * rc;
-			if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
-			mint = smax(mint, t1);
-			maxt = smin(maxt, t2);
-			if (mint > maxt) go = false;
-		}
-	}
-	{
-		float rayMinT = rmint;
-		if (rayMinT == kEpsilon) {
-			float m = smax(smax(fabsf(ox), fabsf(oy)), fabsf(oz));
-			if (MODE == 0) m = smax(m, kEpsilon);    // only the (ray, its) variant has the inner max
-			rayMinT *= m;
-		}
-		if (rayMinT > mint) mint = rayMinT;
-		if (rmaxt < maxt) maxt = rmaxt;
-		if (!(maxt > mint)) go = false;
-	}
-
+	bool has = false, retire = false, moreWork = true;
+	uint32_t id = 0;
+	float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, rx = 1, ry = 1, rz = 1;
+	float mint = 0, maxt = 0, tmax0 = 0;
+	float en_t = 0, en_split = 0, ex_t = 0, ex_split = 0;
+	int en_axis = 3, ex_axis = 3, sp = 0;
+	uint32_t ex_node = kNullNode, ex_ref = kSentinel, cur = 0;
 	float best_t = MG_INF, best_u = 0, best_v = 0;
 	uint32_t best_prim = kNoPrim, best_shape = 0;
 	bool found = false;
 	uint32_t c_inner = 0, c_leaf = 0, c_idx = 0, c_tri = 0;
 
-	if (go) {
-		#pragma unroll
-		for (int i = 0; i < 8; ++i) s_mbox[i][tid] = 0xFFFFFFFFu;
-
-		// entry point (stack[enPt]) and current exit point (stack[exPt]) in registers
-		float en_t = mint, en_split = 0.0f; int en_axis = 3;
-		const float tmax0 = maxt;
-		float ex_t = maxt, ex_split = 0.0f; int ex_axis = 3;
-		uint32_t ex_node = kNullNode, ex_ref = kSentinel;
-		int sp = 0;
-		uint32_t cur = 0;
-
-		while (true) {
-			uint2 nd = sc.nodes[cur];
-			while (!(nd.x & 0x80000000u)) {
-				const float split = __uint_as_float(nd.y);
-				const int axis = (int) (nd.x & 3u);
-				const uint32_t left = cur + ((nd.x & 0x3FFFFFFCu) >> 2);
-				if (COUNT) c_inner++;
-				const float oa = sel3(ox, oy, oz, axis), da = sel3(dx, dy, dz, axis);
-				// stack[].p[axis]: ray(t) with the pushed axis overwritten by its split (sahkdtree3.h:248-249)
-				const float pen = (axis == en_axis) ? en_split : (oa + en_t * da);
-				const float pex = (axis == ex_axis) ? ex_split : (oa + ex_t * da);
-				uint32_t farRight;
-				if (pen <= split) {
-					if (pex <= split) { cur = left; nd = sc.nodes[cur]; continue; }         // N1-N3, P5, Z2, Z3
-					if (pen == split) { cur = left + 1; nd = sc.nodes[cur]; continue; }     // Z1
-					farRight = 1u;                                                          // N4
-				} else {
-					if (split < pex) { cur = left + 1; nd = sc.nodes[cur]; continue; }      // P1-P3, N5
-					farRight = 0u;                                                          // P4
-				}
-				const float distToSplit = (split - oa) * sel3(rx, ry, rz, axis);
-				// push the current exit point's reference, make (cur, far) the new exit point
-				if (sp < kStackLDS) s_stack[sp][tid] = ex_ref;
-				else q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref;
-				++sp;
-				ex_ref = (cur << 1) | farRight;
-				ex_t = distToSplit; ex_axis = axis; ex_split = split;
-				ex_node = left + farRight;
-				cur = left + (1u - farRight);
-				nd = sc.nodes[cur];
-			}
-
-			// --- leaf: test the primitives (sahkdtree3.h:262-288, skdtree.h:244-336) ---
-			if (COUNT) c_leaf++;
-			bool hitShadow = false;
-			{
-				uint32_t e = nd.x & 0x7FFFFFFFu;
-				const uint32_t last = nd.y;
-				uint4 A, B, C;
-				if (e != last) {
-					const uint4 *ta = sc.leaf_ta + 3 * (size_t) e;
-					A = ta[0]; B = ta[1]; C = ta[2];
-				}
-				while (e != last) {
-					// software pipeline: the next record is in flight while this one is tested
-					uint4 An = A, Bn = B, Cn = C;
-					if (e + 1 != last) {
-						const uint4 *tn = sc.leaf_ta + 3 * (size_t) (e + 1);
-						An = tn[0]; Bn = tn[1]; Cn = tn[2];
+	for (;;) {
+		// ---- retire finished rays (all lanes take part in the ballots) ----
+		if (MODE == 0) {
+			int bin = -1;
+			if (retire) {
+				ps.hit[id] = make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim);
+				if (BIN) {
+					bin = kNumBins - 1;
+					if (found) {
+						const int b = sc.shape_bsdf[best_shape];
+						if (b >= 0) bin = (int) sc.bsdf_type[b];
 					}
-					const uint32_t prim = C.w;
-					if (COUNT) c_idx++;
-					if (s_mbox[prim & 7u][tid] != prim) {
-						if (COUNT) c_tri++;
-						const float n_u = __uint_as_float(A.y), n_v = __uint_as_float(A.z), n_d = __uint_as_float(A.w);
-						const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
-						const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
-						const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
-						float o_u, o_v, o_k, d_u, d_v, d_k;
-						bool ok = true;
-						if (A.x == 0u) { o_u = oy; o_v = oz; o_k = ox; d_u = dy; d_v = dz; d_k = dx; }
-						else if (A.x == 1u) { o_u = oz; o_v = ox; o_k = oy; d_u = dz; d_v = dx; d_k = dy; }
-						else if (A.x == 2u) { o_u = ox; o_v = oy; o_k = oz; d_u = dx; d_v = dy; d_k = dz; }
-						else { ok = false; o_u = o_v = o_k = d_u = d_v = d_k = 0.0f; }
-						if (MODE != 0 && (C.z & 0x80000000u)) ok = false;    // shape->isOccluder() (skdtree.h:318-333)
-						if (ok) {
-							const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
-							const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
-							if (!(t < mint || t > maxt)) {
-								const float hu = o_u + t * d_u - a_u;
-								const float hv = o_v + t * d_v - a_v;
-								const float u = hv * b_nu + hu * b_nv;
-								const float v = hu * c_nu + hv * c_nv;
-								if (u >= 0 && v >= 0 && u + v <= 1.0f) {
-									if (MODE != 0) { hitShadow = true; break; }
-									maxt = t;      // a later hit with equal t replaces this one (t > maxt rejects)
-									best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = C.z & 0x7FFFFFFFu;
-									found = true;
+				}
+			}
+			if (BIN) {
+				// material sort: one ballot + prefix popcount per bin, one atomic per wave and bin
+				#pragma unroll
+				for (int b = 0; b < kNumBins; ++b) {
+					const bool mine = (bin == b);
+					const uint32_t pos = wave_append(mine, &q.counters[b]);
+					if (mine) q.bins[b][pos] = id;
+				}
+			}
+		} else if (MODE == 1) {
+			// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
+			if (retire && !found) {
+				float4 L = ps.Li[id];
+				const float4 c = ps.nee[id];
+				L.x += c.x; L.y += c.y; L.z += c.z;
+				ps.Li[id] = L;
+			}
+		} else {
+			if (retire)
+				ps.hit[id] = make_uint4(0u, 0u, 0u, found ? 1u : 0u);
+		}
+		retire = false;
+
+		// ---- fetch new rays into idle lanes ----
+		if (moreWork) {
+			const bool need = !has;
+			const unsigned long long needMask = __ballot(need);
+			if (needMask != 0ull) {
+				const uint32_t cnt = (uint32_t) __popcll(needMask);
+				const int leader = __ffsll((long long) needMask) - 1;
+				uint32_t base = 0;
+				if ((int) lane == leader)
+					base = atomicAdd(work_head, cnt);
+				base = __shfl(base, leader);
+				if (base + cnt >= n)
+					moreWork = false;
+				const uint32_t my = base + (uint32_t) __popcll(needMask & ((1ull << lane) - 1ull));
+				if (need && my < n) {
+					id = queue[my];
+					float4 a, b;
+					float rmint, rmaxt;
+					if (MODE == 1) {
+						a = ps.sh_o[id]; b = ps.sh_d[id];
+						rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
+					} else {
+						a = ps.ray_o[id]; b = ps.ray_d[id];
+						rmint = a.w; rmaxt = b.w;
+					}
+					ox = a.x; oy = a.y; oz = a.z; dx = b.x; dy = b.y; dz = b.z;
+					rx = 1.0f / dx; ry = 1.0f / dy; rz = 1.0f / dz;          // Ray::dRcp (ray.h:63-74)
+					// AABB::rayIntersect (aabb.h:349-382) + adaptive epsilon (skdtree.cpp:114-122)
+					bool go = true;
+					mint = -MG_INF; maxt = MG_INF;
+					#pragma unroll
+					for (int i = 0; i < 3; ++i) {
+						const float direction = sel3(dx, dy, dz, i), origin = sel3(ox, oy, oz, i);
+						const float minVal = sc.aabb_min[i], maxVal = sc.aabb_max[i];
+						if (direction == 0) {
+							if (origin < minVal || origin > maxVal) go = false;
+						} else {
+							const float rc = sel3(rx, ry, rz, i);
+							float t1 = (minVal - origin) * rc, t2 = (maxVal - origin) * rc;
+							if (t1 > t2) { const float tmp = t1; t1 = t2; t2 = tmp; }
+							mint = smax(mint, t1);
+							maxt = smin(maxt, t2);
+							if (mint > maxt) go = false;
+						}
+					}
+					float rayMinT = rmint;
+					if (rayMinT == kEpsilon) {
+						float m = smax(smax(fabsf(ox), fabsf(oy)), fabsf(oz));
+						if (MODE == 0) m = smax(m, kEpsilon);    // only the (ray, its) variant has the inner max
+						rayMinT *= m;
+					}
+					if (rayMinT > mint) mint = rayMinT;
+					if (rmaxt < maxt) maxt = rmaxt;
+					if (!(maxt > mint)) go = false;
+
+					best_t = MG_INF; best_u = 0; best_v = 0; best_prim = kNoPrim; best_shape = 0; found = false;
+					if (go) {
+						#pragma unroll
+						for (int i = 0; i < 8; ++i) s_mbox[i][tid] = 0xFFFFFFFFu;
+						// entry point (stack[enPt]) and current exit point (stack[exPt]) in registers
+						en_t = mint; en_split = 0.0f; en_axis = 3;
+						tmax0 = maxt;
+						ex_t = maxt; ex_split = 0.0f; ex_axis = 3; ex_node = kNullNode; ex_ref = kSentinel;
+						sp = 0; cur = 0;
+						has = true;
+					} else {
+						retire = true;
+					}
+				}
+			}
+		}
+		if (__ballot(has || retire) == 0ull)
+			break;
+
+		// ---- traverse ----
+		if (has) {
+			while (true) {
+				uint2 nd = sc.nodes[cur];
+				while (!(nd.x & 0x80000000u)) {
+					const float split = __uint_as_float(nd.y);
+					const int axis = (int) (nd.x & 3u);
+					const uint32_t left = cur + ((nd.x & 0x3FFFFFFCu) >> 2);
+					if (COUNT) c_inner++;
+					const float oa = sel3(ox, oy, oz, axis), da = sel3(dx, dy, dz, axis);
+					// stack[].p[axis]: ray(t) with the pushed axis overwritten by its split (sahkdtree3.h:248-249)
+					const float pen = (axis == en_axis) ? en_split : (oa + en_t * da);
+					const float pex = (axis == ex_axis) ? ex_split : (oa + ex_t * da);
+					uint32_t farRight;
+					if (pen <= split) {
+						if (pex <= split) { cur = left; nd = sc.nodes[cur]; continue; }         // N1-N3, P5, Z2, Z3
+						if (pen == split) { cur = left + 1; nd = sc.nodes[cur]; continue; }     // Z1
+						farRight = 1u;                                                          // N4
+					} else {
+						if (split < pex) { cur = left + 1; nd = sc.nodes[cur]; continue; }      // P1-P3, N5
+						farRight = 0u;                                                          // P4
+					}
+					const float distToSplit = (split - oa) * sel3(rx, ry, rz, axis);
+					// push the current exit point's reference, make (cur, far) the new exit point
+					if (sp < kStackLDS) s_stack[sp][tid] = ex_ref;
+					else q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref;
+					++sp;
+					ex_ref = (cur << 1) | farRight;
+					ex_t = distToSplit; ex_axis = axis; ex_split = split;
+					ex_node = left + farRight;
+					cur = left + (1u - farRight);
+					nd = sc.nodes[cur];
+				}
+
+				// --- leaf: test the primitives (sahkdtree3.h:262-288, skdtree.h:244-336) ---
+				if (COUNT) c_leaf++;
+				bool hitShadow = false;
+				{
+					uint32_t e = nd.x & 0x7FFFFFFFu;
+					const uint32_t last = nd.y;
+					uint4 A, B, C;
+					if (e != last) {
+						const uint4 *ta = sc.leaf_ta + 3 * (size_t) e;
+						A = ta[0]; B = ta[1]; C = ta[2];
+					}
+					while (e != last) {
+						// software pipeline: the next record is in flight while this one is tested
+						uint4 An = A, Bn = B, Cn = C;
+						if (e + 1 != last) {
+							const uint4 *tn = sc.leaf_ta + 3 * (size_t) (e + 1);
+							An = tn[0]; Bn = tn[1]; Cn = tn[2];
+						}
+						const uint32_t prim = C.w;
+						if (COUNT) c_idx++;
+						if (s_mbox[prim & 7u][tid] != prim) {
+							if (COUNT) c_tri++;
+							const float n_u = __uint_as_float(A.y), n_v = __uint_as_float(A.z), n_d = __uint_as_float(A.w);
+							const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
+							const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
+							const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
+							float o_u, o_v, o_k, d_u, d_v, d_k;
+							bool ok = true;
+							if (A.x == 0u) { o_u = oy; o_v = oz; o_k = ox; d_u = dy; d_v = dz; d_k = dx; }
+							else if (A.x == 1u) { o_u = oz; o_v = ox; o_k = oy; d_u = dz; d_v = dx; d_k = dy; }
+							else if (A.x == 2u) { o_u = ox; o_v = oy; o_k = oz; d_u = dx; d_v = dy; d_k = dz; }
+							else { ok = false; o_u = o_v = o_k = d_u = d_v = d_k = 0.0f; }
+							if (MODE != 0 && (C.z & 0x80000000u)) ok = false;    // shape->isOccluder() (skdtree.h:318-333)
+							if (ok) {
+								const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
+								const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
+								if (!(t < mint || t > maxt)) {
+									const float hu = o_u + t * d_u - a_u;
+									const float hv = o_v + t * d_v - a_v;
+									const float u = hv * b_nu + hu * b_nv;
+									const float v = hu * c_nu + hv * c_nv;
+									if (u >= 0 && v >= 0 && u + v <= 1.0f) {
+										if (MODE != 0) { hitShadow = true; break; }
+										maxt = t;      // a later hit with equal t replaces this one (t > maxt rejects)
+										best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = C.z & 0x7FFFFFFFu;
+										found = true;
+									}
 								}
 							}
+							s_mbox[prim & 7u][tid] = prim;
 						}
-						s_mbox[prim & 7u][tid] = prim;
+						A = An; B = Bn; C = Cn;
+						++e;
 					}
-					A = An; B = Bn; C = Cn;
-					++e;
 				}
-			}
-			if (hitShadow) { found = true; break; }
-
-			if (ex_t > maxt)
-				break;
-			// --- pop: the exit point becomes the entry point ---
-			en_t = ex_t; en_axis = ex_axis; en_split = ex_split;
-			cur = ex_node;
-			if (cur == kNullNode)
-				break;
-			--sp;
-			const uint32_t ref = (sp < kStackLDS) ? s_stack[sp][tid]
-			                                      : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
-			if (ref == kSentinel) {
-				ex_t = tmax0; ex_axis = 3; ex_split = 0.0f; ex_node = kNullNode; ex_ref = kSentinel;
-			} else {
-				const uint32_t parent = ref >> 1;
-				const uint2 pn = sc.nodes[parent];
-				const int axis = (int) (pn.x & 3u);
-				const float split = __uint_as_float(pn.y);
-				ex_node = parent + ((pn.x & 0x3FFFFFFCu) >> 2) + (ref & 1u);
-				ex_t = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
-				ex_axis = axis; ex_split = split; ex_ref = ref;
-			}
-		}
-	}
-
-	// --- epilogue ---
-	if (MODE == 0) {
-		int bin = -1;
-		if (active) {
-			ps.hit[id] = make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim);
-			if (BIN) {
-				bin = kNumBins - 1;
-				if (found) {
-					const int b = sc.shape_bsdf[best_shape];
-					if (b >= 0) bin = (int) sc.bsdf_type[b];
+				bool finished = false;
+				if (hitShadow) { found = true; finished = true; }
+				else if (ex_t > maxt) finished = true;
+				else {
+					// --- pop: the exit point becomes the entry point ---
+					en_t = ex_t; en_axis = ex_axis; en_split = ex_split;
+					cur = ex_node;
+					if (cur == kNullNode) {
+						finished = true;
+					} else {
+						--sp;
+						const uint32_t ref = (sp < kStackLDS) ? s_stack[sp][tid]
+						                                      : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
+						if (ref == kSentinel) {
+							ex_t = tmax0; ex_axis = 3; ex_split = 0.0f; ex_node = kNullNode; ex_ref = kSentinel;
+						} else {
+							const uint32_t parent = ref >> 1;
+							const uint2 pn = sc.nodes[parent];
+							const int axis = (int) (pn.x & 3u);
+							const float split = __uint_as_float(pn.y);
+							ex_node = parent + ((pn.x & 0x3FFFFFFCu) >> 2) + (ref & 1u);
+							ex_t = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
+							ex_axis = axis; ex_split = split; ex_ref = ref;
+						}
+					}
 				}
+				if (finished) { has = false; retire = true; break; }
+				// too few lanes left traversing: go back and refill the idle ones
+				if (moreWork && __popcll(__ballot(true)) < q.fetch_threshold)
+					break;
 			}
 		}
-		if (BIN) {
-			// material sort: one ballot + prefix popcount per bin, one atomic per wave and bin
-			#pragma unroll
-			for (int b = 0; b < kNumBins; ++b) {
-				const bool mine = (bin == b);
-				const uint32_t pos = wave_append(mine, &q.counters[b]);
-				if (mine) q.bins[b][pos] = id;
-			}
-		}
-	} else if (MODE == 1) {
-		// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
-		if (active && !found) {
-			float4 L = ps.Li[id];
-			const float4 c = ps.nee[id];
-			L.x += c.x; L.y += c.y; L.z += c.z;
-			ps.Li[id] = L;
-		}
-	} else {
-		if (active)
-			ps.hit[id] = make_uint4(0u, 0u, 0u, found ? 1u : 0u);
 	}
 
 	if (COUNT) {
@@ -426,7 +467,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, DPaths ps, DQu
 			unsigned long long x = v[k];
 			for (int off = 32; off > 0; off >>= 1)
 				x += __shfl_down(x, off);
-			if (lane_id() == 0)
+			if (lane == 0)
 				atomicAdd(&q.trace_counts[k], x);
 		}
 	}
@@ -1039,7 +1080,10 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 
 template <int MODE, bool COUNT, bool BIN>
 static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n) {
-	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks_for(n, kTraceBlock)), dim3(kTraceBlock), 0, s, sc, ps, q, queue, n);
+	// persistent grid: enough workgroups to fill every CU, never more than there are rays
+	const unsigned blocks = std::min<unsigned>(blocks_for(n, kTraceBlock), kTraceGridBlocks);
+	uint32_t *head = q.counters + (MODE == 1 ? kNumBins + 3 : kNumBins + 2);
+	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, sc, ps, q, queue, n, head);
 }
 
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
