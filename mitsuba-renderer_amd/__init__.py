@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtsgpu.so")
 
 EXPORTS = [
-    "mtsgpu_create", "mtsgpu_destroy", "mtsgpu_last_error", "mtsgpu_abi_version", "mtsgpu_set_stream",
+    "mtsgpu_create", "mtsgpu_destroy", "mtsgpu_last_error", "mtsgpu_abi_version", "mtsgpu_abi_sizeof", "mtsgpu_set_stream",
     "mtsgpu_upload_scene", "mtsgpu_set_camera", "mtsgpu_set_integrator", "mtsgpu_set_sampler",
     "mtsgpu_set_tiles", "mtsgpu_set_film_buffer", "mtsgpu_set_options", "mtsgpu_render", "mtsgpu_sync",
     "mtsgpu_read_film", "mtsgpu_clear_film", "mtsgpu_get_stats", "mtsgpu_trace_rays", "mtsgpu_ld_tables",
@@ -59,6 +59,7 @@ def lib():
     L.mtsgpu_destroy.argtypes = [vp]; L.mtsgpu_destroy.restype = None
     L.mtsgpu_last_error.argtypes = [vp]; L.mtsgpu_last_error.restype = C.c_char_p
     L.mtsgpu_abi_version.argtypes = []
+    L.mtsgpu_abi_sizeof.argtypes = [C.c_int]; L.mtsgpu_abi_sizeof.restype = C.c_size_t
     L.mtsgpu_set_stream.argtypes = [vp, vp]
     L.mtsgpu_upload_scene.argtypes = [vp, C.POINTER(abi.Scene)]
     L.mtsgpu_set_camera.argtypes = [vp, C.POINTER(abi.Camera)]

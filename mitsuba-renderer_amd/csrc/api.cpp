@@ -233,6 +233,18 @@ extern "C" {
 
 int mtsgpu_abi_version(void) { return MTSGPU_ABI_VERSION; }
 
+size_t mtsgpu_abi_sizeof(int which) {
+	switch (which) {
+		case 0: return sizeof(mtsgpu_scene);
+		case 1: return sizeof(mtsgpu_camera);
+		case 2: return sizeof(mtsgpu_stats);
+		case 3: return sizeof(mtsgpu_mesh);
+		case 4: return sizeof(mtsgpu_scene_desc);
+		case 5: return sizeof(mtsgpu_kd_params);
+		default: return 0;
+	}
+}
+
 const char *mtsgpu_last_error(const mtsgpu_ctx *ctx) { return ctx ? ctx->error.c_str() : g_lastError.c_str(); }
 
 int mtsgpu_create(int device, mtsgpu_ctx **out) {

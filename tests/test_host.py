@@ -1,0 +1,118 @@
+"""Host-side logic of the product (no GPU needed): ABI surface, flattening, kd-tree builder, error paths."""
+import ctypes as C
+import re
+import os
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _same(a, b):
+    a = np.atleast_1d(np.asarray(a)); b = np.atleast_1d(np.asarray(b))
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def test_library_exports_every_declared_symbol(mts):
+    L = mts.lib()
+    header = open(os.path.join(ROOT, "include", "mtsgpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(mtsgpu_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(L, name), "libmtsgpu.so does not export %s" % name
+    assert sorted(mts.EXPORTS) == declared
+    assert L.mtsgpu_abi_version() == mts.abi.ABI_VERSION
+
+
+def test_ctypes_layout_matches_the_compiled_structs(mts):
+    L, a = mts.lib(), mts.abi
+    for which, typ in enumerate([a.Scene, a.Camera, a.Stats, a.Mesh, a.SceneDesc, a.KdParams]):
+        assert L.mtsgpu_abi_sizeof(which) == C.sizeof(typ), typ.__name__
+
+
+def test_no_gpu_means_a_loud_error_not_a_fallback(mts):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(mts.MtsGpuError) as e:
+        mts.MIPathTracer(maxDepth=4)
+    assert "no HIP device" in str(e.value) or "CPU fallback" in str(e.value)
+
+
+@pytest.mark.parametrize("maker", [
+    lambda s: s.cornell_c1(),
+    lambda s: s.cornell_c3(grid=12, sphere_subdiv=2),
+    lambda s: s.cornell_c5(sphere_subdiv=2),
+    lambda s: s.cornell_c3(grid=40, sphere_subdiv=3),
+])
+def test_flatten_matches_oracle_bit_for_bit(mts, orc, maker):
+    """normals, area CDFs, TriAccel table, SAH kd-tree (nodes + indices), enlarged AABB, bsphere"""
+    sd = maker(mts.scenes)
+    A, B = orc.FlatScene(sd).arrays(), mts.Scene(sd).arrays()
+    assert sorted(A) == sorted(B)
+    bad = [k for k in A if not _same(A[k], B[k])]
+    assert not bad, bad
+
+
+def test_min_max_binning_phase_matches_oracle(mts, orc):
+    """force the > exactPrimThreshold code path (binning, tight boxes, parallel sub-tree jobs) on a small scene"""
+    sd = mts.scenes.cornell_c3(grid=24, sphere_subdiv=2)
+    kp = mts.abi.KdParams(); kp.exact_prim_threshold = 500
+    A, B = orc.FlatScene(sd, kp).arrays(), mts.Scene(sd, kp).arrays()
+    assert _same(A["kd_nodes"], B["kd_nodes"]) and _same(A["kd_indices"], B["kd_indices"])
+    kp1 = mts.abi.KdParams(); kp1.exact_prim_threshold = 500; kp1.n_threads = 1
+    C1 = mts.Scene(sd, kp1).arrays()
+    assert _same(C1["kd_nodes"], B["kd_nodes"]), "tree depends on the number of build threads"
+
+
+def test_kdtree_is_structurally_valid(mts):
+    sd = mts.scenes.cornell_c3(grid=16, sphere_subdiv=2)
+    sc = mts.Scene(sd)
+    A = sc.arrays()
+    nodes, idx = A["kd_nodes"], A["kd_indices"]
+    seen = np.zeros(sd.n_tris, dtype=bool)
+    stack, visited, depth_max = [(0, 1)], 0, 0
+    while stack:
+        n, d = stack.pop()
+        visited += 1; depth_max = max(depth_max, d)
+        a, b = int(nodes[n, 0]), int(nodes[n, 1])
+        if a & 0x80000000:
+            seen[idx[(a & 0x7FFFFFFF):b]] = True
+        else:
+            assert (a & 3) < 3
+            left = n + ((a & 0x3FFFFFFC) >> 2)
+            stack += [(left, d + 1), (left + 1, d + 1)]
+    assert visited == len(nodes) and seen.all()
+    assert depth_max <= 48                       # MTS_KD_MAXDEPTH
+    st = sc.kdstats()
+    assert st["inner"] + st["leaf"] == len(nodes) and st["indices"] == len(idx)
+
+
+def test_camera_matches_oracle(mts, orc):
+    sd = mts.scenes.cornell_c1()
+    for (w, h) in ((256, 256), (320, 200), (200, 320)):
+        a = mts.PerspectiveCamera.for_description(sd, w, h).c
+        b = orc.make_camera(sd, w, h)
+        assert bytes(a) == bytes(b)
+    # raster centre maps to the optical axis
+    m = np.array(list(mts.PerspectiveCamera.for_description(sd, 256, 256).c.raster_to_camera)).reshape(4, 4)
+    p = m @ np.array([128, 128, 0, 1.0]); p = p[:3] / p[3]
+    assert abs(p[0]) < 1e-6 and abs(p[1]) < 1e-6
+
+
+def test_flatten_rejects_bad_input(mts):
+    sd = mts.scenes.cornell_c1()
+    sd.meshes[0].triangles[0, 0] = 99
+    with pytest.raises(mts.MtsGpuError):
+        mts.Scene(sd)
+    sd = mts.scenes.cornell_c1()
+    sd.meshes[0].bsdf = 42
+    with pytest.raises(mts.MtsGpuError):
+        mts.Scene(sd)
+
+
+def test_tiles_of_rank_partition(mts):
+    W, H = 100, 70
+    parts = [mts.filmreduce.tiles_of_rank(W, H, 32, r, 3) for r in range(3)]
+    allp = np.concatenate(parts)
+    assert len(allp) == W * H and len(np.unique(allp)) == W * H

@@ -1,0 +1,209 @@
+"""Oracle self-checks on CPU: traversal vs brute force, BSDF chi-square (method of
+src/tests/test_chisquare.cpp:299-420), integrator quirks, sampler equivalence."""
+import ctypes as C
+import numpy as np
+import pytest
+from conftest import chord_rays
+
+f32p = C.POINTER(C.c_float)
+
+
+def _p(a):
+    return a.ctypes.data_as(f32p)
+
+
+def _brute_force(A, rays):
+    """closest hit over ALL TriAccel records with TriAccel::rayIntersect semantics (float32, numpy)"""
+    ta = A["triaccel"]
+    f = ta.view(np.float32)
+    out_t = np.full(len(rays), np.inf, dtype=np.float32)
+    for k in range(3):
+        sel = np.nonzero(ta[:, 0] == k)[0]
+        if not len(sel):
+            continue
+        ku, kv = (k + 1) % 3, (k + 2) % 3
+        F = f[sel]
+        for i, r in enumerate(rays):
+            o, d = r[0:3], r[4:7]
+            recip = np.float32(1.0) / (d[ku] * F[:, 1] + d[kv] * F[:, 2] + d[k])
+            t = (F[:, 3] - o[ku] * F[:, 1] - o[kv] * F[:, 2] - o[k]) * recip
+            hu = o[ku] + t * d[ku] - F[:, 4]
+            hv = o[kv] + t * d[kv] - F[:, 5]
+            u = hv * F[:, 6] + hu * F[:, 7]
+            v = hu * F[:, 8] + hv * F[:, 9]
+            ok = (t >= r[3]) & (t <= r[7]) & (u >= 0) & (v >= 0) & (u + v <= 1)
+            if ok.any():
+                out_t[i] = min(out_t[i], t[ok].min())
+    return out_t
+
+
+def test_traversal_equals_brute_force(mts, orc):
+    sd = mts.scenes.cornell_c3(grid=6, sphere_subdiv=1)
+    fs = orc.FlatScene(sd)
+    A = fs.arrays()
+    rays = chord_rays(400, (0, 1, 0), 2.2, seed=11)
+    # no adaptive epsilon for the comparison: mint != Epsilon
+    rays[:, 3] = 2e-4
+    with np.errstate(all="ignore"):
+        exp = _brute_force(A, rays)
+    hits, tc = orc.trace_rays(fs.scene, rays, counts=True)
+    got = hits[:, 0].copy().view(np.float32)
+    assert np.array_equal(got, exp)
+    assert tc.n_inner > 0 and tc.n_tri_tested <= tc.n_idx
+
+
+def test_shadow_rays_ignore_non_occluders(mts, orc):
+    sd = mts.scenes.cornell_c1()
+    for m in sd.meshes:
+        if m.name == "back":
+            m.bsdf = -1                      # no BSDF -> Shape::isOccluder() false (skdtree.h:318-333)
+    fs = orc.FlatScene(sd)
+    ray = np.array([[0, 1, 3, 1e-3, 0, 0, -8, 1 - 1e-3]], dtype=np.float32)
+    assert orc.trace_rays(fs.scene, ray, shadow=True)[0, 3] == 0
+    assert orc.trace_rays(fs.scene, ray)[0, 3] != 0xFFFFFFFF     # closest-hit still sees it
+
+
+def _chi2_bsdf(orc, btype, params, wi, n=200000, nt=10, nph=20, seed=3):
+    from scipy import stats
+    L = orc.lib()
+    rng = np.random.RandomState(seed)
+    P = np.zeros(16, dtype=np.float32); P[:len(params)] = params
+    wi = np.asarray(wi, dtype=np.float32); wi /= np.linalg.norm(wi)
+    hist = np.zeros((nt, nph))
+    wo = np.zeros(3, dtype=np.float32); out = np.zeros(3, dtype=np.float32)
+    pdf = C.c_float(); st = C.c_uint32()
+    s = rng.rand(n, 2).astype(np.float32)
+    valid = 0
+    for k in range(n):
+        L.orc_bsdf_sample(btype, _p(P), _p(wi), _p(s[k]), _p(wo), C.byref(pdf), C.byref(st), _p(out))
+        if pdf.value <= 0:
+            continue
+        valid += 1
+        ct = min(max(wo[2], 0.0), 1.0)
+        ph = np.arctan2(wo[1], wo[0]) % (2 * np.pi)
+        hist[min(int(ct * nt), nt - 1), min(int(ph / (2 * np.pi) * nph), nph - 1)] += 1
+    # expected counts: integrate pdf over each (cos theta, phi) cell (midpoint rule on a fine grid)
+    sub = 24
+    expected = np.zeros((nt, nph))
+    w2 = np.zeros(3, dtype=np.float32)
+    for i in range(nt):
+        for j in range(nph):
+            acc = 0.0
+            for a in range(sub):
+                ct = (i + (a + 0.5) / sub) / nt
+                stn = np.sqrt(max(0.0, 1 - ct * ct))
+                for b in range(4):
+                    ph = (j + (b + 0.5) / 4) / nph * 2 * np.pi
+                    w2[:] = (stn * np.cos(ph), stn * np.sin(ph), ct)
+                    acc += L.orc_bsdf_pdf(btype, _p(P), _p(wi), _p(w2))
+            expected[i, j] = acc / (sub * 4) * (1.0 / nt) * (2 * np.pi / nph) * n
+    # pool cells with small expectation (test_chisquare.cpp pools below 5)
+    e, o = expected.ravel(), hist.ravel()
+    big = e >= 5
+    e2 = np.append(e[big], e[~big].sum()); o2 = np.append(o[big], o[~big].sum())
+    if e2[-1] < 5:
+        e2, o2 = e2[:-1], o2[:-1]
+    e2 = e2 * (o2.sum() / e2.sum())
+    chi2 = ((o2 - e2) ** 2 / e2).sum()
+    return 1 - stats.chi2.cdf(chi2, len(e2) - 1), valid / n
+
+
+@pytest.mark.parametrize("name,btype,params,wi", [
+    ("lambertian", 0, [0.5, 0.5, 0.5], (0.3, 0.2, 0.9)),
+    ("roughmetal", 2, [0.3, 0.37, 0.37, 0.37, 2.82, 2.82, 2.82, 1, 1, 1], (0.4, 0.0, 0.9)),
+    ("microfacet", 3, [0.3, 0.5, 0.5, 1.5, 1.0, 1, 1, 1, 1, 1, 1], (0.5, 0.1, 0.8)),
+])
+def test_bsdf_sampling_matches_pdf_chi_square(orc, name, btype, params, wi):
+    """sample() histogram vs integrated pdf(); significance level 0.005 as in test_chisquare.cpp:28"""
+    p, frac = _chi2_bsdf(orc, btype, np.asarray(params, dtype=np.float32), wi, n=40000)
+    assert frac > 0.5
+    assert p > 0.005, "%s: chi-square p-value %g" % (name, p)
+
+
+def test_bsdf_value_over_pdf_consistency(orc):
+    """sample(bRec, pdf, s) returns f and pdf that agree with f() and pdf() at the sampled direction"""
+    L = orc.lib()
+    rng = np.random.RandomState(0)
+    for btype, params in ((0, [0.7, 0.6, 0.5]), (2, [0.1, 0.37, 0.37, 0.37, 2.82, 2.82, 2.82, 1, 1, 1]),
+                          (3, [0.1, 0.5, 0.5, 1.5, 1.0, 1, 1, 1, 1, 1, 1])):
+        P = np.zeros(16, dtype=np.float32); P[:len(params)] = params
+        for _ in range(200):
+            wi = rng.randn(3).astype(np.float32); wi[2] = abs(wi[2]) + 0.1; wi /= np.linalg.norm(wi)
+            s = rng.rand(2).astype(np.float32)
+            wo = np.zeros(3, dtype=np.float32); out = np.zeros(3, dtype=np.float32); f = np.zeros(3, dtype=np.float32)
+            pdf = C.c_float(); st = C.c_uint32()
+            L.orc_bsdf_sample(btype, _p(P), _p(wi), _p(s), _p(wo), C.byref(pdf), C.byref(st), _p(out))
+            if pdf.value == 0:
+                continue
+            L.orc_bsdf_f(btype, _p(P), _p(wi), _p(wo), _p(f))
+            assert np.array_equal(f, out)
+            assert L.orc_bsdf_pdf(btype, _p(P), _p(wi), _p(wo)) == pdf.value
+
+
+def test_dielectric_is_delta_and_energy_conserving(orc):
+    L = orc.lib()
+    P = np.zeros(16, dtype=np.float32); P[:8] = [1.5046, 1.0, 1, 1, 1, 1, 1, 1]
+    wi = np.array([0.3, 0.1, 0.9], dtype=np.float32); wi /= np.linalg.norm(wi)
+    wo = np.zeros(3, dtype=np.float32); out = np.zeros(3, dtype=np.float32)
+    pdf = C.c_float(); st = C.c_uint32()
+    assert L.orc_bsdf_pdf(1, _p(P), _p(wi), _p(wi)) == 0            # dielectric.cpp:105-107
+    kinds = set()
+    for sx in np.linspace(0, 1, 50, dtype=np.float32):
+        s = np.array([sx, 0.5], dtype=np.float32)
+        L.orc_bsdf_sample(1, _p(P), _p(wi), _p(s), _p(wo), C.byref(pdf), C.byref(st), _p(out))
+        kinds.add(st.value)
+        val = out * abs(wo[2]) / pdf.value                         # what path.cpp:136-138 computes
+        if st.value == 0x4:
+            assert np.allclose(val, 1.0, atol=1e-6) and wo[2] > 0
+        else:
+            eta = 1.0 / 1.5046
+            assert np.allclose(val, eta * eta, atol=1e-6) and wo[2] < 0   # radiance scaling eta^2
+    assert kinds == {0x4, 0x8}
+
+
+def test_max_depth_quirks(mts, orc):
+    """maxDepth=1: only directly visible emitters (path.cpp:87); maxDepth=2 adds direct light only"""
+    sd = mts.scenes.cornell_c1()
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 48, 48)
+    f1, _ = orc.render(fs.scene, cam, orc.render_params(1, spp=4))
+    img1 = orc.develop(f1)
+    lit = img1.sum(axis=2) > 0
+    assert 0 < lit.sum() < 48 * 48 * 0.1
+    assert np.allclose(img1[lit].max(), 15.0)
+    assert np.all(f1[..., 3] == f1[..., 4])                       # closed view: alpha == weight
+    f2, st2 = orc.render(fs.scene, cam, orc.render_params(2, spp=4))
+    assert orc.develop(f2).mean() > img1.mean()
+    # depth 2: one camera ray + one BSDF ray per sample that hit a surface; rr never fires (rrDepth 10)
+    assert st2.rays_closest <= 2 * 48 * 48 * 4
+
+
+def test_keyed_and_reference_samplers_agree_statistically(mts, orc):
+    """the keyed samplers replace Random's stream, not the estimator: means agree within noise"""
+    sd = mts.scenes.cornell_c1()
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 24, 24)
+    means = []
+    for kind in (mts.abi.SAMPLER_INDEPENDENT_KEYED, mts.abi.SAMPLER_LD_KEYED):
+        f, _ = orc.render(fs.scene, cam, orc.render_params(4, sampler=kind, spp=64, seed=9))
+        means.append(orc.develop(f).mean())
+    for kind in (0, 1):
+        film = np.zeros((24, 24, 5), dtype=np.float32)
+        prm = orc.render_params(4, spp=64, seed=5489)
+        orc.lib().orc_render_rect_mt(fs.scene, C.byref(cam), C.byref(prm), kind, 0, 0, 24, 24, _p(film))
+        means.append(orc.develop(film).mean())
+    means = np.array(means)
+    assert np.all(np.abs(means / means.mean() - 1) < 0.03), means
+
+
+def test_film_weights_and_determinism(mts, orc):
+    sd = mts.scenes.cornell_c5(sphere_subdiv=1)
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 20, 16)
+    prm = orc.render_params(6, sampler=mts.abi.SAMPLER_LD_KEYED, spp=16, seed=2)
+    a, _ = orc.render(fs.scene, cam, prm)
+    prm1 = orc.render_params(6, sampler=mts.abi.SAMPLER_LD_KEYED, spp=16, seed=2, n_threads=1)
+    b, _ = orc.render(fs.scene, cam, prm1)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))   # thread count does not matter
+    assert a[..., 4].max() <= 16 and a[..., 4].min() >= 14        # weight 0 only for samples on pixel borders
+    assert (a[..., 3] <= a[..., 4]).all() and a[..., 3].min() < 16  # env-lit opening: alpha < 1 somewhere
