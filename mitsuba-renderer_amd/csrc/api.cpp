@@ -344,7 +344,44 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	c->haveScene = false;
 	DScene d{};
 	int rc = 0;
-	rc |= upload(c, (const uint32_t **) &d.nodes, sc->kd_nodes, 2 * (size_t) sc->n_nodes);
+	{
+		// Device node order: 128-byte lines (16 nodes) are filled with breadth-first pieces of
+		// subtrees ("treelets") so that one L1 miss serves several consecutive traversal steps.
+		// The KDNode encoding is unchanged (siblings adjacent, relative offset to the left child,
+		// gkdtree.h:442-470); only where a node lives changes, which traversal results do not depend on.
+		const uint32_t N = sc->n_nodes;
+		std::vector<uint32_t> newIndex(N, 0u);
+		std::vector<uint32_t> stack, cand;           // entries: old index of the left node of a sibling pair
+		auto leftOf = [&](uint32_t i) { return i + ((sc->kd_nodes[2 * (size_t) i] & 0x3FFFFFFCu) >> 2); };
+		auto isLeaf = [&](uint32_t i) { return (sc->kd_nodes[2 * (size_t) i] & 0x80000000u) != 0; };
+		uint32_t pos = 2;                            // slot 0 = root, slot 1 = padding
+		newIndex[0] = 0;
+		if (!isLeaf(0)) cand.push_back(leftOf(0));
+		size_t head = 0;
+		while (head < cand.size() || !stack.empty()) {
+			if (head == cand.size()) { cand.clear(); head = 0; cand.push_back(stack.back()); stack.pop_back(); }
+			const uint32_t l = cand[head++];
+			newIndex[l] = pos; newIndex[l + 1] = pos + 1;
+			pos += 2;
+			for (uint32_t k = 0; k < 2; ++k)
+				if (!isLeaf(l + k)) cand.push_back(leftOf(l + k));
+			if ((pos & 15u) == 0u) {
+				// line full: the remaining frontier becomes the roots of later treelets (depth-first order)
+				for (size_t k = cand.size(); k > head; --k) stack.push_back(cand[k - 1]);
+				cand.clear(); head = 0;
+			}
+		}
+		const uint32_t total = std::max<uint32_t>(pos, 2u);
+		std::vector<uint32_t> dev(2 * (size_t) total, 0u);
+		dev[2] = 0x80000000u; dev[3] = 0u;           // padding slot: empty leaf, never referenced
+		for (uint32_t i = 0; i < N; ++i) {
+			const uint32_t a = sc->kd_nodes[2 * (size_t) i], b = sc->kd_nodes[2 * (size_t) i + 1];
+			uint32_t *o = &dev[2 * (size_t) newIndex[i]];
+			if (a & 0x80000000u) { o[0] = a; o[1] = b; }
+			else { o[0] = (a & 3u) | ((newIndex[leftOf(i)] - newIndex[i]) << 2); o[1] = b; }
+		}
+		rc |= upload(c, (const uint32_t **) &d.nodes, dev.data(), dev.size());
+	}
 	{
 		// TriAccel records re-laid out in leaf order (one contiguous run per leaf, no index
 		// indirection on the device); bit 31 of the shape dword marks non-occluders
