@@ -7,7 +7,7 @@ namespace mg {
 
 constexpr int kNumBins = 5;           // 4 BSDF types + "terminal" (miss / no BSDF)
 constexpr int kTraceBlock = 256;
-constexpr unsigned kTraceGridBlocks = 256 * 5;   // persistent traversal grid: 256 CUs x resident workgroups
+constexpr unsigned kTraceGridBlocks = 256 * 6;   // persistent traversal grid: 256 CUs x resident workgroups
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 
 // Scene in HBM (all pointers are device pointers); see DESIGN.md section 3

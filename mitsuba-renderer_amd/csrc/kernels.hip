@@ -192,8 +192,8 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 // free), levels beyond kStackLDS spill to HBM.  The 8-entry hashed mailbox
 // (sahkdtree3.h:130-144) is kept (LDS) because it decides equal-t ties.
 // ===========================================================================
-constexpr int kStackLDS = 24;
-constexpr int kSpillLevels = 32;      // 24 + 32 >= MTS_KD_MAXDEPTH (48) + 2
+constexpr int kStackLDS = 16;
+constexpr int kSpillLevels = 36;      // 16 + 36 >= MTS_KD_MAXDEPTH (48) + 2
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 
@@ -205,7 +205,7 @@ size_t trace_spill_levels() { return kSpillLevels; }
 // lengths do not leave most of a wave's memory requests unissued.
 
 template <int MODE, bool COUNT, bool BIN>
-__global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, DPaths ps, DQueues q,
+__global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, DQueues q,
                                                        const uint32_t *queue, uint32_t n, uint32_t *work_head) {
 	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
 	__shared__ uint32_t s_mbox[8][kTraceBlock];
