@@ -103,13 +103,7 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	cap = (cap + 255) & ~(size_t) 255;
 	auto &o = c->pathAllocs;
 	int rc = 0;
-	rc |= devAlloc(c, &c->paths.ray_o, cap, o); rc |= devAlloc(c, &c->paths.ray_d, cap, o);
-	rc |= devAlloc(c, &c->paths.hit, cap, o); rc |= devAlloc(c, &c->paths.thr, cap, o);
-	rc |= devAlloc(c, &c->paths.Li, cap, o); rc |= devAlloc(c, &c->paths.bsdf, cap, o);
-	rc |= devAlloc(c, &c->paths.nee, cap, o); rc |= devAlloc(c, &c->paths.sh_o, cap, o);
-	rc |= devAlloc(c, &c->paths.sh_d, cap, o); rc |= devAlloc(c, &c->paths.rng, cap, o);
-	rc |= devAlloc(c, &c->paths.spos, cap, o); rc |= devAlloc(c, &c->paths.pix, cap, o);
-	rc |= devAlloc(c, &c->paths.smp, cap, o);
+	rc |= devAlloc(c, &c->paths.base, cap * kPathSlots, o);
 	for (int b = 0; b < kNumBins; ++b) rc |= devAlloc(c, &c->q.bins[b], cap, o);
 	rc |= devAlloc(c, &c->queueA, cap, o); rc |= devAlloc(c, &c->queueB, cap, o);
 	rc |= devAlloc(c, &c->q.shadow, cap, o);
@@ -579,13 +573,13 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 	c->traceEvUsed = c->shadeEvUsed = 0;
 	if (n == 0) return 0;
 	int rc = ensurePaths(c, n); if (rc) return rc;
-	std::vector<float> o(4 * (size_t) n), d(4 * (size_t) n);
-	for (size_t i = 0; i < n; ++i) {
-		std::memcpy(&o[4 * i], rays + 8 * i, 16);
-		std::memcpy(&d[4 * i], rays + 8 * i + 4, 16);
+	{
+		// host rays -> ray_o / ray_d slots of the path records
+		std::vector<float> od(8 * (size_t) n);
+		std::memcpy(od.data(), rays, od.size() * sizeof(float));
+		HIPCHK(c, hipMemcpy2DAsync(c->paths.base, kPathSlots * sizeof(float4), od.data(), 32, 32, n, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
 	}
-	HIPCHK(c, hipMemcpyAsync(c->paths.ray_o, o.data(), o.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-	HIPCHK(c, hipMemcpyAsync(c->paths.ray_d, d.data(), d.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
 	launch_iota(c->stream, c->queueA, n);
 	HIPCHK(c, hipMemsetAsync(c->q.counters, 0, 16 * sizeof(uint32_t), c->stream));
 	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 4 * sizeof(unsigned long long), c->stream));
@@ -594,7 +588,7 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 	launch_trace(c->stream, shadow ? 2 : 0, c->countTraversal, false, c->dsc, c->paths, c->q, c->queueA, n);
 	if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
 	HIPCHK(c, hipGetLastError());
-	HIPCHK(c, hipMemcpyAsync(hits, c->paths.hit, (size_t) n * 16, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpy2DAsync(hits, 16, c->paths.base + 2, kPathSlots * sizeof(float4), 16, n, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	c->stats.trace_launches = 1;
 	if (shadow) c->stats.rays_shadow = n; else c->stats.rays_closest = n;
@@ -662,17 +656,18 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 	launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList, n, c->explicitSamples, n, c->queueA);
 	HIPCHK(c, hipGetLastError());
 	rc = runBounces(c, cfg, n, nullptr); if (rc) return rc;
-	std::vector<float> Li(4 * (size_t) n), thr(4 * (size_t) n), spos(2 * (size_t) n);
-	HIPCHK(c, hipMemcpyAsync(Li.data(), c->paths.Li, Li.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipMemcpyAsync(thr.data(), c->paths.thr, thr.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(c, hipMemcpyAsync(spos.data(), c->paths.spos, spos.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	std::vector<float> Li(4 * (size_t) n), thr(4 * (size_t) n), spos(4 * (size_t) n);
+	const size_t pitch = kPathSlots * sizeof(float4);
+	HIPCHK(c, hipMemcpy2DAsync(Li.data(), 16, c->paths.base + 4, pitch, 16, n, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpy2DAsync(thr.data(), 16, c->paths.base + 3, pitch, 16, n, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpy2DAsync(spos.data(), 16, c->paths.base + 7, pitch, 16, n, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	for (size_t i = 0; i < n; ++i) {
 		uint32_t flags; int depth;
 		std::memcpy(&flags, &Li[4 * i + 3], 4); std::memcpy(&depth, &thr[4 * i + 3], 4);
 		float *o = out + 8 * i;
 		o[0] = Li[4 * i]; o[1] = Li[4 * i + 1]; o[2] = Li[4 * i + 2]; o[3] = (flags & F_ALPHA) ? 1.0f : 0.0f;
-		o[4] = spos[2 * i]; o[5] = spos[2 * i + 1]; o[6] = (float) depth; o[7] = 0.0f;
+		o[4] = spos[4 * i]; o[5] = spos[4 * i + 1]; o[6] = (float) depth; o[7] = 0.0f;
 	}
 	collectTimings(c);
 	return 0;

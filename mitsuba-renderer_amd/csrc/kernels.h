@@ -36,21 +36,26 @@ struct DScene {
 	float aabb_min[3], aabb_max[3];
 };
 
-// Per-path state, SoA, indexed by path id (paths never move; queues hold ids)
+// Per-path state, indexed by path id (paths never move; queues hold ids).
+// One 256-byte record per path = two 128-byte lines, so that the id-indexed gathers of the
+// shading and traversal kernels cost one or two L1 misses instead of one per field:
+//   line 0: ray_o, ray_d, hit, thr, Li, bsdf, misc, spos   (everything a bounce reads)
+//   line 1: nee, sh_o, sh_d                                  (the pending shadow ray)
+constexpr int kPathSlots = 16;        // float4 slots per record
 struct DPaths {
-	float4 *ray_o;   // o.xyz, mint
-	float4 *ray_d;   // d.xyz, maxt
-	uint4  *hit;     // t bits, u bits, v bits, prim (kNoPrim = miss)
-	float4 *thr;     // throughput rgb, w = depth (int bits)
-	float4 *Li;      // Li rgb, w = flags (uint bits)
-	float4 *bsdf;    // bsdfVal/pdf rgb, w = bsdfPdf
-	float4 *nee;     // pending direct-light contribution rgb
-	float4 *sh_o;    // shadow ray origin p1
-	float4 *sh_d;    // shadow ray direction p2 - p1 (unnormalised)
-	uint2  *rng;     // keyed overflow stream state
-	float2 *spos;    // raster position of the camera sample
-	uint32_t *pix;   // pixel key y*W+x
-	uint32_t *smp;   // sample index within the pixel
+	float4 *base;
+	__host__ __device__ float4 &slot(size_t id, int k) const { return base[id * kPathSlots + k]; }
+	__host__ __device__ float4 &ray_o(size_t id) const { return slot(id, 0); }   // o.xyz, mint
+	__host__ __device__ float4 &ray_d(size_t id) const { return slot(id, 1); }   // d.xyz, maxt
+	__host__ __device__ uint4  &hit(size_t id) const { return reinterpret_cast<uint4 &>(slot(id, 2)); }  // t, u, v bits, prim
+	__host__ __device__ float4 &thr(size_t id) const { return slot(id, 3); }     // throughput rgb, w = depth (int bits)
+	__host__ __device__ float4 &Li(size_t id) const { return slot(id, 4); }      // Li rgb, w = flags (uint bits)
+	__host__ __device__ float4 &bsdf(size_t id) const { return slot(id, 5); }    // bsdfVal/pdf rgb, w = bsdfPdf
+	__host__ __device__ uint4  &misc(size_t id) const { return reinterpret_cast<uint4 &>(slot(id, 6)); } // rng lo, rng hi, sample idx, pixel key
+	__host__ __device__ float4 &spos(size_t id) const { return slot(id, 7); }    // raster position x, y
+	__host__ __device__ float4 &nee(size_t id) const { return slot(id, 8); }     // pending direct-light contribution rgb
+	__host__ __device__ float4 &sh_o(size_t id) const { return slot(id, 9); }    // shadow ray origin p1
+	__host__ __device__ float4 &sh_d(size_t id) const { return slot(id, 10); }   // shadow ray direction p2 - p1
 };
 
 // flags in Li.w

@@ -166,15 +166,13 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 	     w[4] * ld.x + w[5] * ld.y + w[6] * ld.z,
 	     w[8] * ld.x + w[9] * ld.y + w[10] * ld.z);
 
-	ps.ray_o[id] = make_float4(o.x, o.y, o.z, mint);
-	ps.ray_d[id] = make_float4(d.x, d.y, d.z, maxt);
-	ps.thr[id] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(1));   // depth = 1 (integrator.h:186-191)
+	ps.ray_o(id) = make_float4(o.x, o.y, o.z, mint);
+	ps.ray_d(id) = make_float4(d.x, d.y, d.z, maxt);
+	ps.thr(id) = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(1));   // depth = 1 (integrator.h:186-191)
 	const uint32_t flags = F_EMITTED | F_FIRST | (smp.d1 << F_D1_SHIFT) | (smp.d2 << F_D2_SHIFT);
-	ps.Li[id] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(flags));
-	ps.rng[id] = make_uint2((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32));
-	ps.spos[id] = make_float2(sx, sy);
-	ps.pix[id] = pixel;
-	ps.smp[id] = j;
+	ps.Li(id) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(flags));
+	ps.misc(id) = make_uint4((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32), j, pixel);
+	ps.spos(id) = make_float4(sx, sy, 0.0f, 0.0f);
 	queue[id] = id;
 }
 
@@ -230,7 +228,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 		if (MODE == 0) {
 			int bin = -1;
 			if (retire) {
-				ps.hit[id] = make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim);
+				ps.hit(id) = make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim);
 				if (BIN) {
 					bin = kNumBins - 1;
 					if (found) {
@@ -251,14 +249,14 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 		} else if (MODE == 1) {
 			// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
 			if (retire && !found) {
-				float4 L = ps.Li[id];
-				const float4 c = ps.nee[id];
+				float4 L = ps.Li(id);
+				const float4 c = ps.nee(id);
 				L.x += c.x; L.y += c.y; L.z += c.z;
-				ps.Li[id] = L;
+				ps.Li(id) = L;
 			}
 		} else {
 			if (retire)
-				ps.hit[id] = make_uint4(0u, 0u, 0u, found ? 1u : 0u);
+				ps.hit(id) = make_uint4(0u, 0u, 0u, found ? 1u : 0u);
 		}
 		retire = false;
 
@@ -281,10 +279,10 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 					float4 a, b;
 					float rmint, rmaxt;
 					if (MODE == 1) {
-						a = ps.sh_o[id]; b = ps.sh_d[id];
+						a = ps.sh_o(id); b = ps.sh_d(id);
 						rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
 					} else {
-						a = ps.ray_o[id]; b = ps.ray_d[id];
+						a = ps.ray_o(id); b = ps.ray_d(id);
 						rmint = a.w; rmaxt = b.w;
 					}
 					ox = a.x; oy = a.y; oz = a.z; dx = b.x; dy = b.y; dz = b.z;
@@ -849,20 +847,22 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths ps, DConfig cfg
 	bool continues = false, wantShadow = false;
 
 	if (active) {
-		const float4 ro = ps.ray_o[id], rd = ps.ray_d[id];
+		const float4 ro = ps.ray_o(id), rd = ps.ray_d(id);
 		const V3 rayO(ro.x, ro.y, ro.z), rayD(rd.x, rd.y, rd.z);
-		const uint4 h = ps.hit[id];
+		const uint4 h = ps.hit(id);
 		const bool valid = h.w != kNoPrim;
-		float4 T4 = ps.thr[id], L4 = ps.Li[id];
+		float4 T4 = ps.thr(id), L4 = ps.Li(id);
 		V3 thr(T4.x, T4.y, T4.z), Li(L4.x, L4.y, L4.z);
 		int depth = __float_as_int(T4.w);
 		uint32_t flags = __float_as_uint(L4.w);
 		PathSampler smp;
+		uint2 misc_zw;
 		{
-			const uint2 r = ps.rng[id];
+			const uint4 r = ps.misc(id);
 			smp.stream = (uint64_t) r.x | ((uint64_t) r.y << 32);
 			smp.slot = cfg.slot_per_path ? id : (id / cfg.spp);
-			smp.j = ps.smp[id];
+			smp.j = r.z;
+			misc_zw = make_uint2(r.z, r.w);
 			smp.d1 = (flags >> F_D1_SHIFT) & 0xFFu; smp.d2 = (flags >> F_D2_SHIFT) & 0xFFu;
 		}
 		Its its;
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths ps, DConfig cfg
 				if (valid) flags |= F_ALPHA;
 			} else {
 				// ---- tail of the previous iteration (path.cpp:147-208) ----
-				const float4 B4 = ps.bsdf[id];
+				const float4 B4 = ps.bsdf(id);
 				const V3 bsdfVal(B4.x, B4.y, B4.z);
 				const float bsdfPdf = B4.w;
 				const uint32_t sampledType = flags >> F_ST_SHIFT;
@@ -963,12 +963,12 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths ps, DConfig cfg
 						const float bsdfPdf = Bsdf<BT>::pdf(BP, its.wi, woL);
 						const float weight = mi_weight(lRec.pdf, bsdfPdf);
 						// added to Li by k_trace<shadow> iff the segment is unoccluded
-						ps.nee[id] = make_float4(thr.x * lRec.value.x * bsdfVal.x * weight,
+						ps.nee(id) = make_float4(thr.x * lRec.value.x * bsdfVal.x * weight,
 						                         thr.y * lRec.value.y * bsdfVal.y * weight,
 						                         thr.z * lRec.value.z * bsdfVal.z * weight, 0.0f);
 						const V3 sd = lRec.p - its.p;       // Ray(p1, p2 - p1) (scene.h:241-246)
-						ps.sh_o[id] = make_float4(its.p.x, its.p.y, its.p.z, 0.0f);
-						ps.sh_d[id] = make_float4(sd.x, sd.y, sd.z, 0.0f);
+						ps.sh_o(id) = make_float4(its.p.x, its.p.y, its.p.z, 0.0f);
+						ps.sh_d(id) = make_float4(sd.x, sd.y, sd.z, 0.0f);
 						wantShadow = true;
 					}
 				}
@@ -991,17 +991,17 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths ps, DConfig cfg
 			if (woDotGeoN * woL.z <= 0 && cfg.strict_normals)
 				break;
 			// ray = Ray(its.p, wo, time): mint = Epsilon, maxt = inf
-			ps.ray_o[id] = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
-			ps.ray_d[id] = make_float4(wo.x, wo.y, wo.z, MG_INF);
-			ps.bsdf[id] = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, bsdfPdf);
+			ps.ray_o(id) = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
+			ps.ray_d(id) = make_float4(wo.x, wo.y, wo.z, MG_INF);
+			ps.bsdf(id) = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, bsdfPdf);
 			flags = (flags & 0x00FFFFFFu) | (sampledType << F_ST_SHIFT);
 			continues = true;
 		} while (false);
 
 		flags = (flags & ~((0xFFu << F_D1_SHIFT) | (0xFFu << F_D2_SHIFT))) | (smp.d1 << F_D1_SHIFT) | (smp.d2 << F_D2_SHIFT);
-		ps.thr[id] = make_float4(thr.x, thr.y, thr.z, __int_as_float(depth));
-		ps.Li[id] = make_float4(Li.x, Li.y, Li.z, __uint_as_float(flags));
-		ps.rng[id] = make_uint2((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32));
+		ps.thr(id) = make_float4(thr.x, thr.y, thr.z, __int_as_float(depth));
+		ps.Li(id) = make_float4(Li.x, Li.y, Li.z, __uint_as_float(flags));
+		ps.misc(id) = make_uint4((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32), misc_zw.x, misc_zw.y);
 	}
 
 	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue
@@ -1026,8 +1026,8 @@ __global__ void k_accumulate(DPaths ps, DConfig cfg, uint32_t n_slots, uint32_t 
 	const float fsize = 0.5f, factor = 15 / fsize;
 	for (uint32_t j = 0; j < spp; ++j) {
 		const size_t id = (size_t) slot * spp + j;
-		const float4 L = ps.Li[id];
-		const float2 sp = ps.spos[id];
+		const float4 L = ps.Li(id);
+		const float4 sp = ps.spos(id);
 		// Spectrum::isValid (spectrum.h:285-290)
 		if (L.x != L.x || L.x < 0.0f || L.y != L.y || L.y < 0.0f || L.z != L.z || L.z < 0.0f)
 			continue;
