@@ -389,14 +389,22 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 			dst[11] = prim;
 		}
 		rc |= upload(c, (const uint32_t **) &d.leaf_ta, ta.data(), ta.size());
-		std::vector<uint32_t> triShape(sc->n_tris + 1, 0u);
+		// per-primitive position / normal records for the shading kernels
+		std::vector<float> triPos(12 * ((size_t) sc->n_tris + 1), 0.0f), triNrm(12 * ((size_t) sc->n_tris + 1), 0.0f);
 		for (uint32_t s = 0; s < sc->n_shapes; ++s)
-			for (uint32_t t = sc->shape_tri_offset[s]; t < sc->shape_tri_offset[s + 1]; ++t) triShape[t] = s;
-		rc |= upload(c, &d.tri_shape, triShape.data(), triShape.size());
+			for (uint32_t t = sc->shape_tri_offset[s]; t < sc->shape_tri_offset[s + 1]; ++t) {
+				float *P = &triPos[12 * (size_t) t], *Nn = &triNrm[12 * (size_t) t];
+				for (int k = 0; k < 3; ++k) {
+					const uint32_t v = sc->tri_idx[3 * (size_t) t + k];
+					std::memcpy(P + 3 * k, sc->vtx_pos + 3 * (size_t) v, 12);
+					std::memcpy(Nn + 3 * k, sc->vtx_nrm + 3 * (size_t) v, 12);
+				}
+				const uint32_t flags = sc->shape_flags[s];
+				std::memcpy(P + 10, &s, 4); std::memcpy(P + 11, &flags, 4);
+			}
+		rc |= upload(c, (const float **) &d.tri_pos, triPos.data(), triPos.size());
+		rc |= upload(c, (const float **) &d.tri_nrm, triNrm.data(), triNrm.size());
 	}
-	rc |= upload(c, &d.vtx_pos, sc->vtx_pos, 3 * (size_t) sc->n_verts);
-	rc |= upload(c, &d.vtx_nrm, sc->vtx_nrm, 3 * (size_t) sc->n_verts);
-	rc |= upload(c, &d.tri_idx, sc->tri_idx, 3 * (size_t) sc->n_tris);
 	rc |= upload(c, &d.shape_bsdf, sc->shape_bsdf, sc->n_shapes);
 	rc |= upload(c, &d.shape_lum, sc->shape_lum, sc->n_shapes);
 	rc |= upload(c, &d.shape_flags, sc->shape_flags, sc->n_shapes);

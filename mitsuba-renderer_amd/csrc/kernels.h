@@ -17,9 +17,10 @@ struct DScene {
 	// TriAccel of primitive kd_indices[e] (dword 10 = shape | bit31 "not an occluder",
 	// dword 11 = global primitive id), so a leaf's primitives are one contiguous run
 	const uint4    *leaf_ta;
-	const uint32_t *tri_shape;    // [n_tris] shape index of every primitive
-	const float    *vtx_pos, *vtx_nrm;
-	const uint32_t *tri_idx;
+	// per-primitive gather records (3 x 16 B each): p0.xyz p1.xyz p2.xyz | shape, flags, 0   and
+	// n0.xyz n1.xyz n2.xyz | 0 0 0 -- one line instead of 3 index + 9 scattered vertex fetches
+	const float4   *tri_pos;
+	const float4   *tri_nrm;
 	const int32_t  *shape_bsdf, *shape_lum;
 	const uint32_t *shape_flags, *shape_tri_offset;
 	const uint32_t *bsdf_type;

@@ -481,11 +481,9 @@ struct Its {
 
 // fillIntersectionRecord<true> (include/mitsuba/render/skdtree.h:352-432)
 __device__ __forceinline__ void fill_its(const DScene &sc, V3 rayD, uint32_t prim, float u, float v, Its &its) {
-	const uint32_t i0 = sc.tri_idx[3 * (size_t) prim], i1 = sc.tri_idx[3 * (size_t) prim + 1], i2 = sc.tri_idx[3 * (size_t) prim + 2];
-	const float *P = sc.vtx_pos;
-	const V3 p0(P[3 * (size_t) i0], P[3 * (size_t) i0 + 1], P[3 * (size_t) i0 + 2]);
-	const V3 p1(P[3 * (size_t) i1], P[3 * (size_t) i1 + 1], P[3 * (size_t) i1 + 2]);
-	const V3 p2(P[3 * (size_t) i2], P[3 * (size_t) i2 + 1], P[3 * (size_t) i2 + 2]);
+	const float4 *TP = sc.tri_pos + 3 * (size_t) prim;
+	const float4 t0 = TP[0], t1 = TP[1], t2 = TP[2];
+	const V3 p0(t0.x, t0.y, t0.z), p1(t0.w, t1.x, t1.y), p2(t1.z, t1.w, t2.x);
 	const float bx = 1 - u - v, by = u, bz = v;
 	its.p = V3(p0.x * bx + p1.x * by + p2.x * bz, p0.y * bx + p1.y * by + p2.y * bz, p0.z * bx + p1.z * by + p2.z * bz);
 	V3 faceNormal = cross(p1 - p0, p2 - p0);
@@ -493,12 +491,11 @@ __device__ __forceinline__ void fill_its(const DScene &sc, V3 rayD, uint32_t pri
 	if (!isZero(faceNormal))
 		faceNormal = divs(faceNormal, len);
 	its.geoN = faceNormal;
-	its.shape = sc.tri_shape[prim];
-	if (sc.shape_flags[its.shape] & 1u) {
-		const float *N = sc.vtx_nrm;
-		const V3 n0(N[3 * (size_t) i0], N[3 * (size_t) i0 + 1], N[3 * (size_t) i0 + 2]);
-		const V3 n1(N[3 * (size_t) i1], N[3 * (size_t) i1 + 1], N[3 * (size_t) i1 + 2]);
-		const V3 n2(N[3 * (size_t) i2], N[3 * (size_t) i2 + 1], N[3 * (size_t) i2 + 2]);
+	its.shape = __float_as_uint(t2.z);
+	if (__float_as_uint(t2.w) & 1u) {
+		const float4 *TN = sc.tri_nrm + 3 * (size_t) prim;
+		const float4 m0 = TN[0], m1 = TN[1], m2 = TN[2];
+		const V3 n0(m0.x, m0.y, m0.z), n1(m0.w, m1.x, m1.y), n2(m1.z, m1.w, m2.x);
 		its.shN = normalize(V3(n0.x * bx + n1.x * by + n2.x * bz, n0.y * bx + n1.y * by + n2.y * bz, n0.z * bx + n1.z * by + n2.z * bz));
 	} else {
 		its.shN = its.geoN;
@@ -562,20 +559,17 @@ __device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s
 		const uint32_t t0 = sc.shape_tri_offset[s], nT = sc.shape_tri_offset[s + 1] - t0;
 		const int index = dpdf_sample_reuse(sc.lum_tri_cdf + sc.lum_cdf_offset[l], nT, sy);
 		const size_t tri = (size_t) t0 + (uint32_t) index;
-		const uint32_t i0 = sc.tri_idx[3 * tri], i1 = sc.tri_idx[3 * tri + 1], i2 = sc.tri_idx[3 * tri + 2];
-		const float *P = sc.vtx_pos;
-		const V3 p0(P[3 * (size_t) i0], P[3 * (size_t) i0 + 1], P[3 * (size_t) i0 + 2]);
-		const V3 p1(P[3 * (size_t) i1], P[3 * (size_t) i1 + 1], P[3 * (size_t) i1 + 2]);
-		const V3 p2(P[3 * (size_t) i2], P[3 * (size_t) i2 + 1], P[3 * (size_t) i2 + 2]);
+		const float4 *TP = sc.tri_pos + 3 * tri;
+		const float4 q0 = TP[0], q1 = TP[1], q2 = TP[2];
+		const V3 p0(q0.x, q0.y, q0.z), p1(q0.w, q1.x, q1.y), p2(q1.z, q1.w, q2.x);
 		float bx, by;
 		squareToTriangle(sx, sy, bx, by);
 		const V3 sideA = p1 - p0, sideB = p2 - p0;
 		lRec.p = V3(p0.x + (sideA.x * bx) + (sideB.x * by), p0.y + (sideA.y * bx) + (sideB.y * by), p0.z + (sideA.z * bx) + (sideB.z * by));
-		if (sc.shape_flags[s] & 1u) {
-			const float *N = sc.vtx_nrm;
-			const V3 n0(N[3 * (size_t) i0], N[3 * (size_t) i0 + 1], N[3 * (size_t) i0 + 2]);
-			const V3 n1(N[3 * (size_t) i1], N[3 * (size_t) i1 + 1], N[3 * (size_t) i1 + 2]);
-			const V3 n2(N[3 * (size_t) i2], N[3 * (size_t) i2 + 1], N[3 * (size_t) i2 + 2]);
+		if (__float_as_uint(q2.w) & 1u) {
+			const float4 *TN = sc.tri_nrm + 3 * tri;
+			const float4 m0 = TN[0], m1 = TN[1], m2 = TN[2];
+			const V3 n0(m0.x, m0.y, m0.z), n1(m0.w, m1.x, m1.y), n2(m1.z, m1.w, m2.x);
 			const float b0 = 1.0f - bx - by;
 			lRec.n = normalize(V3(n0.x * b0 + n1.x * bx + n2.x * by, n0.y * b0 + n1.y * bx + n2.y * by, n0.z * b0 + n1.z * bx + n2.z * by));
 		} else {
