@@ -101,3 +101,27 @@ def test_tile_sharding_is_exact(gpu_lib, mts, orc):
         assert it.render()
         acc += it.film()
     assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
+
+
+def test_traversal_counters_match_oracle(gpu_lib, mts, orc):
+    """the counting build of k_trace (bench.py's algorithmic bytes) counts what the oracle's counting mode counts"""
+    sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "c3_small")
+    rays = chord_rays(5000, (0, 1, 0), 2.2, seed=21)
+    it.set_options(count_traversal=True)
+    it.trace_rays(rays)
+    st = it.stats()
+    _, tc = orc.trace_rays(oscene.scene, rays, counts=True)
+    assert (st["n_inner"], st["n_leaf"], st["n_idx"], st["n_tri_tested"]) == (tc.n_inner, tc.n_leaf, tc.n_idx, tc.n_tri_tested)
+    it.set_options(count_traversal=False)
+
+
+def test_cancel_and_error_paths(gpu_lib, mts, orc):
+    sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "c1")
+    import ctypes as C
+    flag = C.c_int(1)                                   # Integrator::cancel() before the first stage
+    assert mts.lib().mtsgpu_render(it._ctx, C.byref(flag)) == -4
+    with pytest.raises(mts.MtsGpuError):
+        mts.MIPathTracer(maxDepth=4, rrDepth=0).configure()   # "rrDepth == 0 breaks the computation of alpha values!"
+    fresh = mts.MIPathTracer(maxDepth=4)
+    with pytest.raises(mts.MtsGpuError):
+        fresh.render()                                  # no scene uploaded
