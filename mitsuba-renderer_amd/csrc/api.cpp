@@ -107,12 +107,11 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	for (int b = 0; b < kNumBins; ++b) rc |= devAlloc(c, &c->q.bins[b], cap, o);
 	rc |= devAlloc(c, &c->queueA, cap, o); rc |= devAlloc(c, &c->queueB, cap, o);
 	rc |= devAlloc(c, &c->q.shadow, cap, o);
-	rc |= devAlloc(c, &c->q.counters, 16, o);
+	rc |= devAlloc(c, &c->q.counters, kNumCounters * kCounterStride, o);
 	rc |= devAlloc(c, &c->q.trace_counts, 4, o);
 	rc |= devAlloc(c, &c->q.spill, (size_t) kTraceGridBlocks * kTraceBlock * trace_spill_levels(), o);
 	if (rc) return rc;
 	c->q.spill_stride = kTraceGridBlocks * kTraceBlock;
-	c->q.fetch_threshold = getenv("MTSGPU_FETCH_THRESHOLD") ? atoi(getenv("MTSGPU_FETCH_THRESHOLD")) : 0;
 	HIPCHK(c, hipMemset(c->q.trace_counts, 0, 4 * sizeof(unsigned long long)));
 	c->pathCap = cap;
 	return 0;
@@ -159,7 +158,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 	while (nQ > 0) {
 		if (cancel && *cancel)
 			return fail(c, MTSGPU_ECANCEL, "render cancelled");
-		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, 16 * sizeof(uint32_t), s));
+		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, kNumCounters * kCounterStride * sizeof(uint32_t), s));
 		c->q.next = nxt;
 		// closest hit + material sort
 		hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
@@ -168,20 +167,20 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
 		HIPCHK(c, hipGetLastError());
 		c->stats.rays_closest += nQ; c->stats.trace_launches++;
-		HIPCHK(c, hipMemcpyAsync(c->hostCounters, c->q.counters, kNumBins * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		HIPCHK(c, hipMemcpyAsync(c->hostCounters, c->q.counters, kNumCounters * kCounterStride * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 		HIPCHK(c, hipStreamSynchronize(s));
 		// shade, one launch per BSDF type
 		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
 		if (sev) HIPCHK(c, hipEventRecord(sev[0], s));
 		uint32_t binCount[kNumBins];
-		for (int b = 0; b < kNumBins; ++b) binCount[b] = c->hostCounters[b];
+		for (int b = 0; b < kNumBins; ++b) binCount[b] = c->hostCounters[b * kCounterStride];
 		for (int b = 0; b < kNumBins; ++b)
 			launch_shade(s, b, c->dsc, c->paths, cfg, c->q, binCount[b]);
 		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
 		HIPCHK(c, hipGetLastError());
-		HIPCHK(c, hipMemcpyAsync(c->hostCounters, c->q.counters + kNumBins, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		HIPCHK(c, hipMemcpyAsync(c->hostCounters, c->q.counters, kNumCounters * kCounterStride * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 		HIPCHK(c, hipStreamSynchronize(s));
-		const uint32_t nNext = c->hostCounters[0], nShadow = c->hostCounters[1];
+		const uint32_t nNext = c->hostCounters[kNumBins * kCounterStride], nShadow = c->hostCounters[(kNumBins + 1) * kCounterStride];
 		// shadow rays of this bounce (adds the direct-light term before the next bounce adds its own)
 		if (nShadow) {
 			hipEvent_t *ev2 = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
@@ -258,7 +257,7 @@ int mtsgpu_create(int device, mtsgpu_ctx **out) {
 	c->device = device;
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(nullptr, MTSGPU_EHIP, "hipStreamCreate failed"); }
 	c->ownStream = true;
-	if (hipHostMalloc((void **) &c->hostCounters, 64 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+	if (hipHostMalloc((void **) &c->hostCounters, kNumCounters * kCounterStride * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
 		(void) hipStreamDestroy(c->stream); delete c; return fail(nullptr, MTSGPU_EHIP, "hipHostMalloc failed");
 	}
 	*out = c;
@@ -589,7 +588,6 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 	}
 	launch_iota(c->stream, c->queueA, n);
-	HIPCHK(c, hipMemsetAsync(c->q.counters, 0, 16 * sizeof(uint32_t), c->stream));
 	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 4 * sizeof(unsigned long long), c->stream));
 	hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
 	if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));

@@ -9,6 +9,8 @@ constexpr int kNumBins = 5;           // 4 BSDF types + "terminal" (miss / no BS
 constexpr int kTraceBlock = 256;
 constexpr unsigned kTraceGridBlocks = 256 * 6;   // persistent traversal grid: 256 CUs x resident workgroups
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
+constexpr int kCounterStride = 32;    // one 128-byte line per queue counter (atomics on one line serialise)
+constexpr int kNumCounters = 8;
 
 // Scene in HBM (all pointers are device pointers); see DESIGN.md section 3
 struct DScene {
@@ -84,11 +86,10 @@ struct DQueues {
 	uint32_t *bins[kNumBins];     // per-material queues written by the closest-hit kernel
 	uint32_t *next;               // paths that continue (input of the next closest-hit launch)
 	uint32_t *shadow;             // paths with a pending shadow ray
-	uint32_t *counters;           // [0..4] bins, [5] next, [6] shadow, [7] closest-hit work head, [8] shadow work head
+	uint32_t *counters;           // [i * kCounterStride]: i = 0..4 bins, 5 next, 6 shadow
 	unsigned long long *trace_counts;  // n_inner, n_leaf, n_idx, n_tri_tested (u64 x 4)
 	uint32_t *spill;              // traversal stack overflow: [level][thread]
 	uint32_t spill_stride;
-	int32_t fetch_threshold;      // refill a wave's idle lanes when fewer than this many still traverse
 };
 
 // --- launchers (kernels.hip) -------------------------------------------------

@@ -197,142 +197,88 @@ constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 
 size_t trace_spill_levels() { return kSpillLevels; }
 
-// Persistent waves with dynamic ray fetch: a wave keeps traversing while at least
-// kFetchThreshold of its 64 lanes still hold a ray; below that the idle lanes write their
-// results and pull the next rays from the queue (one atomic per wave), so divergent ray
-// lengths do not leave most of a wave's memory requests unissued.
-
+// Persistent waves: the grid is sized to fill the chip once and every wave walks the queue in
+// 64-ray batches with a fixed stride (no work-queue atomic: a single head word saturates at
+// ~88 fetches/us, MI355X_MICROARCH.md "dequeue").  64 consecutive queue entries per wave keep the
+// coherence of neighbouring camera samples; a measured alternative that refilled idle lanes
+// mid-batch lost 45 % to the coherence it destroys.
 template <int MODE, bool COUNT, bool BIN>
 __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, DQueues q,
-                                                       const uint32_t *queue, uint32_t n, uint32_t *work_head) {
+                                                          const uint32_t *queue, uint32_t n) {
 	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
 	__shared__ uint32_t s_mbox[8][kTraceBlock];
 	const uint32_t tid = threadIdx.x;
 	const uint32_t gtid = blockIdx.x * kTraceBlock + tid;     // spill slot of this lane
 	const uint32_t lane = lane_id();
+	const uint32_t stride = gridDim.x * kTraceBlock;
 
-	bool has = false, retire = false, moreWork = true;
-	uint32_t id = 0;
-	float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, rx = 1, ry = 1, rz = 1;
-	float mint = 0, maxt = 0, tmax0 = 0;
-	float en_t = 0, en_split = 0, ex_t = 0, ex_split = 0;
-	int en_axis = 3, ex_axis = 3, sp = 0;
-	uint32_t ex_node = kNullNode, ex_ref = kSentinel, cur = 0;
-	float best_t = MG_INF, best_u = 0, best_v = 0;
-	uint32_t best_prim = kNoPrim, best_shape = 0;
-	bool found = false;
 	uint32_t c_inner = 0, c_leaf = 0, c_idx = 0, c_tri = 0;
 
-	for (;;) {
-		// ---- retire finished rays (all lanes take part in the ballots) ----
-		if (MODE == 0) {
-			int bin = -1;
-			if (retire) {
-				ps.hit(id) = make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim);
-				if (BIN) {
-					bin = kNumBins - 1;
-					if (found) {
-						const int b = sc.shape_bsdf[best_shape];
-						if (b >= 0) bin = (int) sc.bsdf_type[b];
-					}
+	// each wave owns the batches (64 consecutive queue entries) wave_id, wave_id + n_waves, ...
+	for (uint32_t batch = blockIdx.x * kTraceBlock + (tid & ~63u); batch < n; batch += stride) {
+		const uint32_t my = batch + lane;
+		const bool active = my < n;
+		uint32_t id = 0;
+		float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, rx = 1, ry = 1, rz = 1;
+		float mint = 0, maxt = 0, tmax0 = 0;
+		float en_t = 0, en_split = 0, ex_t = 0, ex_split = 0;
+		int en_axis = 3, ex_axis = 3, sp = 0;
+		uint32_t ex_node = kNullNode, ex_ref = kSentinel, cur = 0;
+		float best_t = MG_INF, best_u = 0, best_v = 0;
+		uint32_t best_prim = kNoPrim, best_shape = 0;
+		bool found = false, has = false;
+
+		if (active) {
+			id = queue[my];
+			float4 a, b;
+			float rmint, rmaxt;
+			if (MODE == 1) {
+				a = ps.sh_o(id); b = ps.sh_d(id);
+				rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
+			} else {
+				a = ps.ray_o(id); b = ps.ray_d(id);
+				rmint = a.w; rmaxt = b.w;
+			}
+			ox = a.x; oy = a.y; oz = a.z; dx = b.x; dy = b.y; dz = b.z;
+			rx = 1.0f / dx; ry = 1.0f / dy; rz = 1.0f / dz;          // Ray::dRcp (ray.h:63-74)
+			// AABB::rayIntersect (aabb.h:349-382) + adaptive epsilon (skdtree.cpp:114-122)
+			bool go = true;
+			mint = -MG_INF; maxt = MG_INF;
+			#pragma unroll
+			for (int i = 0; i < 3; ++i) {
+				const float direction = sel3(dx, dy, dz, i), origin = sel3(ox, oy, oz, i);
+				const float minVal = sc.aabb_min[i], maxVal = sc.aabb_max[i];
+				if (direction == 0) {
+					if (origin < minVal || origin > maxVal) go = false;
+				} else {
+					const float rc = sel3(rx, ry, rz, i);
+					float t1 = (minVal - origin) * rc, t2 = (maxVal - origin) * rc;
+					if (t1 > t2) { const float tmp = t1; t1 = t2; t2 = tmp; }
+					mint = smax(mint, t1);
+					maxt = smin(maxt, t2);
+					if (mint > maxt) go = false;
 				}
 			}
-			if (BIN) {
-				// material sort: one ballot + prefix popcount per bin, one atomic per wave and bin
+			float rayMinT = rmint;
+			if (rayMinT == kEpsilon) {
+				float m = smax(smax(fabsf(ox), fabsf(oy)), fabsf(oz));
+				if (MODE == 0) m = smax(m, kEpsilon);    // only the (ray, its) variant has the inner max
+				rayMinT *= m;
+			}
+			if (rayMinT > mint) mint = rayMinT;
+			if (rmaxt < maxt) maxt = rmaxt;
+			if (!(maxt > mint)) go = false;
+			if (go) {
 				#pragma unroll
-				for (int b = 0; b < kNumBins; ++b) {
-					const bool mine = (bin == b);
-					const uint32_t pos = wave_append(mine, &q.counters[b]);
-					if (mine) q.bins[b][pos] = id;
-				}
-			}
-		} else if (MODE == 1) {
-			// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
-			if (retire && !found) {
-				float4 L = ps.Li(id);
-				const float4 c = ps.nee(id);
-				L.x += c.x; L.y += c.y; L.z += c.z;
-				ps.Li(id) = L;
-			}
-		} else {
-			if (retire)
-				ps.hit(id) = make_uint4(0u, 0u, 0u, found ? 1u : 0u);
-		}
-		retire = false;
-
-		// ---- fetch new rays into idle lanes ----
-		if (moreWork) {
-			const bool need = !has;
-			const unsigned long long needMask = __ballot(need);
-			if (needMask != 0ull) {
-				const uint32_t cnt = (uint32_t) __popcll(needMask);
-				const int leader = __ffsll((long long) needMask) - 1;
-				uint32_t base = 0;
-				if ((int) lane == leader)
-					base = atomicAdd(work_head, cnt);
-				base = __shfl(base, leader);
-				if (base + cnt >= n)
-					moreWork = false;
-				const uint32_t my = base + (uint32_t) __popcll(needMask & ((1ull << lane) - 1ull));
-				if (need && my < n) {
-					id = queue[my];
-					float4 a, b;
-					float rmint, rmaxt;
-					if (MODE == 1) {
-						a = ps.sh_o(id); b = ps.sh_d(id);
-						rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
-					} else {
-						a = ps.ray_o(id); b = ps.ray_d(id);
-						rmint = a.w; rmaxt = b.w;
-					}
-					ox = a.x; oy = a.y; oz = a.z; dx = b.x; dy = b.y; dz = b.z;
-					rx = 1.0f / dx; ry = 1.0f / dy; rz = 1.0f / dz;          // Ray::dRcp (ray.h:63-74)
-					// AABB::rayIntersect (aabb.h:349-382) + adaptive epsilon (skdtree.cpp:114-122)
-					bool go = true;
-					mint = -MG_INF; maxt = MG_INF;
-					#pragma unroll
-					for (int i = 0; i < 3; ++i) {
-						const float direction = sel3(dx, dy, dz, i), origin = sel3(ox, oy, oz, i);
-						const float minVal = sc.aabb_min[i], maxVal = sc.aabb_max[i];
-						if (direction == 0) {
-							if (origin < minVal || origin > maxVal) go = false;
-						} else {
-							const float rc = sel3(rx, ry, rz, i);
-							float t1 = (minVal - origin) * rc, t2 = (maxVal - origin) * rc;
-							if (t1 > t2) { const float tmp = t1; t1 = t2; t2 = tmp; }
-							mint = smax(mint, t1);
-							maxt = smin(maxt, t2);
-							if (mint > maxt) go = false;
-						}
-					}
-					float rayMinT = rmint;
-					if (rayMinT == kEpsilon) {
-						float m = smax(smax(fabsf(ox), fabsf(oy)), fabsf(oz));
-						if (MODE == 0) m = smax(m, kEpsilon);    // only the (ray, its) variant has the inner max
-						rayMinT *= m;
-					}
-					if (rayMinT > mint) mint = rayMinT;
-					if (rmaxt < maxt) maxt = rmaxt;
-					if (!(maxt > mint)) go = false;
-
-					best_t = MG_INF; best_u = 0; best_v = 0; best_prim = kNoPrim; best_shape = 0; found = false;
-					if (go) {
-						#pragma unroll
-						for (int i = 0; i < 8; ++i) s_mbox[i][tid] = 0xFFFFFFFFu;
-						// entry point (stack[enPt]) and current exit point (stack[exPt]) in registers
-						en_t = mint; en_split = 0.0f; en_axis = 3;
-						tmax0 = maxt;
-						ex_t = maxt; ex_split = 0.0f; ex_axis = 3; ex_node = kNullNode; ex_ref = kSentinel;
-						sp = 0; cur = 0;
-						has = true;
-					} else {
-						retire = true;
-					}
-				}
+				for (int i = 0; i < 8; ++i) s_mbox[i][tid] = 0xFFFFFFFFu;
+				// entry point (stack[enPt]) and current exit point (stack[exPt]) in registers
+				en_t = mint; en_split = 0.0f; en_axis = 3;
+				tmax0 = maxt;
+				ex_t = maxt; ex_split = 0.0f; ex_axis = 3; ex_node = kNullNode; ex_ref = kSentinel;
+				sp = 0; cur = 0;
+				has = true;
 			}
 		}
-		if (__ballot(has || retire) == 0ull)
-			break;
 
 		// ---- traverse ----
 		if (has) {
@@ -449,11 +395,44 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 						}
 					}
 				}
-				if (finished) { has = false; retire = true; break; }
-				// too few lanes left traversing: go back and refill the idle ones
-				if (moreWork && __popcll(__ballot(true)) < q.fetch_threshold)
+				if (finished)
 					break;
 			}
+		}
+
+		// ---- results of this batch (all lanes take part in the ballots) ----
+		if (MODE == 0) {
+			int bin = -1;
+			if (active) {
+				ps.hit(id) = make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim);
+				if (BIN) {
+					bin = kNumBins - 1;
+					if (found) {
+						const int b = sc.shape_bsdf[best_shape];
+						if (b >= 0) bin = (int) sc.bsdf_type[b];
+					}
+				}
+			}
+			if (BIN) {
+				// material sort: one ballot + prefix popcount per bin, one atomic per wave and bin
+				#pragma unroll
+				for (int b = 0; b < kNumBins; ++b) {
+					const bool mine = (bin == b);
+					const uint32_t pos = wave_append(mine, &q.counters[b * kCounterStride]);
+					if (mine) q.bins[b][pos] = id;
+				}
+			}
+		} else if (MODE == 1) {
+			// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
+			if (active && !found) {
+				float4 L = ps.Li(id);
+				const float4 c = ps.nee(id);
+				L.x += c.x; L.y += c.y; L.z += c.z;
+				ps.Li(id) = L;
+			}
+		} else {
+			if (active)
+				ps.hit(id) = make_uint4(0u, 0u, 0u, found ? 1u : 0u);
 		}
 	}
 
@@ -999,9 +978,9 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths ps, DConfig cfg
 	}
 
 	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue
-	const uint32_t pn = wave_append(continues, &q.counters[kNumBins]);
+	const uint32_t pn = wave_append(continues, &q.counters[kNumBins * kCounterStride]);
 	if (continues) q.next[pn] = id;
-	const uint32_t psh = wave_append(wantShadow, &q.counters[kNumBins + 1]);
+	const uint32_t psh = wave_append(wantShadow, &q.counters[(kNumBins + 1) * kCounterStride]);
 	if (wantShadow) q.shadow[psh] = id;
 }
 
@@ -1076,8 +1055,7 @@ template <int MODE, bool COUNT, bool BIN>
 static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n) {
 	// persistent grid: enough workgroups to fill every CU, never more than there are rays
 	const unsigned blocks = std::min<unsigned>(blocks_for(n, kTraceBlock), kTraceGridBlocks);
-	uint32_t *head = q.counters + (MODE == 1 ? kNumBins + 3 : kNumBins + 2);
-	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, sc, ps, q, queue, n, head);
+	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, sc, ps, q, queue, n);
 }
 
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
