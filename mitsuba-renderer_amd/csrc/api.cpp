@@ -104,7 +104,11 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	auto &o = c->pathAllocs;
 	int rc = 0;
 	rc |= devAlloc(c, &c->paths.base, cap * kPathSlots, o);
-	for (int b = 0; b < kNumBins; ++b) rc |= devAlloc(c, &c->q.bins[b], cap, o);
+	// every shard (workgroups with blockIdx % kBinShards == s) sees at most 1/kBinShards of the 256-ray
+	// batches plus one per workgroup, and all of them may land in one bin
+	const size_t segCap = cap / kBinShards + (size_t) kTraceBlock * (kTraceGridBlocks / kBinShards + 2);
+	for (int b = 0; b < kNumBins; ++b) rc |= devAlloc(c, &c->q.bins[b], segCap * kBinShards, o);
+	c->q.bin_seg_cap = (uint32_t) segCap;
 	rc |= devAlloc(c, &c->queueA, cap, o); rc |= devAlloc(c, &c->queueB, cap, o);
 	rc |= devAlloc(c, &c->q.shadow, cap, o);
 	rc |= devAlloc(c, &c->q.counters, kNumCounters * kCounterStride, o);
@@ -172,15 +176,24 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		// shade, one launch per BSDF type
 		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
 		if (sev) HIPCHK(c, hipEventRecord(sev[0], s));
-		uint32_t binCount[kNumBins];
-		for (int b = 0; b < kNumBins; ++b) binCount[b] = c->hostCounters[b * kCounterStride];
+		BinView views[kNumBins];
+		for (int b = 0; b < kNumBins; ++b) {
+			uint32_t acc = 0;
+			for (int k = 0; k < kBinShards; ++k) {
+				views[b].prefix[k] = acc;
+				const uint32_t cnt = c->hostCounters[(b * kBinShards + k) * kCounterStride];
+				if (cnt > c->q.bin_seg_cap) return fail(c, MTSGPU_EHIP, "internal: bin segment overflow");
+				acc += cnt;
+			}
+			views[b].prefix[kBinShards] = acc;
+		}
 		for (int b = 0; b < kNumBins; ++b)
-			launch_shade(s, b, c->dsc, c->paths, cfg, c->q, binCount[b]);
+			launch_shade(s, b, c->dsc, c->paths, cfg, c->q, views[b]);
 		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
 		HIPCHK(c, hipGetLastError());
 		HIPCHK(c, hipMemcpyAsync(c->hostCounters, c->q.counters, kNumCounters * kCounterStride * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 		HIPCHK(c, hipStreamSynchronize(s));
-		const uint32_t nNext = c->hostCounters[kNumBins * kCounterStride], nShadow = c->hostCounters[(kNumBins + 1) * kCounterStride];
+		const uint32_t nNext = c->hostCounters[kNumBins * kBinShards * kCounterStride], nShadow = c->hostCounters[(kNumBins * kBinShards + 1) * kCounterStride];
 		// shadow rays of this bounce (adds the direct-light term before the next bounce adds its own)
 		if (nShadow) {
 			hipEvent_t *ev2 = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;

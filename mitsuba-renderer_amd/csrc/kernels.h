@@ -10,7 +10,9 @@ constexpr int kTraceBlock = 256;
 constexpr unsigned kTraceGridBlocks = 256 * 6;   // persistent traversal grid: 256 CUs x resident workgroups
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 constexpr int kCounterStride = 32;    // one 128-byte line per queue counter (atomics on one line serialise)
-constexpr int kNumCounters = 8;
+constexpr int kBinShards = 16;        // the closest-hit kernel appends to bins[b] through 16 independent segments
+constexpr int kNumCounters = kNumBins * kBinShards + 2;   // bins x shards, next, shadow
+constexpr int kShadeBlock = 512;
 
 // Scene in HBM (all pointers are device pointers); see DESIGN.md section 3
 struct DScene {
@@ -83,10 +85,11 @@ struct DConfig {
 };
 
 struct DQueues {
-	uint32_t *bins[kNumBins];     // per-material queues written by the closest-hit kernel
+	uint32_t *bins[kNumBins];     // per-material queues written by the closest-hit kernel: kBinShards segments of bin_seg_cap
+	uint32_t bin_seg_cap;
 	uint32_t *next;               // paths that continue (input of the next closest-hit launch)
 	uint32_t *shadow;             // paths with a pending shadow ray
-	uint32_t *counters;           // [i * kCounterStride]: i = 0..4 bins, 5 next, 6 shadow
+	uint32_t *counters;           // [i * kCounterStride]: i = b * kBinShards + shard for the bins, then next, shadow
 	unsigned long long *trace_counts;  // n_inner, n_leaf, n_idx, n_tri_tested (u64 x 4)
 	uint32_t *spill;              // traversal stack overflow: [level][thread]
 	uint32_t spill_stride;
@@ -103,8 +106,10 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 // mode 2: any-hit over ps.ray_* (writes ps.hit.w = occluded) -- test/benchmark API
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
                   const DQueues &q, const uint32_t *queue, uint32_t n);
+// prefix[s] = number of entries of the bin in segments < s (prefix[kBinShards] = total)
+struct BinView { uint32_t prefix[kBinShards + 1]; };
 void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
-                  const DQueues &q, uint32_t n);
+                  const DQueues &q, const BinView &view);
 void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,
                        uint32_t spp_per_slot, float *film);
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, size_t n);

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 	const uint32_t gtid = blockIdx.x * kTraceBlock + tid;     // spill slot of this lane
 	const uint32_t lane = lane_id();
 	const uint32_t stride = gridDim.x * kTraceBlock;
+	const uint32_t shard = blockIdx.x % kBinShards;     // contention on a bin counter is spread over kBinShards words
 
 	uint32_t c_inner = 0, c_leaf = 0, c_idx = 0, c_tri = 0;
 
@@ -418,8 +419,8 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 				#pragma unroll
 				for (int b = 0; b < kNumBins; ++b) {
 					const bool mine = (bin == b);
-					const uint32_t pos = wave_append(mine, &q.counters[b * kCounterStride]);
-					if (mine) q.bins[b][pos] = id;
+					const uint32_t pos = wave_append(mine, &q.counters[(b * kBinShards + shard) * kCounterStride]);
+					if (mine) q.bins[b][(size_t) shard * q.bin_seg_cap + pos] = id;
 				}
 			}
 		} else if (MODE == 1) {
@@ -813,10 +814,19 @@ __device__ __forceinline__ float mi_weight(float pdfA, float pdfB) {     // path
 // update; path.cpp:171-208) runs first because it needs the new hit.
 // ===========================================================================
 template <int BT>
-__global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, uint32_t n) {
+__global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, BinView view) {
+	__shared__ uint32_t s_cnt[2][kShadeBlock / 64];
+	__shared__ uint32_t s_base[2];
 	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-	const bool active = gtid < n;
-	const uint32_t id = active ? q.bins[BT][gtid] : 0u;
+	const bool active = gtid < view.prefix[kBinShards];
+	uint32_t id = 0u;
+	if (active) {
+		int seg = 0;
+		#pragma unroll
+		for (int k = 1; k < kBinShards; ++k)
+			if (gtid >= view.prefix[k]) seg = k;
+		id = q.bins[BT][(size_t) seg * q.bin_seg_cap + (gtid - view.prefix[seg])];
+	}
 	bool continues = false, wantShadow = false;
 
 	if (active) {
@@ -977,11 +987,24 @@ __global__ __launch_bounds__(256) void k_shade(DScene sc, DPaths ps, DConfig cfg
 		ps.misc(id) = make_uint4((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32), misc_zw.x, misc_zw.y);
 	}
 
-	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue
-	const uint32_t pn = wave_append(continues, &q.counters[kNumBins * kCounterStride]);
-	if (continues) q.next[pn] = id;
-	const uint32_t psh = wave_append(wantShadow, &q.counters[(kNumBins + 1) * kCounterStride]);
-	if (wantShadow) q.shadow[psh] = id;
+	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue.
+	// ballot + prefix popcount inside each wave, an LDS scan across the 8 waves, ONE atomic per
+	// workgroup and queue (a queue counter is a single word: every atomic on it serialises)
+	const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+	const unsigned long long mN = __ballot(continues), mS = __ballot(wantShadow);
+	if (lane == 0) { s_cnt[0][wave] = (uint32_t) __popcll(mN); s_cnt[1][wave] = (uint32_t) __popcll(mS); }
+	__syncthreads();
+	if (threadIdx.x < 2) {
+		uint32_t total = 0;
+		for (int w = 0; w < kShadeBlock / 64; ++w) total += s_cnt[threadIdx.x][w];
+		s_base[threadIdx.x] = total ? atomicAdd(&q.counters[(kNumBins * kBinShards + threadIdx.x) * kCounterStride], total) : 0u;
+	}
+	__syncthreads();
+	uint32_t offN = s_base[0], offS = s_base[1];
+	for (uint32_t w = 0; w < wave; ++w) { offN += s_cnt[0][w]; offS += s_cnt[1][w]; }
+	const unsigned long long below = (1ull << lane) - 1ull;
+	if (continues) q.next[offN + (uint32_t) __popcll(mN & below)] = id;
+	if (wantShadow) q.shadow[offS + (uint32_t) __popcll(mS & below)] = id;
 }
 
 // ===========================================================================
@@ -1072,15 +1095,16 @@ void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &s
 }
 
 void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
-                  const DQueues &q, uint32_t n) {
+                  const DQueues &q, const BinView &view) {
+	const uint32_t n = view.prefix[kBinShards];
 	if (!n) return;
-	const dim3 g(blocks_for(n, 256)), b(256);
+	const dim3 g(blocks_for(n, kShadeBlock)), b(kShadeBlock);
 	switch (bin) {
-		case 0: hipLaunchKernelGGL(k_shade<0>, g, b, 0, s, sc, ps, cfg, q, n); break;
-		case 1: hipLaunchKernelGGL(k_shade<1>, g, b, 0, s, sc, ps, cfg, q, n); break;
-		case 2: hipLaunchKernelGGL(k_shade<2>, g, b, 0, s, sc, ps, cfg, q, n); break;
-		case 3: hipLaunchKernelGGL(k_shade<3>, g, b, 0, s, sc, ps, cfg, q, n); break;
-		default: hipLaunchKernelGGL(k_shade<4>, g, b, 0, s, sc, ps, cfg, q, n); break;
+		case 0: hipLaunchKernelGGL(k_shade<0>, g, b, 0, s, sc, ps, cfg, q, view); break;
+		case 1: hipLaunchKernelGGL(k_shade<1>, g, b, 0, s, sc, ps, cfg, q, view); break;
+		case 2: hipLaunchKernelGGL(k_shade<2>, g, b, 0, s, sc, ps, cfg, q, view); break;
+		case 3: hipLaunchKernelGGL(k_shade<3>, g, b, 0, s, sc, ps, cfg, q, view); break;
+		default: hipLaunchKernelGGL(k_shade<4>, g, b, 0, s, sc, ps, cfg, q, view); break;
 	}
 }
 
