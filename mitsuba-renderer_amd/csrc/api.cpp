@@ -203,6 +203,18 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 			HIPCHK(c, hipGetLastError());
 			c->stats.rays_shadow += nShadow; c->stats.trace_launches++;
 		}
+		if (getenv("MTSGPU_DEBUG")) {
+			HIPCHK(c, hipStreamSynchronize(s));
+			float a = 0, b2 = 0, c2 = 0;
+			if (c->timeKernels) {
+				const size_t ti = c->traceEvUsed - (nShadow ? 2 : 1);
+				(void) hipEventElapsedTime(&a, c->traceEvents[ti].first, c->traceEvents[ti].second);
+				(void) hipEventElapsedTime(&b2, c->shadeEvents[c->shadeEvUsed - 1].first, c->shadeEvents[c->shadeEvUsed - 1].second);
+				if (nShadow) (void) hipEventElapsedTime(&c2, c->traceEvents[ti + 1].first, c->traceEvents[ti + 1].second);
+			}
+			fprintf(stderr, "bounce: closest %u rays %.3f ms (%.2f Grays/s) | shade %.3f ms | shadow %u rays %.3f ms (%.2f Grays/s)\n",
+			        nQ, a, a > 0 ? nQ / a / 1e6 : 0.0, b2, nShadow, c2, c2 > 0 ? nShadow / c2 / 1e6 : 0.0);
+		}
 		std::swap(cur, nxt);
 		nQ = nNext;
 	}
