@@ -125,3 +125,66 @@ def test_cancel_and_error_paths(gpu_lib, mts, orc):
     fresh = mts.MIPathTracer(maxDepth=4)
     with pytest.raises(mts.MtsGpuError):
         fresh.render()                                  # no scene uploaded
+
+
+# --------------------------------------------------------------------------------------------
+# BASELINE.json full size: the 1 044 482-triangle C3 scene at 1024 x 1024
+# --------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c3_full(gpu_lib, mts, orc):
+    sd = mts.scenes.cornell_c3()                      # grid 320 -> 1 024 000 wall triangles
+    scene = mts.Scene(sd)
+    oscene = orc.FlatScene(sd)
+    assert scene.sc.n_tris == 1044482
+    # the two independent host implementations agree on the whole tree
+    assert np.array_equal(scene.arrays()["kd_nodes"], oscene.arrays()["kd_nodes"])
+    assert np.array_equal(scene.arrays()["kd_indices"], oscene.arrays()["kd_indices"])
+    return sd, scene, oscene
+
+
+def test_full_size_li_samples_bit_exact(c3_full, mts, orc):
+    sd, scene, oscene = c3_full
+    W = H = 1024
+    cam = mts.PerspectiveCamera.for_description(sd, W, H)
+    it = mts.MIPathTracer(maxDepth=sd.max_depth)
+    it.preprocess(scene, cam, sampler="ldsampler", sampleCount=64, seed=0x5EED)
+    rng = np.random.RandomState(11)
+    ps = np.stack([rng.randint(0, W, 3000), rng.randint(0, H, 3000), rng.randint(0, 64, 3000)], axis=1).astype(np.uint32)
+    got = it.li_samples(ps)
+    op = orc.render_params(sd.max_depth, sampler=mts.abi.SAMPLER_LD_KEYED, spp=64, seed=0x5EED)
+    exp = orc.li_samples(oscene.scene, orc.make_camera(sd, W, H), op, ps)
+    bad = (got.view(np.uint32) != exp.view(np.uint32)).any(axis=1)
+    assert not bad.any(), "%d of %d samples differ" % (bad.sum(), len(ps))
+    assert exp[:, 6].max() >= 10                       # deep paths (glass + russian roulette) are covered
+
+
+def test_full_size_frame_properties(c3_full, mts, orc):
+    """size-independent properties at 1024^2: determinism, tile sharding, weight/alpha checksums,
+    and a crop rendered by the oracle"""
+    sd, scene, oscene = c3_full
+    W = H = 1024
+    spp = 4
+    cam = mts.PerspectiveCamera.for_description(sd, W, H)
+    it = mts.MIPathTracer(maxDepth=sd.max_depth)
+    it.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp, seed=3)
+    assert it.render()
+    a = it.film()
+    it.clear_film(); assert it.render()
+    assert np.array_equal(a.view(np.uint32), it.film().view(np.uint32))          # run-to-run identical
+    st = it.stats()
+    assert st["camera_samples"] == W * H * spp
+    # sharding over 5 parts (what 5 GPUs would render) sums to the same film
+    acc = np.zeros_like(a)
+    for part in range(5):
+        it.clear_film(); it.set_tiles(32, part, 5); assert it.render()
+        acc += it.film()
+    assert np.array_equal(acc.view(np.uint32), a.view(np.uint32))
+    # checksums: every sample lands in exactly one pixel with weight 1 (or 0 on a pixel border)
+    w = a[..., 4].astype(np.float64)
+    assert w.max() <= spp and w.sum() >= W * H * spp * 0.999
+    assert (a[..., 3] <= a[..., 4]).all() and np.isfinite(a).all() and (a[..., :3] >= 0).all()
+    # oracle crop at matched seeds
+    op = orc.render_params(sd.max_depth, sampler=mts.abi.SAMPLER_LD_KEYED, spp=spp, seed=3)
+    crop, _ = orc.render(oscene.scene, orc.make_camera(sd, W, H), op, rect=(600, 640, 664, 680))
+    assert np.array_equal(crop[640:680, 600:664].view(np.uint32), a[640:680, 600:664].view(np.uint32))
+    assert crop[640:680, 600:664, :3].max() > 0
