@@ -153,6 +153,14 @@ def main():
     one_spp_ms = (time.perf_counter() - t1) * 1e3
 
     if rank == 0:
+        # HBM traffic of the traversal launches from a separate PMC pass of the same frame (profiles/)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj["workload"] == {"grid": args.grid, "res": args.res, "spp": args.spp} and world == 1:
+                traffic = tj["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         total_samples = W * H * spp_total * args.steps
         value = total_samples / elapsed / 1e6
         achieved = bytes_per_step * args.steps / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
@@ -174,7 +182,8 @@ def main():
             "roofline": {
                 "kernel": "k_trace (closest-hit + shadow kd-tree traversal)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_per_step / max(counts["trace_launches"], 1),
                 "algorithmic_bytes_per_step": bytes_per_step, "bytes_per_ray": bytes_per_step / max(rays, 1),
                 "rays_per_step": rays, "launches_per_step": counts["trace_launches"],
                 "avg_launch_ms": trace_ms / max(trace_launches, 1), "trace_ms_per_step": trace_ms / args.steps,
