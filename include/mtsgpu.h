@@ -159,6 +159,11 @@ int  mtsgpu_set_sampler(mtsgpu_ctx *ctx, int kind, uint32_t spp, int ld_depth, u
 /* ImageBlock sharding (src/librender/imageproc.cpp:43-78): this ctx renders the
  * tiles t of the block_size^2 grid with (t % n_parts) == part. */
 int  mtsgpu_set_tiles(mtsgpu_ctx *ctx, int block_size, int part, int n_parts);
+/* Reconstruction filter of the film as a TabulatedFilter (src/librender/rfilter.cpp:40-69,
+ * include/mitsuba/render/rfilter.h:65-102): half extents and the 16x16 table Film::getTabulatedFilter()
+ * holds.  values == NULL selects the box filter (src/rfilters/box.cpp).  Filters wider than half a
+ * pixel make every ImageBlock carry a border of ceil(size - 0.5) pixels (renderproc.cpp:143-144). */
+int  mtsgpu_set_rfilter(mtsgpu_ctx *ctx, float size_x, float size_y, const float *values);
 /* Optional: render into a caller-owned device buffer [H][W][5] f32 (spec rgb, alpha, weight) */
 int  mtsgpu_set_film_buffer(mtsgpu_ctx *ctx, void *device_ptr);
 /* Tuning knobs (0 = default): paths in flight per pass; enable traversal counters */
@@ -223,6 +228,10 @@ const mtsgpu_scene *mtsgpu_flat_scene_get(const mtsgpu_flat_scene *fs);
 void mtsgpu_flat_scene_free(mtsgpu_flat_scene *fs);
 /* kd-tree statistics logged by the reference builder (gkdtree.h:1178-1213) */
 int  mtsgpu_flat_scene_kdstats(const mtsgpu_flat_scene *fs, double *out6 /* inner, leaf, idx, expTrav, expLeaves, expPrims */);
+
+/* TabulatedFilter for the `box` (kind 0) and `gaussian` (kind 1; halfSize, stddev properties,
+ * src/rfilters/gaussian.cpp:30-42,62-65) plugins: size_xy[2], values[256] */
+int  mtsgpu_tabulate_filter(int kind, float half_size, float stddev, float *size_xy, float *values);
 
 /* PerspectiveCameraImpl::configure for a lookAt camera (perspective.cpp:43-71,
  * transform.cpp:100-124,174-190).  fov in degrees along the smaller image side. */

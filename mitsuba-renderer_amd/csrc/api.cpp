@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <cmath>
 
 using namespace mg;
 
@@ -39,6 +40,10 @@ struct mtsgpu_ctx {
 
 	// film
 	float *film = nullptr; bool ownFilm = false; size_t filmPixels = 0;
+	float filtSizeX = 0.5f, filtSizeY = 0.5f; int filtBorder = 0;
+	float *filtValues = nullptr;           // device [16][16]
+	TileMeta *tileMeta = nullptr; size_t tileMetaCap = 0;
+	float *blocks = nullptr; size_t blocksCap = 0;
 
 	// per-pass buffers
 	size_t pathCap = 0;
@@ -142,6 +147,7 @@ DConfig makeConfig(const mtsgpu_ctx *c, bool slotPerPath) {
 	cfg.spp = effectiveSpp(c); cfg.ld_depth = c->ldDepth; cfg.seed = c->seed;
 	cfg.slot_per_path = slotPerPath ? 1 : 0;
 	cfg.ld_scr = c->ldScr; cfg.ld_perm = c->ldPerm;
+	cfg.filt_size_x = c->filtSizeX; cfg.filt_size_y = c->filtSizeY; cfg.filt_border = c->filtBorder; cfg.filt_values = c->filtValues;
 	return cfg;
 }
 
@@ -299,6 +305,9 @@ void mtsgpu_destroy(mtsgpu_ctx *c) {
 	if (c->ldScr) (void) hipFree(c->ldScr);
 	if (c->ldPerm) (void) hipFree(c->ldPerm);
 	if (c->explicitSamples) (void) hipFree(c->explicitSamples);
+	if (c->filtValues) (void) hipFree(c->filtValues);
+	if (c->tileMeta) (void) hipFree(c->tileMeta);
+	if (c->blocks) (void) hipFree(c->blocks);
 	if (c->hostCounters) (void) hipHostFree(c->hostCounters);
 	for (auto &e : c->traceEvents) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
 	for (auto &e : c->shadeEvents) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
@@ -484,6 +493,24 @@ int mtsgpu_set_tiles(mtsgpu_ctx *c, int block_size, int part, int n_parts) {
 	return 0;
 }
 
+int mtsgpu_set_rfilter(mtsgpu_ctx *c, float size_x, float size_y, const float *values) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	if (!values) { c->filtSizeX = c->filtSizeY = 0.5f; c->filtBorder = 0; return 0; }
+	if (!(size_x > 0) || !(size_y > 0) || size_x > 8 || size_y > 8) return fail(c, MTSGPU_EINVAL, "bad filter size");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (!c->filtValues) HIPCHK(c, hipMalloc((void **) &c->filtValues, 256 * sizeof(float)));
+	HIPCHK(c, hipMemcpy(c->filtValues, values, 256 * sizeof(float), hipMemcpyHostToDevice));
+	c->filtSizeX = size_x; c->filtSizeY = size_y;
+	c->filtBorder = (int) std::ceil(std::max(size_x, size_y) - 0.5f);       // renderproc.cpp:143-144
+	return 0;
+}
+
+int mtsgpu_tabulate_filter(int kind, float half_size, float stddev, float *size_xy, float *values) {
+	if (!size_xy || !values || (kind != 0 && kind != 1)) return fail(nullptr, MTSGPU_EINVAL, "bad filter arguments");
+	tabulateFilter(kind, half_size, stddev, size_xy, values);
+	return 0;
+}
+
 int mtsgpu_set_film_buffer(mtsgpu_ctx *c, void *device_ptr) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
 	if (c->ownFilm && c->film) (void) hipFree(c->film);
@@ -529,12 +556,18 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	const uint32_t spp = effectiveSpp(c);
 	// ImageBlock work units (imageproc.cpp:43-78) owned by this context: tile t -> part t % n_parts
 	std::vector<uint32_t> pixels;
+	std::vector<TileMeta> tiles;
 	const int tx = (W + bs - 1) / bs, ty = (H + bs - 1) / bs;
 	for (int t = 0; t < tx * ty; ++t) {
 		if (t % c->nParts != c->part) continue;
 		const int x0 = (t % tx) * bs, y0 = (t / tx) * bs;
-		for (int y = y0; y < std::min(y0 + bs, H); ++y)
-			for (int x = x0; x < std::min(x0 + bs, W); ++x)
+		TileMeta tm{};
+		tm.x0 = x0; tm.y0 = y0; tm.w = std::min(bs, W - x0); tm.h = std::min(bs, H - y0);
+		tm.slot_base = (uint32_t) pixels.size(); tm.block_index = (uint32_t) tiles.size();
+		tm.colour = (uint32_t) (((t % tx) & 1) + 2 * ((t / tx) & 1));
+		tiles.push_back(tm);
+		for (int y = y0; y < y0 + tm.h; ++y)
+			for (int x = x0; x < x0 + tm.w; ++x)
 				pixels.push_back((uint32_t) y * (uint32_t) W + (uint32_t) x);
 	}
 	std::memset(&c->stats, 0, sizeof(c->stats));
@@ -543,8 +576,11 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, pixels.size()); if (rc) return rc;
 	HIPCHK(c, hipMemcpyAsync(c->pixelList, pixels.data(), pixels.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 
+	const bool wideFilter = c->filtBorder > 0;
+	if (wideFilter && 2 * c->filtBorder > bs) return fail(c, MTSGPU_EINVAL, "filter border %d too wide for block size %d", c->filtBorder, bs);
 	const uint64_t maxPaths = c->maxPaths ? c->maxPaths : (72ull << 20);
-	const size_t slotsPerPass = (size_t) std::max<uint64_t>(1, std::min<uint64_t>(pixels.size(), maxPaths / spp));
+	size_t slotsPerPass = (size_t) std::max<uint64_t>(1, std::min<uint64_t>(pixels.size(), maxPaths / spp));
+	if (wideFilter) slotsPerPass = std::max<size_t>(slotsPerPass, (size_t) bs * bs);     // passes hold whole tiles
 	if ((uint64_t) slotsPerPass * spp > 0x7FFFFFFFull) return fail(c, MTSGPU_EINVAL, "pass too large");
 	rc = ensurePaths(c, slotsPerPass * spp); if (rc) return rc;
 	if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED) {
@@ -553,12 +589,31 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	}
 	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 4 * sizeof(unsigned long long), c->stream));
 	const DConfig cfg = makeConfig(c, false);
+	const size_t fullBlock = (size_t) (bs + 2 * c->filtBorder) * (bs + 2 * c->filtBorder) * 5;
+	if (wideFilter) {
+		rc = ensureBuf(c, &c->tileMeta, &c->tileMetaCap, tiles.size()); if (rc) return rc;
+		rc = ensureBuf(c, &c->blocks, &c->blocksCap, tiles.size() * fullBlock); if (rc) return rc;
+	}
 
 	hipEvent_t t0, t1;
 	HIPCHK(c, hipEventCreate(&t0)); HIPCHK(c, hipEventCreate(&t1));
 	HIPCHK(c, hipEventRecord(t0, c->stream));
-	for (size_t base = 0; base < pixels.size(); base += slotsPerPass) {
-		const uint32_t nSlots = (uint32_t) std::min(slotsPerPass, pixels.size() - base);
+	size_t tileCursor = 0;
+	for (size_t base = 0; base < pixels.size();) {
+		uint32_t nSlots;
+		size_t tileFirst = tileCursor;
+		if (wideFilter) {
+			// whole tiles only: a block gathers from all samples of its tile
+			size_t acc = 0;
+			while (tileCursor < tiles.size() && (acc == 0 || acc + (size_t) tiles[tileCursor].w * tiles[tileCursor].h <= slotsPerPass)) {
+				tiles[tileCursor].slot_base = (uint32_t) acc;                 // slot inside this pass
+				acc += (size_t) tiles[tileCursor].w * tiles[tileCursor].h;
+				++tileCursor;
+			}
+			nSlots = (uint32_t) acc;
+		} else {
+			nSlots = (uint32_t) std::min(slotsPerPass, pixels.size() - base);
+		}
 		const uint32_t nPaths = nSlots * spp;
 		if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED)
 			launch_ld_tables(c->stream, cfg, c->pixelList + base, nSlots, c->ldScr, c->ldPerm);
@@ -566,10 +621,21 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 		HIPCHK(c, hipGetLastError());
 		rc = runBounces(c, cfg, nPaths, cancel);
 		if (rc) { (void) hipEventDestroy(t0); (void) hipEventDestroy(t1); return rc; }
-		launch_accumulate(c->stream, c->paths, cfg, nSlots, spp, c->film);
+		if (wideFilter) {
+			const uint32_t nT = (uint32_t) (tileCursor - tileFirst);
+			HIPCHK(c, hipMemcpyAsync(c->tileMeta + tileFirst, tiles.data() + tileFirst, nT * sizeof(TileMeta), hipMemcpyHostToDevice, c->stream));
+			launch_splat_blocks(c->stream, c->paths, cfg, c->tileMeta + tileFirst, nT, spp, bs, c->blocks);
+		} else {
+			launch_accumulate(c->stream, c->paths, cfg, nSlots, spp, c->film);
+		}
 		HIPCHK(c, hipGetLastError());
 		c->stats.camera_samples += nPaths;
+		base += nSlots;
 	}
+	if (wideFilter)
+		for (uint32_t colour = 0; colour < 4; ++colour)
+			launch_add_blocks(c->stream, cfg, c->tileMeta, (uint32_t) tiles.size(), colour, bs, c->blocks, c->film);
+	HIPCHK(c, hipGetLastError());
 	HIPCHK(c, hipEventRecord(t1, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	float ms = 0;

@@ -213,6 +213,40 @@ void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatSc
 	sc.background_lum = background;
 }
 
+// TabulatedFilter::TabulatedFilter (src/librender/rfilter.cpp:40-69) over BoxFilter::evaluate
+// (src/rfilters/box.cpp:42-44) or GaussianFilter (src/rfilters/gaussian.cpp:30-42,62-65).
+// Host-side configure step; std::exp is the same libm call the reference makes.
+void tabulateFilter(int kind, float halfSize, float stddev, float *sizeXY, float *values) {
+	constexpr int R = 15;                                    // FILTER_RESOLUTION
+	float alpha = 0, cst = 0, sx, sy;
+	if (kind == 1) {
+		if (halfSize <= 0) halfSize = 2.0f;
+		if (stddev <= 0) stddev = 0.5f;
+		alpha = 1 / (2 * stddev * stddev);
+		sx = sy = halfSize;
+		cst = std::exp(-alpha * sx * sx);
+	} else {
+		sx = sy = 0.5f;
+	}
+	float sum = 0;
+	for (int y = 0; y < R + 1; ++y) {
+		const float yPos = (y + 0.5f) / R * sy;
+		for (int x = 0; x < R + 1; ++x) {
+			float v = 0;
+			if (x != R && y != R) {
+				const float xPos = (x + 0.5f) / R * sx;
+				v = (kind == 1) ? std::max(0.0f, std::exp(-alpha * xPos * xPos) - cst) * std::max(0.0f, std::exp(-alpha * yPos * yPos) - cst)
+				                : 1.0f;
+			}
+			values[y * 16 + x] = v;
+			sum += v;
+		}
+	}
+	sum *= 4 * sx * sy / (R * R);
+	for (int i = 0; i < 256; ++i) values[i] /= sum;
+	sizeXY[0] = sx; sizeXY[1] = sy;
+}
+
 // ---------------------------------------------------------------------------
 // Camera: Transform algebra of src/libcore/transform.cpp with the generic
 // Gauss-Jordan Matrix::invert (include/mitsuba/core/matrix.inl:140-190)

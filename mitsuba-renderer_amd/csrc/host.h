@@ -29,6 +29,8 @@ struct FlatScene {
 };
 
 void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatScene &fs);
+// TabulatedFilter of the box (kind 0) / gaussian (kind 1) plugins: sizeXY[2], values[16*16]
+void tabulateFilter(int kind, float halfSize, float stddev, float *sizeXY, float *values);
 void makeCamera(const float origin[3], const float target[3], const float up[3], float fovDeg, int width, int height,
                 mtsgpu_camera &out);
 

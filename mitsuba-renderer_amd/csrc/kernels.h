@@ -80,6 +80,10 @@ struct DConfig {
 	uint32_t spp; int32_t ld_depth;
 	uint64_t seed;
 	int32_t slot_per_path;        // 1: one sampler slot per path (explicit sample lists)
+	// TabulatedFilter (rfilter.h:65-102); border = ceil(max(size) - 0.5) (renderproc.cpp:143-144)
+	float filt_size_x, filt_size_y;
+	int32_t filt_border;
+	const float *filt_values;     // [16][16] on the device
 	const uint32_t *ld_scr;       // [slot][3*ld_depth]
 	const uint16_t *ld_perm;      // [slot][2*ld_depth][spp]
 };
@@ -112,6 +116,12 @@ void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, co
                   const DQueues &q, const BinView &view);
 void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,
                        uint32_t spp_per_slot, float *film);
+// ImageBlock tiles of one context: rect, first sampler slot of the tile inside its pass, block index
+struct TileMeta { int32_t x0, y0, w, h; uint32_t slot_base; uint32_t block_index; uint32_t colour; uint32_t pad; };
+void launch_splat_blocks(hipStream_t s, const DPaths &ps, const DConfig &cfg, const TileMeta *tiles, uint32_t n_tiles,
+                         uint32_t spp, int block_size, float *blocks);
+void launch_add_blocks(hipStream_t s, const DConfig &cfg, const TileMeta *tiles, uint32_t n_tiles, uint32_t colour,
+                       int block_size, const float *blocks, float *film);
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, size_t n);
 void launch_iota(hipStream_t s, uint32_t *p, uint32_t n);
 size_t trace_spill_levels();

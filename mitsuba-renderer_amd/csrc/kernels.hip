@@ -1051,6 +1051,84 @@ __global__ void k_accumulate(DPaths ps, DConfig cfg, uint32_t n_slots, uint32_t 
 }
 
 // ===========================================================================
+// K7b: ImageBlock::putSample for reconstruction filters wider than a pixel (gaussian, ...).
+// Like the reference, every tile owns a block with a border (renderproc.cpp:143-144,
+// imageblock.h:80-138) that only its own samples splat into; the blocks are then added to the film
+// (Film::putImageBlock, mfilm.cpp:118-143).  One lane per block pixel GATHERS the samples that
+// reach it, in (tile pixel row-major, sample index) order, so the sums are reproducible.
+// ===========================================================================
+__global__ __launch_bounds__(256) void k_splat_blocks(DPaths ps, DConfig cfg, const TileMeta *tiles, uint32_t spp,
+                                                     int block_size, float *blocks) {
+	const TileMeta tm = tiles[blockIdx.x];
+	const int border = cfg.filt_border, full = block_size + 2 * border;
+	const int fullW = tm.w + 2 * border, fullH = tm.h + 2 * border;
+	const float sizeX = cfg.filt_size_x, sizeY = cfg.filt_size_y;
+	const float factorX = 15 / sizeX, factorY = 15 / sizeY;      // FILTER_RESOLUTION / size (rfilter.cpp:43-45)
+	const int RX = (int) ceilf(sizeX + 0.5f), RY = (int) ceilf(sizeY + 0.5f);
+	const float offX = (float) (tm.x0 - border), offY = (float) (tm.y0 - border);
+	float *blk = blocks + (size_t) tm.block_index * full * full * 5;
+	for (int p = threadIdx.x; p < fullW * fullH; p += blockDim.x) {
+		const int yl = p / fullW, xl = p - yl * fullW;
+		const int X = tm.x0 - border + xl, Y = tm.y0 - border + yl;
+		float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+		if (X >= 0 && X < cfg.width && Y >= 0 && Y < cfg.height) {
+			const int pyLo = max(Y - RY, tm.y0), pyHi = min(Y + RY, tm.y0 + tm.h - 1);
+			const int pxLo = max(X - RX, tm.x0), pxHi = min(X + RX, tm.x0 + tm.w - 1);
+			for (int py = pyLo; py <= pyHi; ++py)
+				for (int px = pxLo; px <= pxHi; ++px) {
+					const size_t first = ((size_t) tm.slot_base + (size_t) (py - tm.y0) * tm.w + (px - tm.x0)) * spp;
+					for (uint32_t j = 0; j < spp; ++j) {
+						const float4 L = ps.Li(first + j);
+						const float4 sp = ps.spos(first + j);
+						if (L.x != L.x || L.x < 0.0f || L.y != L.y || L.y < 0.0f || L.z != L.z || L.z < 0.0f)
+							continue;                                   // Spectrum::isValid
+						const float slx = sp.x - 0.5f - offX, sly = sp.y - 0.5f - offY;
+						int xStart = (int) ceilf(slx - sizeX), xEnd = (int) floorf(slx + sizeX);
+						int yStart = (int) ceilf(sly - sizeY), yEnd = (int) floorf(sly + sizeY);
+						xStart = max(0, xStart); yStart = max(0, yStart);
+						xEnd = min(xEnd, fullW - 1); yEnd = min(yEnd, fullH - 1);
+						if (xl < xStart || xl > xEnd || yl < yStart || yl > yEnd)
+							continue;
+						const int ix = min((int) (factorX * fabsf(xl - slx)), 15);
+						const int iy = min((int) (factorY * fabsf(yl - sly)), 15);
+						const float weight = cfg.filt_values[iy * 16 + ix];
+						if (weight == 0.0f)
+							continue;
+						const float alpha = (__float_as_uint(L.w) & F_ALPHA) ? 1.0f : 0.0f;
+						a0 += L.x * weight; a1 += L.y * weight; a2 += L.z * weight;
+						a3 += alpha * weight; a4 += weight;
+					}
+				}
+		}
+		float *o = blk + 5 * ((size_t) yl * full + xl);
+		o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4;
+	}
+}
+
+// Film::putImageBlock for all tiles of one colour (tx%2 + 2*(ty%2)): their bordered blocks are
+// disjoint, so plain adds are race-free and the film is bit-reproducible.
+__global__ __launch_bounds__(256) void k_add_blocks(DConfig cfg, const TileMeta *tiles, uint32_t n_tiles, uint32_t colour,
+                                                   int block_size, const float *blocks, float *film) {
+	if (blockIdx.x >= n_tiles)
+		return;
+	const TileMeta tm = tiles[blockIdx.x];
+	if (tm.colour != colour)
+		return;
+	const int border = cfg.filt_border, full = block_size + 2 * border;
+	const int fullW = tm.w + 2 * border, fullH = tm.h + 2 * border;
+	const float *blk = blocks + (size_t) tm.block_index * full * full * 5;
+	for (int p = threadIdx.x; p < fullW * fullH; p += blockDim.x) {
+		const int yl = p / fullW, xl = p - yl * fullW;
+		const int X = tm.x0 - border + xl, Y = tm.y0 - border + yl;
+		if (X < 0 || X >= cfg.width || Y < 0 || Y >= cfg.height)
+			continue;
+		const float *b = blk + 5 * ((size_t) yl * full + xl);
+		float *o = film + 5 * ((size_t) Y * cfg.width + X);
+		o[0] += b[0]; o[1] += b[1]; o[2] += b[2]; o[3] += b[3]; o[4] += b[4];
+	}
+}
+
+// ===========================================================================
 // launchers
 // ===========================================================================
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned) ((n + bs - 1) / bs); }
@@ -1113,4 +1191,15 @@ void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint
 	if (n_slots) hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, ps, cfg, n_slots, spp_per_slot, film);
 }
 
+} // namespace mg
+
+namespace mg {
+void launch_splat_blocks(hipStream_t s, const DPaths &ps, const DConfig &cfg, const TileMeta *tiles, uint32_t n_tiles,
+                         uint32_t spp, int block_size, float *blocks) {
+	if (n_tiles) hipLaunchKernelGGL(k_splat_blocks, dim3(n_tiles), dim3(256), 0, s, ps, cfg, tiles, spp, block_size, blocks);
+}
+void launch_add_blocks(hipStream_t s, const DConfig &cfg, const TileMeta *tiles, uint32_t n_tiles, uint32_t colour,
+                       int block_size, const float *blocks, float *film) {
+	if (n_tiles) hipLaunchKernelGGL(k_add_blocks, dim3(n_tiles), dim3(256), 0, s, cfg, tiles, n_tiles, colour, block_size, blocks, film);
+}
 } // namespace mg

@@ -123,6 +123,19 @@ void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_
 void orc_render_rect_mt(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *p,
                         int kind, int x0, int y0, int x1, int y1, float *film);
 
+/* TabulatedFilter (src/librender/rfilter.cpp:40-69): kind 0 = box (src/rfilters/box.cpp),
+ * 1 = gaussian (src/rfilters/gaussian.cpp, halfSize / stddev properties) */
+typedef struct orc_tabfilter { float size_x, size_y, values[16][16]; } orc_tabfilter;
+void orc_tabulate_filter(int kind, float half_size, float stddev, orc_tabfilter *out);
+/* BlockedRenderProcess: every ImageBlock tile (imageproc.cpp:43-78) with t % n_parts == part is
+ * rendered into a block with a border of ceil(size - 0.5) pixels (renderproc.cpp:143-144) through
+ * ImageBlock::putSample, then added to the film (Film::putImageBlock, mfilm.cpp:118-143).
+ * Summation order is fixed: inside a block by (pixel row-major, sample index),
+ * blocks by (tx%2 + 2*(ty%2)) colour. */
+void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *p,
+                      const orc_tabfilter *filter, int block_size, int part, int n_parts,
+                      float *film, mtsgpu_stats *stats);
+
 /* BSDF entry points for the chi-square self-consistency test (test_chisquare.cpp:299-420).
  * wi, wo in the local shading frame. */
 void  orc_bsdf_f(uint32_t type, const float *params, const float wi[3], const float wo[3], float out[3]);

@@ -21,6 +21,10 @@ class RenderParams(C.Structure):
                 ("seed", C.c_uint64), ("n_threads", C.c_int)]
 
 
+class TabFilter(C.Structure):
+    _fields_ = [("size_x", C.c_float), ("size_y", C.c_float), ("values", (C.c_float * 16) * 16)]
+
+
 class TraceCounts(C.Structure):
     _fields_ = [("n_inner", C.c_uint64), ("n_leaf", C.c_uint64), ("n_idx", C.c_uint64), ("n_tri_tested", C.c_uint64)]
 
@@ -88,6 +92,9 @@ def lib():
                                  u32p, C.c_uint32, f32p]
     L.orc_render_rect_mt.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(RenderParams),
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+    L.orc_tabulate_filter.argtypes = [C.c_int, C.c_float, C.c_float, C.POINTER(TabFilter)]
+    L.orc_render_tiles.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(RenderParams), C.POINTER(TabFilter),
+                                   C.c_int, C.c_int, C.c_int, f32p, C.POINTER(abi.Stats)]
     L.orc_bsdf_f.argtypes = [C.c_uint32, f32p, f32p, f32p, f32p]
     L.orc_bsdf_pdf.argtypes = [C.c_uint32, f32p, f32p, f32p]; L.orc_bsdf_pdf.restype = C.c_float
     L.orc_bsdf_sample.argtypes = [C.c_uint32, f32p, f32p, f32p, f32p, f32p, u32p, f32p]
@@ -173,3 +180,17 @@ def develop(film):
     with np.errstate(divide="ignore", invalid="ignore"):
         inv = np.where(w > 0, np.float32(1.0) / w, np.float32(0)).astype(np.float32)
     return (film[..., :3] * inv).astype(np.float32)
+
+
+def tabulate_filter(kind="gaussian", half_size=2.0, stddev=0.5):
+    f = TabFilter()
+    lib().orc_tabulate_filter({"box": 0, "gaussian": 1}[kind], half_size, stddev, C.byref(f))
+    return f
+
+
+def render_tiles(scene_ptr, cam, params, filt, block_size=32, part=0, n_parts=1):
+    film = np.zeros((cam.height, cam.width, 5), dtype=np.float32)
+    st = abi.Stats()
+    lib().orc_render_tiles(scene_ptr, C.byref(cam), C.byref(params), C.byref(filt), block_size, part, n_parts,
+                           abi.ptr(film, abi.f32p), C.byref(st))
+    return film, st

@@ -1095,3 +1095,157 @@ void orc_render_rect_mt(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const 
 	}
 	free(t1d); free(t2d);
 }
+
+/* ========================================================================== */
+/* General reconstruction filters: tiles with borders                         */
+/* ========================================================================== */
+/* TabulatedFilter::TabulatedFilter (rfilter.cpp:40-69) over BoxFilter::evaluate (box.cpp:42-44)
+ * or GaussianFilter::evaluate (gaussian.cpp:62-65, ctor :30-42).  std::exp here is the host libm,
+ * as in the reference's configure step (not on the per-sample path). */
+void orc_tabulate_filter(int kind, float half_size, float stddev, orc_tabfilter *out) {
+	float alpha = 0, cst = 0;
+	if (kind == 1) {
+		if (half_size <= 0) half_size = 2.0f;
+		if (stddev <= 0) stddev = 0.5f;
+		alpha = 1 / (2*stddev*stddev);
+		out->size_x = out->size_y = half_size;
+		cst = expf(-alpha * out->size_x * out->size_x);
+	} else {
+		out->size_x = out->size_y = 0.5f;
+	}
+	float sum = 0;
+	for (int y = 0; y < FILTER_RESOLUTION+1; ++y) {
+		float yPos = (y + 0.5f) / FILTER_RESOLUTION * out->size_y;
+		for (int x = 0; x < FILTER_RESOLUTION+1; ++x) {
+			if (x == FILTER_RESOLUTION || y == FILTER_RESOLUTION) {
+				out->values[y][x] = 0;
+			} else {
+				float xPos = (x + 0.5f) / FILTER_RESOLUTION * out->size_x;
+				if (kind == 1)
+					out->values[y][x] = fmaxf_((float) 0.0f, expf(-alpha * xPos * xPos) - cst)
+					                  * fmaxf_((float) 0.0f, expf(-alpha * yPos * yPos) - cst);
+				else
+					out->values[y][x] = 1.0f;
+			}
+			sum += out->values[y][x];
+		}
+	}
+	sum *= 4*out->size_x*out->size_y / (FILTER_RESOLUTION*FILTER_RESOLUTION);
+	for (int y = 0; y < FILTER_RESOLUTION+1; ++y)
+		for (int x = 0; x < FILTER_RESOLUTION+1; ++x)
+			out->values[y][x] /= sum;
+}
+
+typedef struct { float L[3], alpha, sx, sy; int valid; } tsample_t;
+
+void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *prm,
+                      const orc_tabfilter *filter, int bs, int part, int n_parts,
+                      float *film, mtsgpu_stats *stats) {
+	const uint32_t spp = effective_spp(prm);
+	const int W = cam->width, H = cam->height;
+	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED;
+	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
+	const int tx = (W + bs - 1) / bs, ty = (H + bs - 1) / bs, nTiles = tx * ty;
+	/* m_borderSize (renderproc.cpp:143-144) */
+	const int border = (int) ceilf(fmaxf_(filter->size_x, filter->size_y) - (float) 0.5);
+	const int full = bs + 2 * border;
+	const float factorX = FILTER_RESOLUTION / filter->size_x, factorY = FILTER_RESOLUTION / filter->size_y;
+	const int RX = (int) ceilf(filter->size_x + 0.5f), RY = (int) ceilf(filter->size_y + 0.5f);
+	float **blocks = (float **) calloc((size_t) nTiles, sizeof(float *));
+	uint64_t nClosest = 0, nShadow = 0, nSamples = 0;
+#ifdef _OPENMP
+	int nthreads = prm->n_threads > 0 ? prm->n_threads : omp_get_max_threads();
+#pragma omp parallel num_threads(nthreads) reduction(+:nClosest,nShadow,nSamples)
+#endif
+	{
+		uint32_t *scr = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 3 * (size_t) depth) : NULL;
+		uint32_t *perm = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 2 * (size_t) depth * spp) : NULL;
+		tsample_t *smp = (tsample_t *) malloc(sizeof(tsample_t) * (size_t) bs * bs * spp);
+		mtsgpu_stats st; memset(&st, 0, sizeof(st));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+		for (int t = 0; t < nTiles; ++t) {
+			if (t % n_parts != part) continue;
+			const int x0 = (t % tx) * bs, y0 = (t / tx) * bs;
+			const int w = (x0 + bs <= W ? bs : W - x0), h = (y0 + bs <= H ? bs : H - y0);
+			/* 1. the camera samples of the tile (integrator.cpp:150-169) */
+			for (int py = 0; py < h; ++py) for (int px = 0; px < w; ++px) {
+				const uint32_t pixelKey = (uint32_t) (y0 + py) * (uint32_t) W + (uint32_t) (x0 + px);
+				if (isLD) orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);
+				for (uint32_t j = 0; j < spp; ++j) {
+					sampler_t s; memset(&s, 0, sizeof(s));
+					s.kind = isLD ? 1 : 0;
+					s.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
+					s.depth = depth; s.spp = spp; s.index = j; s.scr = scr; s.perm = perm;
+					float sample[2];
+					sampler_next2d(&s, sample);
+					sample[0] += x0 + px; sample[1] += y0 + py;
+					ray_t eyeRay;
+					camera_generate_ray(cam, sample, &eyeRay);
+					li_result res;
+					path_li(sc, prm, &eyeRay, &s, &res, &st);
+					tsample_t *o = &smp[((size_t) py * w + px) * spp + j];
+					o->L[0] = res.Li[0]; o->L[1] = res.Li[1]; o->L[2] = res.Li[2]; o->alpha = res.alpha;
+					o->sx = sample[0]; o->sy = sample[1];
+					o->valid = 1;
+					for (int c = 0; c < 3; ++c) if (res.Li[c] != res.Li[c] || res.Li[c] < 0.0f) o->valid = 0;
+				}
+			}
+			nSamples += (uint64_t) w * h * spp;
+			/* 2. ImageBlock::putSample for every block pixel, gathered in a fixed order */
+			float *blk = (float *) calloc((size_t) full * full * 5, sizeof(float));
+			const int fullW = w + 2 * border, fullH = h + 2 * border;
+			const float offX = (float) (x0 - border), offY = (float) (y0 - border);
+			for (int yl = 0; yl < fullH; ++yl) for (int xl = 0; xl < fullW; ++xl) {
+				const int X = x0 - border + xl, Y = y0 - border + yl;
+				if (X < 0 || X >= W || Y < 0 || Y >= H) continue;     /* dropped by Film::putImageBlock */
+				float acc[5] = { 0, 0, 0, 0, 0 };
+				for (int py = (Y - RY > y0 ? Y - RY : y0); py <= (Y + RY < y0 + h - 1 ? Y + RY : y0 + h - 1); ++py)
+				for (int px = (X - RX > x0 ? X - RX : x0); px <= (X + RX < x0 + w - 1 ? X + RX : x0 + w - 1); ++px) {
+					const tsample_t *ps = &smp[((size_t) (py - y0) * w + (px - x0)) * spp];
+					for (uint32_t j = 0; j < spp; ++j) {
+						const tsample_t *q = &ps[j];
+						if (!q->valid) continue;
+						const float slx = q->sx - 0.5f - offX, sly = q->sy - 0.5f - offY;
+						int xStart = (int) ceilf(slx - filter->size_x), xEnd = (int) floorf(slx + filter->size_x);
+						int yStart = (int) ceilf(sly - filter->size_y), yEnd = (int) floorf(sly + filter->size_y);
+						if (xStart < 0) xStart = 0;
+						if (yStart < 0) yStart = 0;
+						if (xEnd > fullW-1) xEnd = fullW-1;
+						if (yEnd > fullH-1) yEnd = fullH-1;
+						if (xl < xStart || xl > xEnd || yl < yStart || yl > yEnd) continue;
+						int ix = (int) (factorX * fabsf(xl - slx)); if (ix > FILTER_RESOLUTION) ix = FILTER_RESOLUTION;
+						int iy = (int) (factorY * fabsf(yl - sly)); if (iy > FILTER_RESOLUTION) iy = FILTER_RESOLUTION;
+						const float weight = filter->values[iy][ix];
+						if (weight == 0.0f) continue;
+						acc[0] += q->L[0] * weight; acc[1] += q->L[1] * weight; acc[2] += q->L[2] * weight;
+						acc[3] += q->alpha * weight; acc[4] += weight;
+					}
+				}
+				float *o = blk + 5 * ((size_t) yl * full + xl);
+				for (int c = 0; c < 5; ++c) o[c] = acc[c];
+			}
+			blocks[t] = blk;
+		}
+		nClosest += st.rays_closest; nShadow += st.rays_shadow;
+		free(scr); free(perm); free(smp);
+	}
+	/* 3. Film::putImageBlock in colour order */
+	for (int colour = 0; colour < 4; ++colour)
+		for (int t = 0; t < nTiles; ++t) {
+			if (!blocks[t] || (((t % tx) & 1) + 2 * ((t / tx) & 1)) != colour) continue;
+			const int x0 = (t % tx) * bs, y0 = (t / tx) * bs;
+			const int w = (x0 + bs <= W ? bs : W - x0), h = (y0 + bs <= H ? bs : H - y0);
+			for (int yl = 0; yl < h + 2 * border; ++yl) for (int xl = 0; xl < w + 2 * border; ++xl) {
+				const int X = x0 - border + xl, Y = y0 - border + yl;
+				if (X < 0 || X >= W || Y < 0 || Y >= H) continue;
+				const float *b = blocks[t] + 5 * ((size_t) yl * full + xl);
+				float *o = film + 5 * ((size_t) Y * W + X);
+				for (int c = 0; c < 5; ++c) o[c] += b[c];
+			}
+		}
+	for (int t = 0; t < nTiles; ++t) free(blocks[t]);
+	free(blocks);
+	if (stats) { stats->camera_samples += nSamples; stats->rays_closest += nClosest; stats->rays_shadow += nShadow; }
+}

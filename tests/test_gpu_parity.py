@@ -188,3 +188,30 @@ def test_full_size_frame_properties(c3_full, mts, orc):
     crop, _ = orc.render(oscene.scene, orc.make_camera(sd, W, H), op, rect=(600, 640, 664, 680))
     assert np.array_equal(crop[640:680, 600:664].view(np.uint32), a[640:680, 600:664].view(np.uint32))
     assert crop[640:680, 600:664, :3].max() > 0
+
+
+def test_gaussian_rfilter_matches_oracle(gpu_lib, mts, orc):
+    """the default film filter (film.cpp:89-95): bordered ImageBlocks + Film::putImageBlock"""
+    sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "c5_small", W=80, H=72, sampler="ldsampler", spp=8)
+    size, values = it.set_rfilter("gaussian")
+    of = orc.tabulate_filter("gaussian")
+    assert np.array_equal(values.view(np.uint32), np.array(of.values, dtype=np.float32).view(np.uint32)) and size[0] == of.size_x
+    assert it.render()
+    film = it.film()
+    ofilm, ost = orc.render_tiles(oscene.scene, ocam, op, of)
+    assert np.array_equal(film.view(np.uint32), ofilm.view(np.uint32))
+    # many small passes (whole tiles per pass) give the same film
+    it.set_options(max_paths=32 * 32 * 8 * 2)
+    it.clear_film(); assert it.render()
+    assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32))
+    it.set_options(max_paths=0)
+    # tile sharding: blocks of different parts overlap in their borders; the sum order differs by association only
+    acc = np.zeros_like(film)
+    for part in range(3):
+        it.clear_film(); it.set_tiles(32, part, 3); assert it.render()
+        acc += it.film()
+    assert np.allclose(acc, film, rtol=2e-6, atol=1e-7)
+    # back to the box filter
+    it.set_rfilter("box"); it.set_tiles(32, 0, 1); it.clear_film(); assert it.render()
+    obox, _ = orc.render(oscene.scene, ocam, op)
+    assert np.array_equal(it.film().view(np.uint32), obox.view(np.uint32))

@@ -207,3 +207,28 @@ def test_film_weights_and_determinism(mts, orc):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))   # thread count does not matter
     assert a[..., 4].max() <= 16 and a[..., 4].min() >= 14        # weight 0 only for samples on pixel borders
     assert (a[..., 3] <= a[..., 4]).all() and a[..., 3].min() < 16  # env-lit opening: alpha < 1 somewhere
+
+
+def test_bordered_tiles_and_gaussian_filter(mts, orc):
+    """ImageBlock borders (renderproc.cpp:143-144): the box filter through the tile path equals the plain
+    per-pixel path; the gaussian film conserves weight and radiance; product and oracle tabulate identically"""
+    sd = mts.scenes.cornell_c1()
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 70, 50)
+    prm = orc.render_params(4, sampler=mts.abi.SAMPLER_LD_KEYED, spp=8, seed=3)
+    a, _ = orc.render(fs.scene, cam, prm)
+    b, _ = orc.render_tiles(fs.scene, cam, prm, orc.tabulate_filter("box"))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    g = orc.tabulate_filter("gaussian")
+    tab = np.array(g.values, dtype=np.float32)
+    assert g.size_x == 2.0 and tab[15].sum() == 0 and tab[:, 15].sum() == 0 and tab[0, 0] == tab.max()
+    # rfilter.cpp:62-68: the table integrates to one over the filter footprint
+    assert abs(tab.sum() * 4 * g.size_x * g.size_y / 225.0 - 1.0) < 1e-5
+    c, _ = orc.render_tiles(fs.scene, cam, prm, g)
+    assert abs(orc.develop(c).mean() / orc.develop(a).mean() - 1) < 0.02
+    # interior pixels collect about spp of weight
+    assert abs(c[10:-10, 10:-10, 4].mean() / 8 - 1) < 0.05
+    # host tabulation of the product == oracle
+    size = np.zeros(2, dtype=np.float32); vals = np.zeros(256, dtype=np.float32)
+    assert mts.lib().mtsgpu_tabulate_filter(1, 2.0, 0.5, mts.abi.ptr(size, mts.abi.f32p), mts.abi.ptr(vals, mts.abi.f32p)) == 0
+    assert np.array_equal(vals.reshape(16, 16).view(np.uint32), tab.view(np.uint32)) and size[0] == 2.0
