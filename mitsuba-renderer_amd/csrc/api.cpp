@@ -418,8 +418,11 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 			const uint32_t prim = sc->kd_indices[e];
 			uint32_t *dst = &ta[12 * (size_t) e];
 			std::memcpy(dst, sc->triaccel + 12 * (size_t) prim, 48);
-			if (sc->shape_bsdf[dst[10]] < 0) dst[10] |= 0x80000000u;
-			dst[11] = prim;
+			// dword 0 = k<<30 | non-occluder<<29 | primitive id (the head of the record decides everything
+			// up to the plane distance); dword 10 stays the shape index
+			if (prim >= (1u << 29)) return fail(c, MTSGPU_EINVAL, "more than 2^29 primitives");
+			dst[0] = (std::min(dst[0], 3u) << 30) | (sc->shape_bsdf[dst[10]] < 0 ? 0x20000000u : 0u) | prim;
+			dst[11] = 0;
 		}
 		rc |= upload(c, (const uint32_t **) &d.leaf_ta, ta.data(), ta.size());
 		// per-primitive position / normal records for the shading kernels

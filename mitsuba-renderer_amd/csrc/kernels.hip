@@ -321,37 +321,35 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 				{
 					uint32_t e = nd.x & 0x7FFFFFFFu;
 					const uint32_t last = nd.y;
-					uint4 A, B, C;
-					if (e != last) {
-						const uint4 *ta = sc.leaf_ta + 3 * (size_t) e;
-						A = ta[0]; B = ta[1]; C = ta[2];
-					}
+					// record = 3 x 16 B: A = (k<<30 | non-occluder<<29 | prim, n_u, n_v, n_d), B = (a_u, a_v, b_nu, b_nv),
+					// C = (c_nu, c_nv, shape, -).  A alone decides the mailbox test and the plane distance t; B and C
+					// are only fetched for primitives whose t lies inside [mint, maxt] (triaccel.h:141-149).
+					uint4 A;
+					if (e != last) A = sc.leaf_ta[3 * (size_t) e];
 					while (e != last) {
-						// software pipeline: the next record is in flight while this one is tested
-						uint4 An = A, Bn = B, Cn = C;
-						if (e + 1 != last) {
-							const uint4 *tn = sc.leaf_ta + 3 * (size_t) (e + 1);
-							An = tn[0]; Bn = tn[1]; Cn = tn[2];
-						}
-						const uint32_t prim = C.w;
+						uint4 An = A;
+						if (e + 1 != last) An = sc.leaf_ta[3 * (size_t) (e + 1)];      // next record's head in flight
+						const uint32_t prim = A.x & 0x1FFFFFFFu, k = A.x >> 30;
 						if (COUNT) c_idx++;
 						if (s_mbox[prim & 7u][tid] != prim) {
 							if (COUNT) c_tri++;
 							const float n_u = __uint_as_float(A.y), n_v = __uint_as_float(A.z), n_d = __uint_as_float(A.w);
-							const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
-							const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
-							const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
 							float o_u, o_v, o_k, d_u, d_v, d_k;
 							bool ok = true;
-							if (A.x == 0u) { o_u = oy; o_v = oz; o_k = ox; d_u = dy; d_v = dz; d_k = dx; }
-							else if (A.x == 1u) { o_u = oz; o_v = ox; o_k = oy; d_u = dz; d_v = dx; d_k = dy; }
-							else if (A.x == 2u) { o_u = ox; o_v = oy; o_k = oz; d_u = dx; d_v = dy; d_k = dz; }
+							if (k == 0u) { o_u = oy; o_v = oz; o_k = ox; d_u = dy; d_v = dz; d_k = dx; }
+							else if (k == 1u) { o_u = oz; o_v = ox; o_k = oy; d_u = dz; d_v = dx; d_k = dy; }
+							else if (k == 2u) { o_u = ox; o_v = oy; o_k = oz; d_u = dx; d_v = dy; d_k = dz; }
 							else { ok = false; o_u = o_v = o_k = d_u = d_v = d_k = 0.0f; }
-							if (MODE != 0 && (C.z & 0x80000000u)) ok = false;    // shape->isOccluder() (skdtree.h:318-333)
+							if (MODE != 0 && (A.x & 0x20000000u)) ok = false;    // shape->isOccluder() (skdtree.h:318-333)
 							if (ok) {
 								const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
 								const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
 								if (!(t < mint || t > maxt)) {
+									const uint4 B = sc.leaf_ta[3 * (size_t) e + 1];
+									const uint2 C = *reinterpret_cast<const uint2 *>(sc.leaf_ta + 3 * (size_t) e + 2);
+									const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
+									const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
+									const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
 									const float hu = o_u + t * d_u - a_u;
 									const float hv = o_v + t * d_v - a_v;
 									const float u = hv * b_nu + hu * b_nv;
@@ -359,14 +357,14 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 									if (u >= 0 && v >= 0 && u + v <= 1.0f) {
 										if (MODE != 0) { hitShadow = true; break; }
 										maxt = t;      // a later hit with equal t replaces this one (t > maxt rejects)
-										best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = C.z & 0x7FFFFFFFu;
+										best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = e;
 										found = true;
 									}
 								}
 							}
 							s_mbox[prim & 7u][tid] = prim;
 						}
-						A = An; B = Bn; C = Cn;
+						A = An;
 						++e;
 					}
 				}
@@ -409,7 +407,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 				if (BIN) {
 					bin = kNumBins - 1;
 					if (found) {
-						const int b = sc.shape_bsdf[best_shape];
+						const int b = sc.shape_bsdf[sc.leaf_ta[3 * (size_t) best_shape + 2].z];   // shape of the hit record
 						if (b >= 0) bin = (int) sc.bsdf_type[b];
 					}
 				}
