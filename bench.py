@@ -90,7 +90,10 @@ def main():
     # --- scene (host side: generate, flatten, upload; not timed) ---
     sd = pkg.scenes.cornell_c3(grid=args.grid, sphere_subdiv=5)
     t0 = time.time()
-    scene = pkg.Scene(sd)
+    kp = None
+    if os.environ.get("MTSGPU_KD_TRAV"):          # experiment knob: Scene property kdTraversalCost (scene.cpp:54-88)
+        kp = pkg.abi.KdParams(); kp.traversal_cost = float(os.environ["MTSGPU_KD_TRAV"])
+    scene = pkg.Scene(sd, kp)
     flatten_s = time.time() - t0
     W = H = args.res
     spp_total = args.spp * world
