@@ -43,16 +43,29 @@ enum {
 	MTSGPU_BSDF_ROUGHMETAL = 2, /* params: [0] alphaB [1..3] ior [4..6] k [7..9] specRefl        */
 	MTSGPU_BSDF_MICROFACET = 3, /* params: [0] alphaB [1] kd [2] ks [3] intIOR [4] extIOR
 	                                       [5..7] diffuseRefl [8..10] specRefl                  */
-	MTSGPU_BSDF_NTYPES = 4
+	MTSGPU_BSDF_MIRROR = 4,     /* params: [0..2] specularReflectance            (src/bsdfs/mirror.cpp)      */
+	MTSGPU_BSDF_PHONG = 5,      /* params: [0] exponent [1] kd [2] ks [3] specularSamplingWeight
+	                                       [4] diffuseSamplingWeight [5..7] diffuseRefl [8..10] specRefl
+	                                       (values after Phong::configure, src/bsdfs/phong.cpp:74-96)   */
+	MTSGPU_BSDF_NTYPES = 6,
+	/* OR-ed into bsdf_type: the BSDF is wrapped in a `twosided` adapter (src/bsdfs/twosided.cpp) */
+	MTSGPU_BSDF_TWOSIDED = 0x100
 };
 #define MTSGPU_BSDF_NPARAMS 16
 
 /* Luminaire plugins on the path (src/luminaires/{area,constant}.cpp) */
 enum {
 	MTSGPU_LUM_AREA = 0,     /* params: [0..2] intensity; shape = emitting TriMesh            */
-	MTSGPU_LUM_CONSTANT = 1  /* params: [0..2] intensity [3..5] bsphere centre [6] radius      */
+	MTSGPU_LUM_CONSTANT = 1, /* params: [0..2] intensity [3..5] bsphere centre [6] radius      */
+	/* delta luminaires (isIntersectable() == false, path.cpp:118-120) */
+	MTSGPU_LUM_POINT = 2,    /* params: [0..2] intensity [3..5] position                (src/luminaires/point.cpp) */
+	MTSGPU_LUM_DIRECTIONAL = 3, /* [0..2] intensity [3..5] direction (unit) [6] disk radius = scene bsphere radius
+	                               (src/luminaires/directional.cpp:65-91)                                        */
+	MTSGPU_LUM_SPOT = 4      /* [0..2] intensity [3..5] position [6] cos(beamWidth) [7] cos(cutoffAngle)
+	                            [8] cutoffAngle (rad) [9] 1/(cutoffAngle-beamWidth) [10..18] world->luminaire
+	                            3x3 (row major) [19] beamWidth (rad)           (src/luminaires/spot.cpp:33-118) */
 };
-#define MTSGPU_LUM_NPARAMS 8
+#define MTSGPU_LUM_NPARAMS 24
 
 /* Sampler kinds.  *_KEYED are the per-(pixel,sample)-keyed forms of the two
  * reference samplers (src/samplers/{independent,ldsampler}.cpp): identical
@@ -121,6 +134,8 @@ typedef struct mtsgpu_camera {
 	float camera_to_world[16];  /* row-major 4x4, m_cameraToWorld                             */
 	float near_clip, far_clip;  /* camera.cpp:121-123                                         */
 	int32_t width, height;      /* film size == crop size                                     */
+	float aperture_radius;      /* thin lens (perspective.cpp:90-103); 0 = pinhole            */
+	float focus_depth;          /* camera.cpp:164                                             */
 } mtsgpu_camera;
 
 /* Per-kernel-class counters/timings of the last render (measurement, section 8d) */
@@ -210,7 +225,7 @@ typedef struct mtsgpu_scene_desc {
 	const float    *bsdf_params;
 	uint32_t n_lums;
 	const uint32_t *lum_type;    /* area luminaires must be referenced by exactly one mesh */
-	const float    *lum_params;  /* constant: only intensity needed, bsphere is computed   */
+	const float    *lum_params;  /* constant/directional: bsphere-derived entries are computed; spot: [6],[7],[9] are computed */
 	float camera_pos[3];         /* for ConstantLuminaire::preprocess (constant.cpp:49-63) */
 	int32_t has_camera;
 } mtsgpu_scene_desc;

@@ -127,17 +127,21 @@ class Scene:
 class PerspectiveCamera:
     """`perspective` camera plugin: lookAt toWorld transform, fov along the smaller side, pinhole."""
 
-    def __init__(self, origin, target, up, fov, width, height):
+    def __init__(self, origin, target, up, fov, width, height, apertureRadius=0.0, focusDepth=None):
         self.c = abi.Camera()
         rc = lib().mtsgpu_make_camera(abi.ptr(_f(origin), abi.f32p), abi.ptr(_f(target), abi.f32p), abi.ptr(_f(up), abi.f32p),
                                       C.c_float(fov), int(width), int(height), C.byref(self.c))
         if rc != 0:
             raise MtsGpuError("mtsgpu_make_camera: %s" % lib().mtsgpu_last_error(None).decode())
+        if apertureRadius > 0:                       # thin lens (camera.cpp:164-166, perspective.cpp:90-103)
+            self.c.aperture_radius = apertureRadius
+            self.c.focus_depth = self.c.far_clip if focusDepth is None else focusDepth
 
     @classmethod
     def for_description(cls, desc, width, height):
         c = desc.camera
-        return cls(c["origin"], c["target"], c["up"], c["fov"], width, height)
+        return cls(c["origin"], c["target"], c["up"], c["fov"], width, height,
+                   apertureRadius=c.get("aperture", 0.0), focusDepth=c.get("focus"))
 
     @property
     def width(self):

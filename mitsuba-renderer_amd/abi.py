@@ -6,10 +6,11 @@ import ctypes as C
 import numpy as np
 
 ABI_VERSION = 1
-BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET = 0, 1, 2, 3
+BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET, BSDF_MIRROR, BSDF_PHONG = 0, 1, 2, 3, 4, 5
+BSDF_TWOSIDED = 0x100
 BSDF_NPARAMS = 16
-LUM_AREA, LUM_CONSTANT = 0, 1
-LUM_NPARAMS = 8
+LUM_AREA, LUM_CONSTANT, LUM_POINT, LUM_DIRECTIONAL, LUM_SPOT = 0, 1, 2, 3, 4
+LUM_NPARAMS = 24
 SAMPLER_INDEPENDENT_KEYED, SAMPLER_LD_KEYED = 0, 1
 SHAPE_HAS_NORMALS = 1
 
@@ -40,6 +41,7 @@ class Camera(C.Structure):
         ("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
         ("near_clip", C.c_float), ("far_clip", C.c_float),
         ("width", C.c_int32), ("height", C.c_int32),
+        ("aperture_radius", C.c_float), ("focus_depth", C.c_float),
     ]
 
 

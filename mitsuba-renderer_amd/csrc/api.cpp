@@ -141,6 +141,7 @@ DConfig makeConfig(const mtsgpu_ctx *c, bool slotPerPath) {
 	std::memcpy(cfg.r2c, c->cam.raster_to_camera, sizeof(cfg.r2c));
 	std::memcpy(cfg.c2w, c->cam.camera_to_world, sizeof(cfg.c2w));
 	cfg.near_clip = c->cam.near_clip; cfg.far_clip = c->cam.far_clip;
+	cfg.aperture_radius = c->cam.aperture_radius; cfg.focus_depth = c->cam.focus_depth;
 	cfg.width = c->cam.width; cfg.height = c->cam.height;
 	cfg.max_depth = c->maxDepth; cfg.rr_depth = c->rrDepth; cfg.strict_normals = c->strictNormals;
 	cfg.sampler_kind = c->samplerKind;
@@ -354,14 +355,14 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	for (uint32_t t = 0; t < sc->n_tris; ++t)
 		if (sc->triaccel[12 * (size_t) t + 10] >= sc->n_shapes) return fail(c, MTSGPU_EINVAL, "TriAccel %u: shape index out of range", t);
 	for (uint32_t b = 0; b < sc->n_bsdfs; ++b)
-		if (sc->bsdf_type[b] >= MTSGPU_BSDF_NTYPES) return fail(c, MTSGPU_EINVAL, "BSDF %u: unknown type", b);
+		if ((sc->bsdf_type[b] & ~(uint32_t) MTSGPU_BSDF_TWOSIDED) >= MTSGPU_BSDF_NTYPES) return fail(c, MTSGPU_EINVAL, "BSDF %u: unknown type", b);
 	for (uint32_t l = 0; l < sc->n_lums; ++l) {
 		if (sc->lum_type[l] == MTSGPU_LUM_AREA) {
 			const int32_t s = sc->lum_shape[l];
 			if (s < 0 || s >= (int32_t) sc->n_shapes) return fail(c, MTSGPU_EINVAL, "luminaire %u: bad shape", l);
 			const uint32_t n = sc->shape_tri_offset[s + 1] - sc->shape_tri_offset[s];
 			if (sc->lum_cdf_offset[l + 1] - sc->lum_cdf_offset[l] != n + 1) return fail(c, MTSGPU_EINVAL, "luminaire %u: CDF size mismatch", l);
-		} else if (sc->lum_type[l] != MTSGPU_LUM_CONSTANT) {
+		} else if (sc->lum_type[l] > MTSGPU_LUM_SPOT) {
 			return fail(c, MTSGPU_EINVAL, "luminaire %u: unknown type", l);
 		}
 	}

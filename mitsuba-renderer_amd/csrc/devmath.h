@@ -145,12 +145,11 @@ HD float dlog(float x) {
 	return (float) ((double) e * LN2 + logm);
 }
 
-HD float datan(float x) {
+HD double atan_d(double xin) {
 	const double PIO2 = 1.57079632679489655800e+00;
 	const double PIO4 = 7.85398163397448278999e-01;
 	const double TAN_PIO8 = 0.41421356237309503;
-	if (x != x) return x;
-	double xd = (double) x;
+	double xd = xin;
 	bool neg = xd < 0.0;
 	if (neg) xd = -xd;
 	bool inv = xd > 1.0;
@@ -179,10 +178,79 @@ HD float datan(float x) {
 	double a = base + y * p;
 	if (inv) a = PIO2 - a;
 	if (neg) a = -a;
-	return (float) a;
+	return a;
+}
+HD float datan(float x) { if (x != x) return x; return (float) atan_d((double) x); }
+// std::acos: 2 atan(sqrt((1 - x) / (1 + x)))
+HD float dacos(float x) {
+	const double PI = 3.14159265358979311600e+00;
+	if (x != x || x > 1.0f || x < -1.0f) return __builtin_nanf("");
+	if (x == -1.0f) return (float) PI;
+	const double xd = (double) x;
+	return (float) (2.0 * atan_d(sqrt((1.0 - xd) / (1.0 + xd))));
 }
 
 HD float dpow4(float x) { double d = (double) x * (double) x; return (float) (d * d); }
+
+// binary64 exp / log (same reductions and polynomials as dexp / dlog) for pow
+HD double exp_d(double xd) {
+	const double LOG2E = 1.44269504088896338700e+00;
+	const double LN2_HI = 6.93147180369123816490e-01;
+	const double LN2_LO = 1.90821492927058770002e-10;
+	if (xd != xd) return xd;
+	if (xd > 700.0) return (double) MG_INF;
+	if (xd < -700.0) return 0.0;
+	double kd = xd * LOG2E;
+	long long k = (long long) (kd + (kd >= 0 ? 0.5 : -0.5));
+	double kf = (double) k;
+	double r = (xd - kf * LN2_HI) - kf * LN2_LO;
+	double p = 1.0 / 6227020800.0;
+	p = p * r + 1.0 / 479001600.0;
+	p = p * r + 1.0 / 39916800.0;
+	p = p * r + 1.0 / 3628800.0;
+	p = p * r + 1.0 / 362880.0;
+	p = p * r + 1.0 / 40320.0;
+	p = p * r + 1.0 / 5040.0;
+	p = p * r + 1.0 / 720.0;
+	p = p * r + 1.0 / 120.0;
+	p = p * r + 1.0 / 24.0;
+	p = p * r + 1.0 / 6.0;
+	p = p * r + 0.5;
+	p = p * r + 1.0;
+	p = p * r + 1.0;
+	return p * bits2d((uint64_t) (k + 1023) << 52);
+}
+HD double log_d(double xd) {
+	const double LN2 = 6.93147180559945286227e-01;
+	const double SQRT2 = 1.41421356237309514547e+00;
+	uint64_t bits = d2bits(xd);
+	long long e = (long long) ((bits >> 52) & 0x7ff) - 1023;
+	double m = bits2d((bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+	if (m > SQRT2) { m = m * 0.5; e = e + 1; }
+	double s = (m - 1.0) / (m + 1.0);
+	double s2 = s * s;
+	double p = 1.0 / 19.0;
+	p = p * s2 + 1.0 / 17.0;
+	p = p * s2 + 1.0 / 15.0;
+	p = p * s2 + 1.0 / 13.0;
+	p = p * s2 + 1.0 / 11.0;
+	p = p * s2 + 1.0 / 9.0;
+	p = p * s2 + 1.0 / 7.0;
+	p = p * s2 + 1.0 / 5.0;
+	p = p * s2 + 1.0 / 3.0;
+	p = p * s2 + 1.0;
+	return (double) e * LN2 + 2.0 * s * p;
+}
+// std::pow(x, y), x >= 0
+HD float dpow(float x, float y) {
+	if (x != x || y != y) return __builtin_nanf("");
+	if (y == 0.0f) return 1.0f;
+	if (x < 0.0f) return __builtin_nanf("");
+	if (x == 0.0f) return y > 0.0f ? 0.0f : MG_INF;
+	if (x == 1.0f) return 1.0f;
+	if (x == MG_INF) return y > 0.0f ? MG_INF : 0.0f;
+	return (float) exp_d((double) y * log_d((double) x));
+}
 
 // ---------------------------------------------------------------------------
 // Keyed stream + Random's derived draws (src/libcore/random.cpp:196-227)
@@ -262,6 +330,21 @@ HD V3 squareToHemispherePSA(float sx, float sy) {
 HD void squareToTriangle(float sx, float sy, float &bx, float &by) {
 	float a = sqrtf(1.0f - sx);
 	bx = 1 - a; by = a * sy;
+}
+// util.cpp:629-651
+HD void squareToDiskConcentric(float sx, float sy, float &ox, float &oy) {
+	const float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f;
+	float cx, cy;
+	if (r1 == 0 && r2 == 0) { cx = 0; cy = 0; }
+	else if (r1 > -r2) {
+		if (r1 > r2) { cx = r1; cy = (kPi / 4.0f) * r2 / r1; }
+		else { cx = r2; cy = (kPi / 4.0f) * (2.0f - r1 / r2); }
+	} else {
+		if (r1 < r2) { cx = -r1; cy = (kPi / 4.0f) * (4.0f + r2 / r1); }
+		else { cx = -r2; cy = (kPi / 4.0f) * (6.0f - r1 / r2); }
+	}
+	float s, c; dsincos(cy, s, c);
+	ox = cx * c; oy = cx * s;
 }
 // util.cpp:602-611
 HD void coordinateSystem(V3 a, V3 &b, V3 &c) {

@@ -182,6 +182,14 @@ void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatSc
 			}
 			P[3] = center.x; P[4] = center.y; P[5] = center.z; P[6] = br;
 			background = (int32_t) l;
+		} else if (fs.lumType[l] == MTSGPU_LUM_POINT) {
+			// nothing to derive (point.cpp:28-33)
+		} else if (fs.lumType[l] == MTSGPU_LUM_DIRECTIONAL) {
+			P[6] = radius;                          // DirectionalLuminaire::preprocess (directional.cpp:65-72)
+		} else if (fs.lumType[l] == MTSGPU_LUM_SPOT) {
+			P[6] = std::cos(P[19]);                 // SpotLuminaire::configure (spot.cpp:56-62)
+			P[7] = std::cos(P[8]);
+			P[9] = 1.0f / (P[8] - P[19]);
 		} else {
 			throw std::runtime_error("flatten: unknown luminaire type");
 		}
@@ -348,6 +356,7 @@ void makeCamera(const float origin[3], const float target[3], const float up[3],
 	std::memcpy(out.camera_to_world, c2w, sizeof(float) * 16);
 	out.near_clip = nearClip; out.far_clip = farClip;
 	out.width = width; out.height = height;
+	out.aperture_radius = 0.0f; out.focus_depth = farClip;     // camera.cpp:164-166 defaults
 }
 
 } // namespace mg

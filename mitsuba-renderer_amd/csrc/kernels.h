@@ -5,7 +5,8 @@
 
 namespace mg {
 
-constexpr int kNumBins = 5;           // 4 BSDF types + "terminal" (miss / no BSDF)
+constexpr int kNumBsdfTypes = 6;      // lambertian, dielectric, roughmetal, microfacet, mirror, phong
+constexpr int kNumBins = kNumBsdfTypes + 1;   // + "terminal" (miss / no BSDF)
 constexpr int kTraceBlock = 256;
 constexpr unsigned kTraceGridBlocks = 256 * 6;   // persistent traversal grid: 256 CUs x resident workgroups
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
@@ -74,6 +75,7 @@ enum : uint32_t {
 struct DConfig {
 	float r2c[16], c2w[16];       // rasterToCamera, cameraToWorld (row major)
 	float near_clip, far_clip;
+	float aperture_radius, focus_depth;   // thin lens (perspective.cpp:90-103); 0 = pinhole
 	int32_t width, height;
 	int32_t max_depth, rr_depth, strict_normals;
 	int32_t sampler_kind;

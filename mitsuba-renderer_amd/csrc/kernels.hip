@@ -138,7 +138,8 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 	PathSampler smp;
 	smp.stream = keyedInit(cfg.seed, pixel, 1 + (uint64_t) j);
 	smp.slot = slot; smp.j = j; smp.d1 = 0; smp.d2 = 0;
-	float sx, sy;
+	float sx, sy, lensX = 0, lensY = 0;
+	if (cfg.aperture_radius > 0.0f) sampler_next2d(cfg, smp, lensX, lensY);     // needsLensSample (integrator.cpp:156-157)
 	sampler_next2d(cfg, smp, sx, sy);
 	sx += (float) px; sy += (float) py;
 
@@ -151,15 +152,27 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 	V3 ic(ix, iy, iz);
 	if (iw != 1.0f)
 		ic = divs(ic, iw);
+	V3 lo(0.0f, 0.0f, 0.0f);
+	if (cfg.aperture_radius > 0.0f) {
+		// perspective.cpp:90-103: sample the aperture, aim at the focal plane
+		float lpx, lpy;
+		squareToDiskConcentric(lensX, lensY, lpx, lpy);
+		lpx *= cfg.aperture_radius; lpy *= cfg.aperture_radius;
+		const float tf = cfg.focus_depth / ic.z;
+		const V3 itsFocal(0.0f + tf * ic.x, 0.0f + tf * ic.y, 0.0f + tf * ic.z);
+		lo.x += lpx;
+		lo.y += lpy;
+		ic = itsFocal - lo;
+	}
 	V3 ld = normalize(ic);
 	float invZ = 1.0f / ld.z;
 	float mint = cfg.near_clip * invZ, maxt = cfg.far_clip * invZ;
 	// m_cameraToWorld(localRay, ray) (transform.h:219-235)
 	const float *w = cfg.c2w;
-	V3 o(w[0] * 0.0f + w[1] * 0.0f + w[2] * 0.0f + w[3],
-	     w[4] * 0.0f + w[5] * 0.0f + w[6] * 0.0f + w[7],
-	     w[8] * 0.0f + w[9] * 0.0f + w[10] * 0.0f + w[11]);
-	float ow = w[12] * 0.0f + w[13] * 0.0f + w[14] * 0.0f + w[15];
+	V3 o(w[0] * lo.x + w[1] * lo.y + w[2] * lo.z + w[3],
+	     w[4] * lo.x + w[5] * lo.y + w[6] * lo.z + w[7],
+	     w[8] * lo.x + w[9] * lo.y + w[10] * lo.z + w[11]);
+	float ow = w[12] * lo.x + w[13] * lo.y + w[14] * lo.z + w[15];
 	if (ow != 1.0f)
 		o = divs(o, ow);
 	V3 d(w[0] * ld.x + w[1] * ld.y + w[2] * ld.z,
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 					bin = kNumBins - 1;
 					if (found) {
 						const int b = sc.shape_bsdf[sc.leaf_ta[3 * (size_t) best_shape + 2].z];   // shape of the hit record
-						if (b >= 0) bin = (int) sc.bsdf_type[b];
+						if (b >= 0) bin = (int) (sc.bsdf_type[b] & 0xFFu);
 					}
 				}
 			}
@@ -529,7 +542,7 @@ __device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s
 	float sx = s0, sy = s1;
 	const int l = dpdf_sample_reuse(sc.lum_sel_cdf, sc.n_lums, sx);
 	const float lumPdf = sc.lum_sel_pdf[l];
-	const float *LP = sc.lum_params + 8 * (size_t) l;
+	const float *LP = sc.lum_params + 24 * (size_t) l;
 	if (sc.lum_type[l] == 0u) {
 		// AreaLuminaire::sample (area.cpp:68-79) -> Shape::sampleSolidAngle (shape.cpp:65-75)
 		// -> TriMesh::sampleArea (trimesh.cpp:297-302) -> Triangle::sample (triangle.cpp:23-47)
@@ -564,6 +577,32 @@ __device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s
 		} else {
 			lRec.pdf = 0;
 		}
+	} else if (sc.lum_type[l] == 2u || sc.lum_type[l] == 4u) {
+		// PointLuminaire::sample (point.cpp:55-63) / SpotLuminaire::sample (spot.cpp:110-118)
+		const V3 pos(LP[3], LP[4], LP[5]);
+		const V3 lumToP = p - pos;
+		const float invDist = 1.0f / length(lumToP);
+		lRec.p = pos;
+		lRec.d = lumToP * invDist;
+		lRec.n = V3(0, 0, 0);
+		lRec.pdf = 1.0f;
+		V3 result(LP[0], LP[1], LP[2]);
+		if (sc.lum_type[l] == 4u) {
+			// falloffCurve (spot.cpp:84-103), constant texture; cosTheta = m_worldToLuminaire(d).z
+			const float cosTheta = LP[16] * lRec.d.x + LP[17] * lRec.d.y + LP[18] * lRec.d.z;
+			if (cosTheta <= LP[7]) result = V3(0, 0, 0);
+			else if (!(cosTheta >= LP[6])) result = result * ((LP[8] - dacos(cosTheta)) * LP[9]);
+		}
+		lRec.value = result * (invDist * invDist);
+	} else if (sc.lum_type[l] == 3u) {
+		// DirectionalLuminaire::sample (directional.cpp:84-91)
+		const V3 dir(LP[3], LP[4], LP[5]);
+		const float k = 2 * LP[6];
+		lRec.p = V3(p.x - dir.x * k, p.y - dir.y * k, p.z - dir.z * k);
+		lRec.d = dir;
+		lRec.n = V3(0, 0, 0);
+		lRec.pdf = 1.0f;
+		lRec.value = V3(LP[0], LP[1], LP[2]);
 	} else {
 		// ConstantLuminaire::sample (constant.cpp:73-87)
 		const V3 d = squareToSphere(sx, sy);
@@ -790,12 +829,101 @@ template <> struct Bsdf<3> {
 	}
 };
 
-// "terminal" bin: never evaluated
+// Mirror (src/bsdfs/mirror.cpp:60-86): f = pdf = 0, delta reflection
 template <> struct Bsdf<4> {
+	static __device__ __forceinline__ V3 f(const float *, V3, V3) { return V3(0, 0, 0); }
+	static __device__ __forceinline__ float pdf(const float *, V3, V3) { return 0.0f; }
+	static __device__ __forceinline__ V3 sample(const float *P, V3 wi, float, float, V3 &wo, float &pdf, uint32_t &st) {
+		wo = V3(-wi.x, -wi.y, wi.z);
+		st = T_DELTA_REFL;
+		pdf = fabsf(wo.z);
+		return V3(P[0], P[1], P[2]);
+	}
+};
+
+// Phong (src/bsdfs/phong.cpp:104-212), parameters after Phong::configure, through BSDF::sample(bRec, pdf, s)
+template <> struct Bsdf<5> {
+	static constexpr float kInvTwoPi = 0.15915494309189533577f;
+	static __device__ __forceinline__ V3 f(const float *P, V3 wi, V3 wo) {
+		if (wi.z <= 0 || wo.z <= 0) return V3(0, 0, 0);
+		const V3 R(-wi.x, -wi.y, wi.z);
+		const float alpha = dot(R, wo);
+		float specRef;
+		if (alpha <= 0.0f) specRef = 0.0f;
+		else specRef = (P[0] + 2) * kInvTwoPi * dpow(alpha, P[0]) * P[2];
+		V3 r(0.0f + P[8] * specRef, 0.0f + P[9] * specRef, 0.0f + P[10] * specRef);
+		const float dk = kInvPi * P[1];
+		r.x += P[5] * dk; r.y += P[6] * dk; r.z += P[7] * dk;
+		return r;
+	}
+	static __device__ __forceinline__ float pdf_spec(const float *P, V3 wi, V3 wo) {
+		const V3 R(-wi.x, -wi.y, wi.z);
+		const float alpha = dot(R, wo);
+		float specPdf = dpow(alpha, P[0]) * (P[0] + 1.0f) / (2.0f * kPi);
+		if (alpha <= 0) specPdf = 0;
+		return specPdf;
+	}
+	static __device__ __forceinline__ float pdf(const float *P, V3 wi, V3 wo) {
+		if (wo.z <= 0 || wi.z <= 0) return 0.0f;
+		return P[3] * pdf_spec(P, wi, wo) + P[4] * (wo.z * kInvPi);
+	}
+	static __device__ __forceinline__ V3 sample(const float *P, V3 wi, float sx, float sy, V3 &wo, float &pdfv, uint32_t &st) {
+		pdfv = 0; st = 0; wo = V3(0, 0, 0);
+		if (wi.z <= 0) return V3(0, 0, 0);
+		V3 qv(0, 0, 0);
+		if (sx <= P[3]) {
+			sx /= P[3];
+			const V3 R(-wi.x, -wi.y, wi.z);                     // sampleSpecular (:157-182)
+			const float sinAlpha = sqrtf(1 - dpow(sy, 2 / (P[0] + 1)));
+			const float cosAlpha = dpow(sy, 1 / (P[0] + 1));
+			const float phi = (2.0f * kPi) * sx;
+			float sp, cp; dsincos(phi, sp, cp);
+			const V3 l(sinAlpha * cp, sinAlpha * sp, cosAlpha);
+			V3 fs, ft;
+			coordinateSystem(R, fs, ft);                         // Frame(R).toWorld(localDir)
+			wo = V3(fs.x * l.x + ft.x * l.y + R.x * l.z, fs.y * l.x + ft.y * l.y + R.y * l.z, fs.z * l.x + ft.z * l.y + R.z * l.z);
+			st = T_GLOSSY_REFL;
+			if (wo.z <= 0) return V3(0, 0, 0);
+			const float pdfVal = pdf(P, wi, wo);
+			if (pdfVal == 0) return V3(0, 0, 0);
+			qv = f(P, wi, wo) * (1.0f / pdfVal);
+		} else {
+			sx = (sx - P[3]) / P[4];
+			wo = squareToHemispherePSA(sx, sy);                  // sampleDiffuse (:188-193)
+			st = T_DIFFUSE_REFL;
+			qv = f(P, wi, wo) * (1.0f / pdf(P, wi, wo));
+		}
+		if (isZero(qv)) return V3(0, 0, 0);
+		pdfv = pdf(P, wi, wo);
+		return f(P, wi, wo);
+	}
+};
+
+// "terminal" bin: never evaluated
+template <> struct Bsdf<kNumBsdfTypes> {
 	static __device__ __forceinline__ V3 f(const float *, V3, V3) { return V3(0, 0, 0); }
 	static __device__ __forceinline__ float pdf(const float *, V3, V3) { return 0.0f; }
 	static __device__ __forceinline__ V3 sample(const float *, V3, float, float, V3 &wo, float &pdf, uint32_t &st) {
 		wo = V3(0, 0, 0); pdf = 0; st = 0; return V3(0, 0, 0);
+	}
+};
+
+// TwoSidedBRDF adapter (src/bsdfs/twosided.cpp:80-130) around any BSDF whose type carries MTSGPU_BSDF_TWOSIDED
+template <int BT> struct Bsdf2 {
+	static __device__ __forceinline__ V3 f(bool two, const float *P, V3 wi, V3 wo) {
+		if (two && wi.z < 0) { wi.z *= -1; wo.z *= -1; }
+		return Bsdf<BT>::f(P, wi, wo);
+	}
+	static __device__ __forceinline__ float pdf(bool two, const float *P, V3 wi, V3 wo) {
+		if (two && wi.z < 0) { wi.z *= -1; wo.z *= -1; }
+		return Bsdf<BT>::pdf(P, wi, wo);
+	}
+	static __device__ __forceinline__ V3 sample(bool two, const float *P, V3 wi, float sx, float sy, V3 &wo, float &pdf, uint32_t &st) {
+		bool flipped = false;
+		if (two && wi.z < 0) { wi.z *= -1; flipped = true; }
+		const V3 result = Bsdf<BT>::sample(P, wi, sx, sy, wo, pdf, st);
+		if (flipped && !isZero(result) && pdf != 0) wo.z *= -1;
+		return result;
 	}
 };
 
@@ -868,14 +996,14 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 				if (valid) {
 					if (shapeLum >= 0) {
 						// LuminaireSamplingRecord(its, -ray.d); value = its.Le(-ray.d) (area.cpp:62-66)
-						const float *LP = sc.lum_params + 8 * (size_t) shapeLum;
+						const float *LP = sc.lum_params + 24 * (size_t) shapeLum;
 						lp = its.p; ln = its.geoN; llum = shapeLum;
 						lvalue = (dot(-rayD, its.geoN) <= 0) ? V3(0, 0, 0) : V3(LP[0], LP[1], LP[2]);
 						hitLuminaire = true;
 					}
 				} else {
 					if (sc.background_lum >= 0) {
-						const float *LP = sc.lum_params + 8 * (size_t) sc.background_lum;
+						const float *LP = sc.lum_params + 24 * (size_t) sc.background_lum;
 						llum = sc.background_lum;
 						lvalue = V3(LP[0], LP[1], LP[2]);
 						hitLuminaire = true;
@@ -909,18 +1037,19 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 			// ---- head of the iteration (path.cpp:62-98) ----
 			if (!valid) {
 				if ((flags & F_EMITTED) && sc.background_lum >= 0) {
-					const float *LP = sc.lum_params + 8 * (size_t) sc.background_lum;
+					const float *LP = sc.lum_params + 24 * (size_t) sc.background_lum;
 					Li.x += thr.x * LP[0]; Li.y += thr.y * LP[1]; Li.z += thr.z * LP[2];
 				}
 				break;
 			}
-			if (BT == 4)
+			if (BT == kNumBsdfTypes)
 				break;                                      // bsdf == NULL (path.cpp:72-77)
 			const int bsdfIdx = sc.shape_bsdf[its.shape];
 			const float *BP = sc.bsdf_params + 16 * (size_t) bsdfIdx;
+			const bool twoSided = (sc.bsdf_type[bsdfIdx] & 0x100u) != 0;
 			if (shapeLum >= 0 && (flags & F_EMITTED)) {
 				// Li += pathThroughput * its.Le(-ray.d) (path.cpp:80-81, area.cpp:62-66)
-				const float *LP = sc.lum_params + 8 * (size_t) shapeLum;
+				const float *LP = sc.lum_params + 24 * (size_t) shapeLum;
 				const V3 le = (dot(-rayD, its.geoN) <= 0) ? V3(0.0f, 0.0f, 0.0f) : V3(LP[0], LP[1], LP[2]);
 				Li.x += thr.x * le.x; Li.y += thr.y * le.y; Li.z += thr.z * le.z;
 			}
@@ -938,10 +1067,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 				if (sample_luminaire(sc, its.p, s0, s1, lRec)) {
 					const V3 wo = -lRec.d;
 					const V3 woL(dot(wo, its.shS), dot(wo, its.shT), dot(wo, its.shN));
-					V3 bsdfVal = Bsdf<BT>::f(BP, its.wi, woL) * fabsf(woL.z);
+					V3 bsdfVal = Bsdf2<BT>::f(twoSided, BP, its.wi, woL) * fabsf(woL.z);
 					const float woDotGeoN = dot(its.geoN, wo);
 					if (!isZero(bsdfVal) && (!cfg.strict_normals || woDotGeoN * woL.z > 0)) {
-						const float bsdfPdf = Bsdf<BT>::pdf(BP, its.wi, woL);
+						// isIntersectable() || isBackgroundLuminaire() (path.cpp:118-120): 0 for delta luminaires
+						const float bsdfPdf = (sc.lum_type[lRec.lum] <= 1u) ? Bsdf2<BT>::pdf(twoSided, BP, its.wi, woL) : 0.0f;
 						const float weight = mi_weight(lRec.pdf, bsdfPdf);
 						// added to Li by k_trace<shadow> iff the segment is unoccluded
 						ps.nee(id) = make_float4(thr.x * lRec.value.x * bsdfVal.x * weight,
@@ -959,7 +1089,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 			float s0, s1;
 			sampler_next2d(cfg, smp, s0, s1);
 			V3 woL; float bsdfPdf; uint32_t sampledType;
-			V3 bsdfVal = Bsdf<BT>::sample(BP, its.wi, s0, s1, woL, bsdfPdf, sampledType);
+			V3 bsdfVal = Bsdf2<BT>::sample(twoSided, BP, its.wi, s0, s1, woL, bsdfPdf, sampledType);
 			if (!isZero(bsdfVal))
 				bsdfVal = bsdfVal * fabsf(woL.z);          // sampleCos (bsdf.h:273-279)
 			if (isZero(bsdfVal))
@@ -1180,7 +1310,9 @@ void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, co
 		case 1: hipLaunchKernelGGL(k_shade<1>, g, b, 0, s, sc, ps, cfg, q, view); break;
 		case 2: hipLaunchKernelGGL(k_shade<2>, g, b, 0, s, sc, ps, cfg, q, view); break;
 		case 3: hipLaunchKernelGGL(k_shade<3>, g, b, 0, s, sc, ps, cfg, q, view); break;
-		default: hipLaunchKernelGGL(k_shade<4>, g, b, 0, s, sc, ps, cfg, q, view); break;
+		case 4: hipLaunchKernelGGL(k_shade<4>, g, b, 0, s, sc, ps, cfg, q, view); break;
+		case 5: hipLaunchKernelGGL(k_shade<5>, g, b, 0, s, sc, ps, cfg, q, view); break;
+		default: hipLaunchKernelGGL(k_shade<kNumBsdfTypes>, g, b, 0, s, sc, ps, cfg, q, view); break;
 	}
 }
 

@@ -56,6 +56,53 @@ class SceneDescription:
     def microfacet(self, alpha=0.1, kd=0.5, ks=0.5, int_ior=1.5, ext_ior=1.0, rd=1.0, rs=1.0):
         return self.add_bsdf(abi.BSDF_MICROFACET, [alpha, kd, ks, int_ior, ext_ior, rd, rd, rd, rs, rs, rs])
 
+    def mirror(self, r=0.8):
+        return self.add_bsdf(abi.BSDF_MIRROR, [r, r, r])
+
+    def phong(self, exponent=10.0, rd=0.5, rs=0.2, kd=1.0, ks=1.0):
+        """parameter block as Phong::configure() leaves it (src/bsdfs/phong.cpp:74-96), float32 arithmetic"""
+        kd, ks, rd, rs = F(kd), F(ks), F(rd), F(rs)
+        if kd * rd + ks * rs > F(1.0):                       # verifyEnergyConservation
+            norm = F(1) / (kd * rd + ks * rs)
+            kd, ks = kd * norm, ks * norm
+        avg_d = (rd + rd + rd) * F(1.0 / 3) * kd             # Spectrum::average() * m_kd
+        avg_s = (rs + rs + rs) * F(1.0 / 3) * ks
+        ssw = avg_s / (avg_d + avg_s)
+        dsw = F(1.0) - ssw
+        return self.add_bsdf(abi.BSDF_PHONG, [exponent, kd, ks, ssw, dsw, rd, rd, rd, rs, rs, rs])
+
+    def twosided(self, bsdf):
+        """wrap an existing BSDF block in the `twosided` adapter (src/bsdfs/twosided.cpp)"""
+        self.bsdf_type[bsdf] |= abi.BSDF_TWOSIDED
+        return bsdf
+
+    def point_light(self, position, intensity):
+        l = self.add_lum(abi.LUM_POINT, [intensity] * 3 if np.isscalar(intensity) else intensity)
+        self.lum_params[l][3:6] = np.asarray(position, dtype=np.float32)
+        return l
+
+    def directional_light(self, direction, intensity):
+        l = self.add_lum(abi.LUM_DIRECTIONAL, [intensity] * 3 if np.isscalar(intensity) else intensity)
+        d = np.asarray(direction, dtype=np.float32)
+        self.lum_params[l][3:6] = d / np.sqrt((d * d).sum(), dtype=np.float32)
+        return l
+
+    def spot_light(self, position, target, intensity, cutoff_deg=20.0, beam_deg=None):
+        """SpotLuminaire with toWorld = lookAt(position, target, up) (src/luminaires/spot.cpp:33-62)"""
+        l = self.add_lum(abi.LUM_SPOT, [intensity] * 3 if np.isscalar(intensity) else intensity)
+        P = self.lum_params[l]
+        pos, tgt = np.asarray(position, dtype=np.float32), np.asarray(target, dtype=np.float32)
+        d = tgt - pos; d = d / np.sqrt((d * d).sum(), dtype=np.float32)
+        up = np.array([0, 0, 1], dtype=np.float32) if abs(d[2]) < 0.9 else np.array([1, 0, 0], dtype=np.float32)
+        right = np.cross(d, up).astype(np.float32); right /= np.sqrt((right * right).sum(), dtype=np.float32)
+        new_up = np.cross(right, d).astype(np.float32)
+        P[3:6] = pos
+        beam = cutoff_deg * 0.75 if beam_deg is None else beam_deg
+        P[8] = F(cutoff_deg) * (F(np.pi) / F(180.0))         # degToRad
+        P[19] = F(beam) * (F(np.pi) / F(180.0))
+        P[10:13] = right; P[13:16] = new_up; P[16:19] = d    # world -> luminaire rotation (rows)
+        return l
+
     def add_lum(self, ltype, intensity):
         p = np.zeros(abi.LUM_NPARAMS, dtype=np.float32)
         p[:3] = np.asarray(intensity, dtype=np.float32)
@@ -253,5 +300,31 @@ def cornell_c5(sphere_subdiv=4):
     return sd
 
 
+def next_rows(sphere_subdiv=2):
+    """mirror / phong / twosided BSDFs, point / spot / directional luminaires, thin lens"""
+    sd = SceneDescription("next_rows")
+    white = sd.twosided(sd.lambertian(0.73))
+    red = sd.twosided(sd.lambertian(0.63, 0.065, 0.05))
+    green = sd.lambertian(0.14, 0.45, 0.091)
+    for name, p0, e1, e2, nrm in _box_faces():
+        pos, tri = _quad(p0, e1, e2, nrm)
+        if name == "back":
+            tri = tri[:, [0, 2, 1]]                 # wound the wrong way round: only a twosided BSDF shades it
+        sd.add_mesh(pos, tri, bsdf={"left": red, "right": green}.get(name, white), face_normals=True, name=name)
+    _add_light(sd, intensity=6.0)
+    mats = [sd.mirror(0.8), sd.phong(20.0, 0.4, 0.3), sd.twosided(sd.roughmetal(0.2)), sd.phong(5.0, 0.9, 0.6)]
+    centres = [(-0.5, 0.3, -0.4), (0.5, 0.3, -0.4), (-0.5, 0.3, 0.45), (0.5, 0.3, 0.45)]
+    for m, c in zip(mats, centres):
+        pos, tri = icosphere(sphere_subdiv, 0.3, c)
+        sd.add_mesh(pos, tri, bsdf=m, face_normals=False, name="sphere")
+    sd.point_light((0.0, 1.2, 0.6), 0.6)
+    sd.spot_light((-0.8, 1.8, 0.8), (0.4, 0.0, -0.3), 25.0, cutoff_deg=25.0)
+    sd.directional_light((0.3, -1.0, -0.4), 0.4)
+    sd.camera["aperture"] = 0.04
+    sd.camera["focus"] = 3.3
+    sd.max_depth = 8
+    return sd
+
+
 def by_name(name, **kw):
-    return {"c1": cornell_c1, "c3": cornell_c3, "c5": cornell_c5}[name](**kw)
+    return {"c1": cornell_c1, "c3": cornell_c3, "c5": cornell_c5, "next": next_rows}[name](**kw)

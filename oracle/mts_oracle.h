@@ -77,6 +77,8 @@ void  orc_fresnel_conductor(float cosTheta, const float eta[3], const float k[3]
 /* deterministic elementary functions shared (as a specification) with the kernels */
 float orc_sinf(float x); float orc_cosf(float x); float orc_expf(float x);
 float orc_logf(float x); float orc_atanf(float x); float orc_pow4f(float x);
+float orc_powf(float x, float y); float orc_acosf(float x);
+void  orc_square_to_disk_concentric(const float s[2], float out[2]);
 
 /* ---------------- triangle code ------------------------------------------- */
 /* Triangle::getClippedAABB (src/libcore/triangle.cpp:59-158); returns 0 if invalid */

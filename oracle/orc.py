@@ -141,6 +141,9 @@ def make_camera(desc, width, height):
     c = desc.camera
     lib().orc_make_camera(abi.ptr(_f(c["origin"]), abi.f32p), abi.ptr(_f(c["target"]), abi.f32p),
                           abi.ptr(_f(c["up"]), abi.f32p), C.c_float(c["fov"]), width, height, C.byref(cam))
+    if c.get("aperture", 0.0) > 0:
+        cam.aperture_radius = c["aperture"]
+        cam.focus_depth = c.get("focus", cam.far_clip)
     return cam
 
 

@@ -384,12 +384,11 @@ float orc_logf(float x) {
 	return (float) ((double) e * LN2 + logm);
 }
 
-float orc_atanf(float x) {
+static double dm_atan_d(double xin) {
 	const double PIO2 = 1.57079632679489655800e+00;
 	const double PIO4 = 7.85398163397448278999e-01;
 	const double TAN_PIO8 = 0.41421356237309503;
-	if (x != x) return x;
-	double xd = (double) x;
+	double xd = xin;
 	int neg = xd < 0.0;
 	if (neg) xd = -xd;
 	int inv = xd > 1.0;
@@ -418,13 +417,90 @@ float orc_atanf(float x) {
 	double a = base + y * p;
 	if (inv) a = PIO2 - a;
 	if (neg) a = -a;
-	return (float) a;
+	return a;
+}
+
+float orc_atanf(float x) {
+	if (x != x) return x;
+	return (float) dm_atan_d((double) x);
 }
 
 /* std::pow(x, 4.0f) */
 float orc_pow4f(float x) {
 	double d = (double) x * (double) x;
 	return (float) (d * d);
+}
+
+/* binary64 exp / log with the same reductions and polynomials as orc_expf / orc_logf */
+static double dm_exp_d(double xd) {
+	const double LOG2E = 1.44269504088896338700e+00;
+	const double LN2_HI = 6.93147180369123816490e-01;
+	const double LN2_LO = 1.90821492927058770002e-10;
+	if (xd != xd) return xd;
+	if (xd > 700.0) return INFINITY;
+	if (xd < -700.0) return 0.0;
+	double kd = xd * LOG2E;
+	long long k = (long long) (kd + (kd >= 0 ? 0.5 : -0.5));
+	double kf = (double) k;
+	double r = (xd - kf * LN2_HI) - kf * LN2_LO;
+	double p = 1.0 / 6227020800.0;
+	p = p * r + 1.0 / 479001600.0;
+	p = p * r + 1.0 / 39916800.0;
+	p = p * r + 1.0 / 3628800.0;
+	p = p * r + 1.0 / 362880.0;
+	p = p * r + 1.0 / 40320.0;
+	p = p * r + 1.0 / 5040.0;
+	p = p * r + 1.0 / 720.0;
+	p = p * r + 1.0 / 120.0;
+	p = p * r + 1.0 / 24.0;
+	p = p * r + 1.0 / 6.0;
+	p = p * r + 0.5;
+	p = p * r + 1.0;
+	p = p * r + 1.0;
+	return p * u64_as_double((uint64_t) (k + 1023) << 52);
+}
+
+static double dm_log_d(double xd) {      /* xd > 0, finite, normal */
+	const double LN2 = 6.93147180559945286227e-01;
+	const double SQRT2 = 1.41421356237309514547e+00;
+	uint64_t bits = double_as_u64(xd);
+	long long e = (long long) ((bits >> 52) & 0x7ff) - 1023;
+	double m = u64_as_double((bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+	if (m > SQRT2) { m = m * 0.5; e = e + 1; }
+	double s = (m - 1.0) / (m + 1.0);
+	double s2 = s * s;
+	double p = 1.0 / 19.0;
+	p = p * s2 + 1.0 / 17.0;
+	p = p * s2 + 1.0 / 15.0;
+	p = p * s2 + 1.0 / 13.0;
+	p = p * s2 + 1.0 / 11.0;
+	p = p * s2 + 1.0 / 9.0;
+	p = p * s2 + 1.0 / 7.0;
+	p = p * s2 + 1.0 / 5.0;
+	p = p * s2 + 1.0 / 3.0;
+	p = p * s2 + 1.0;
+	return (double) e * LN2 + 2.0 * s * p;
+}
+
+/* std::pow(x, y) for x >= 0 (phong.cpp:120,133,163-164): exp(y * log(x)) in binary64 */
+float orc_powf(float x, float y) {
+	if (x != x || y != y) return NAN;
+	if (y == 0.0f) return 1.0f;
+	if (x < 0.0f) return NAN;
+	if (x == 0.0f) return y > 0.0f ? 0.0f : INFINITY;
+	if (x == 1.0f) return 1.0f;
+	if (x == INFINITY) return y > 0.0f ? INFINITY : 0.0f;
+	return (float) dm_exp_d((double) y * dm_log_d((double) x));
+}
+
+/* std::acos (spot.cpp:98): 2 atan(sqrt((1-x)/(1+x))) in binary64 */
+float orc_acosf(float x) {
+	const double PI = 3.14159265358979311600e+00;
+	if (x != x || x > 1.0f || x < -1.0f) return NAN;
+	if (x == -1.0f) return (float) PI;
+	double xd = (double) x;
+	double q = sqrt((1.0 - xd) / (1.0 + xd));
+	return (float) (2.0 * dm_atan_d(q));
 }
 
 /* ========================================================================== */
@@ -460,6 +536,24 @@ void orc_square_to_hemisphere_psa(const float s[2], float out[3]) {
 void orc_square_to_triangle(const float s[2], float out[2]) {
 	float a = sqrtf(1.0f - s[0]);
 	out[0] = 1 - a; out[1] = a * s[1];
+}
+
+/* util.cpp:629-651 */
+void orc_square_to_disk_concentric(const float s[2], float out[2]) {
+	float r1 = 2.0f*s[0] - 1.0f;
+	float r2 = 2.0f*s[1] - 1.0f;
+	float cx, cy;
+	if (r1 == 0 && r2 == 0) {
+		cx = 0; cy = 0;
+	} else if (r1 > -r2) {
+		if (r1 > r2) { cx = r1; cy = (ORC_PI/4.0f) * r2/r1; }
+		else { cx = r2; cy = (ORC_PI/4.0f) * (2.0f - r1/r2); }
+	} else {
+		if (r1 < r2) { cx = -r1; cy = (ORC_PI/4.0f) * (4.0f + r2/r1); }
+		else { cx = -r2; cy = (ORC_PI/4.0f) * (6.0f - r1/r2); }
+	}
+	out[0] = cx * orc_cosf(cy);
+	out[1] = cx * orc_sinf(cy);
 }
 
 /* util.cpp:602-611 */

@@ -355,6 +355,38 @@ static void luminaire_sample(const mtsgpu_scene *sc, int l, const float p[3], lr
 		} else {
 			lRec->pdf = 0;
 		}
+	} else if (sc->lum_type[l] == MTSGPU_LUM_POINT || sc->lum_type[l] == MTSGPU_LUM_SPOT) {
+		/* PointLuminaire::sample (point.cpp:55-63) / SpotLuminaire::sample (spot.cpp:110-118) */
+		float lumToP[3];
+		v3_sub(lumToP, p, P + 3);
+		float invDist = 1.0f / v3_length(lumToP);
+		lRec->p[0] = P[3]; lRec->p[1] = P[4]; lRec->p[2] = P[5];
+		v3_scale(lRec->d, lumToP, invDist);
+		lRec->n[0] = lRec->n[1] = lRec->n[2] = 0.0f;
+		lRec->pdf = 1.0f;
+		float result[3] = { P[0], P[1], P[2] };
+		if (sc->lum_type[l] == MTSGPU_LUM_SPOT) {
+			/* falloffCurve (spot.cpp:84-103), constant texture */
+			const float *M = P + 10;
+			const float *d = lRec->d;
+			const float cosTheta = M[6] * d[0] + M[7] * d[1] + M[8] * d[2];     /* m_worldToLuminaire(d).z */
+			if (cosTheta <= P[7]) {
+				result[0] = result[1] = result[2] = 0.0f;
+			} else if (!(cosTheta >= P[6])) {
+				float f = (P[8] - orc_acosf(cosTheta)) * P[9];
+				result[0] *= f; result[1] *= f; result[2] *= f;
+			}
+		}
+		float i2 = invDist*invDist;
+		lRec->value[0] = result[0] * i2; lRec->value[1] = result[1] * i2; lRec->value[2] = result[2] * i2;
+	} else if (sc->lum_type[l] == MTSGPU_LUM_DIRECTIONAL) {
+		/* DirectionalLuminaire::sample (directional.cpp:84-91) */
+		const float k = 2 * P[6];
+		lRec->p[0] = p[0] - P[3] * k; lRec->p[1] = p[1] - P[4] * k; lRec->p[2] = p[2] - P[5] * k;
+		lRec->d[0] = P[3]; lRec->d[1] = P[4]; lRec->d[2] = P[5];
+		lRec->n[0] = lRec->n[1] = lRec->n[2] = 0.0f;
+		lRec->pdf = 1.0f;
+		lRec->value[0] = P[0]; lRec->value[1] = P[1]; lRec->value[2] = P[2];
 	} else {
 		/* ConstantLuminaire::sample (constant.cpp:73-87) */
 		float d[3], nearHit, farHit, dv[3];
@@ -577,27 +609,121 @@ static void microfacet_sample(const float *P, const float wi[3], const float _sa
 	}
 }
 
-void orc_bsdf_f(uint32_t type, const float *P, const float wi[3], const float wo[3], float out[3]) {
+/* ---- Phong (src/bsdfs/phong.cpp:104-212); params after configure() ---- */
+#define ORC_INV_TWOPI 0.15915494309189533577f
+static void phong_f(const float *P, const float wi[3], const float wo[3], float out[3]) {
+	out[0] = out[1] = out[2] = 0.0f;
+	if (wi[2] <= 0 || wo[2] <= 0)
+		return;
+	const float R[3] = { -wi[0], -wi[1], wi[2] };
+	float alpha = v3_dot(R, wo);
+	float specRef;
+	if (alpha <= 0.0f)
+		specRef = 0.0f;
+	else
+		specRef = (P[0] + 2) * ORC_INV_TWOPI * orc_powf(alpha, P[0]) * P[2];
+	for (int i = 0; i < 3; ++i) out[i] += P[8+i] * specRef;
+	const float dk = ORC_INV_PI * P[1];
+	for (int i = 0; i < 3; ++i) out[i] += P[5+i] * dk;
+}
+static float phong_pdf_spec(const float *P, const float wi[3], const float wo[3]) {
+	const float R[3] = { -wi[0], -wi[1], wi[2] };
+	float alpha = v3_dot(R, wo);
+	float specPdf = orc_powf(alpha, P[0]) * (P[0] + 1.0f) / (2.0f * ORC_PI);
+	if (alpha <= 0)
+		specPdf = 0;
+	return specPdf;
+}
+static float phong_pdf(const float *P, const float wi[3], const float wo[3]) {
+	if (wo[2] <= 0 || wi[2] <= 0)
+		return 0.0f;
+	return P[3] * phong_pdf_spec(P, wi, wo) + P[4] * (wo[2] * ORC_INV_PI);
+}
+/* Phong::sample(bRec, sample): returns f / pdf */
+static void phong_sample(const float *P, const float wi[3], const float _sample[2], float wo[3], uint32_t *stype, float out[3]) {
+	float sample[2] = { _sample[0], _sample[1] };
+	out[0] = out[1] = out[2] = 0.0f;
+	if (wi[2] <= 0)
+		return;
+	if (sample[0] <= P[3]) {
+		sample[0] /= P[3];
+		/* sampleSpecular (:157-182) */
+		const float R[3] = { -wi[0], -wi[1], wi[2] };
+		float sinAlpha = sqrtf(1 - orc_powf(sample[1], 2 / (P[0] + 1)));
+		float cosAlpha = orc_powf(sample[1], 1 / (P[0] + 1));
+		float phi = (2.0f * ORC_PI) * sample[0];
+		float localDir[3] = { sinAlpha * orc_cosf(phi), sinAlpha * orc_sinf(phi), cosAlpha };
+		float fs[3], ft[3];
+		orc_coordinate_system(R, fs, ft);                         /* Frame(R).toWorld(localDir) */
+		for (int i = 0; i < 3; ++i) wo[i] = fs[i] * localDir[0] + ft[i] * localDir[1] + R[i] * localDir[2];
+		*stype = T_GLOSSY_REFL;
+		if (wo[2] <= 0)
+			return;
+		float pdfVal = phong_pdf(P, wi, wo);
+		if (pdfVal == 0)
+			return;
+		float f[3]; phong_f(P, wi, wo, f);
+		float recip = 1.0f / pdfVal;
+		out[0] = f[0] * recip; out[1] = f[1] * recip; out[2] = f[2] * recip;
+	} else {
+		sample[0] = (sample[0] - P[3]) / P[4];
+		orc_square_to_hemisphere_psa(sample, wo);                 /* sampleDiffuse (:188-193) */
+		*stype = T_DIFFUSE_REFL;
+		float f[3]; phong_f(P, wi, wo, f);
+		float recip = 1.0f / phong_pdf(P, wi, wo);
+		out[0] = f[0] * recip; out[1] = f[1] * recip; out[2] = f[2] * recip;
+	}
+}
+
+static void bsdf_f_base(uint32_t type, const float *P, const float wi[3], const float wo[3], float out[3]) {
 	switch (type) {
 		case MTSGPU_BSDF_LAMBERTIAN: lambertian_f(P, wi, wo, out); break;
 		case MTSGPU_BSDF_ROUGHMETAL: roughmetal_f(P, wi, wo, out); break;
 		case MTSGPU_BSDF_MICROFACET: microfacet_f(P, wi, wo, out); break;
-		default: out[0] = out[1] = out[2] = 0.0f; break;   /* dielectric.cpp:101-103 */
+		case MTSGPU_BSDF_PHONG: phong_f(P, wi, wo, out); break;
+		default: out[0] = out[1] = out[2] = 0.0f; break;   /* dielectric.cpp:101-103, mirror.cpp:60-62 */
 	}
 }
 
-float orc_bsdf_pdf(uint32_t type, const float *P, const float wi[3], const float wo[3]) {
+static float bsdf_pdf_base(uint32_t type, const float *P, const float wi[3], const float wo[3]) {
 	switch (type) {
 		case MTSGPU_BSDF_LAMBERTIAN: return lambertian_pdf(wi, wo);
 		case MTSGPU_BSDF_ROUGHMETAL: return roughmetal_pdf(P, wi, wo);
 		case MTSGPU_BSDF_MICROFACET: return microfacet_pdf(P, wi, wo);
-		default: return 0.0f;                              /* dielectric.cpp:105-107 */
+		case MTSGPU_BSDF_PHONG: return phong_pdf(P, wi, wo);
+		default: return 0.0f;                              /* dielectric.cpp:105-107, mirror.cpp:64-66 */
 	}
 }
 
-/* BSDF::sample(bRec, pdf, sample): value NOT divided by pdf */
+static void bsdf_sample_base(uint32_t type, const float *P, const float wi[3], const float s[2],
+                             float wo[3], float *pdf, uint32_t *stype, float out[3]);
+
+/* TwoSidedBRDF (src/bsdfs/twosided.cpp:80-130) wraps any of the above when MTSGPU_BSDF_TWOSIDED is set */
+void orc_bsdf_f(uint32_t type, const float *P, const float wi[3], const float wo[3], float out[3]) {
+	float a[3] = { wi[0], wi[1], wi[2] }, b[3] = { wo[0], wo[1], wo[2] };
+	if ((type & MTSGPU_BSDF_TWOSIDED) && a[2] < 0) { a[2] *= -1; b[2] *= -1; }
+	bsdf_f_base(type & 0xFFu, P, a, b, out);
+}
+
+float orc_bsdf_pdf(uint32_t type, const float *P, const float wi[3], const float wo[3]) {
+	float a[3] = { wi[0], wi[1], wi[2] }, b[3] = { wo[0], wo[1], wo[2] };
+	if ((type & MTSGPU_BSDF_TWOSIDED) && a[2] < 0) { a[2] *= -1; b[2] *= -1; }
+	return bsdf_pdf_base(type & 0xFFu, P, a, b);
+}
+
 void orc_bsdf_sample(uint32_t type, const float *P, const float wi[3], const float s[2],
                      float wo[3], float *pdf, uint32_t *stype, float out[3]) {
+	float a[3] = { wi[0], wi[1], wi[2] };
+	int flipped = 0;
+	if ((type & MTSGPU_BSDF_TWOSIDED) && a[2] < 0) { a[2] *= -1; flipped = 1; }
+	bsdf_sample_base(type & 0xFFu, P, a, s, wo, pdf, stype, out);
+	if (flipped && !spec_is_zero(out) && *pdf != 0)
+		wo[2] *= -1;
+}
+
+/* BSDF::sample(bRec, pdf, sample): value NOT divided by pdf */
+static void bsdf_sample_base(uint32_t type, const float *P, const float wi[3], const float s[2],
+                             float wo[3], float *pdf, uint32_t *stype, float out[3]) {
 	out[0] = out[1] = out[2] = 0.0f; *pdf = 0.0f; *stype = 0;
 	wo[0] = wo[1] = wo[2] = 0.0f;
 	switch (type) {
@@ -668,6 +794,24 @@ void orc_bsdf_sample(uint32_t type, const float *P, const float wi[3], const flo
 		microfacet_f(P, wi, wo, out);
 		return;
 	}
+	case MTSGPU_BSDF_MIRROR: {
+		/* mirror.cpp:77-86 */
+		wo[0] = -wi[0]; wo[1] = -wi[1]; wo[2] = wi[2];
+		*stype = T_DELTA_REFL;
+		*pdf = fabsf(wo[2]);
+		out[0] = P[0]; out[1] = P[1]; out[2] = P[2];
+		return;
+	}
+	case MTSGPU_BSDF_PHONG: {
+		/* BSDF::sample(bRec, pdf, sample) fallback (bsdf.cpp:37-48) over phong.cpp:195-212 */
+		float q[3];
+		phong_sample(P, wi, s, wo, stype, q);
+		if (spec_is_zero(q))
+			return;
+		*pdf = phong_pdf(P, wi, wo);
+		phong_f(P, wi, wo, out);
+		return;
+	}
 	default: return;
 	}
 }
@@ -724,7 +868,7 @@ static void sampler_next2d(sampler_t *s, float out[2]) {
 /* ========================================================================== */
 /* Camera (src/cameras/perspective.cpp:77-112)                                */
 /* ========================================================================== */
-static void camera_generate_ray(const mtsgpu_camera *cam, const float dirSample[2], ray_t *ray) {
+static void camera_generate_ray(const mtsgpu_camera *cam, const float dirSample[2], const float lensSample[2], ray_t *ray) {
 	const float (*m)[4] = (const float (*)[4]) cam->raster_to_camera;
 	const float (*w)[4] = (const float (*)[4]) cam->camera_to_world;
 	/* Transform::operator()(Point, Point&) (transform.h:133-149) on (x, y, 0) */
@@ -736,6 +880,18 @@ static void camera_generate_ray(const mtsgpu_camera *cam, const float dirSample[
 	float wv = m[3][0] * px + m[3][1] * py + m[3][2] * pz + m[3][3];
 	if (wv != 1.0f)
 		v3_div(ic, ic, wv);
+	float lo[3] = { 0, 0, 0 };
+	if (cam->aperture_radius > 0.0f) {
+		/* perspective.cpp:90-103: sample the aperture, aim at the focal plane */
+		float lensPos[2];
+		orc_square_to_disk_concentric(lensSample, lensPos);
+		lensPos[0] *= cam->aperture_radius; lensPos[1] *= cam->aperture_radius;
+		float tf = cam->focus_depth / ic[2];
+		float itsFocal[3] = { 0.0f + tf * ic[0], 0.0f + tf * ic[1], 0.0f + tf * ic[2] };
+		lo[0] += lensPos[0];
+		lo[1] += lensPos[1];
+		v3_sub(ic, itsFocal, lo);
+	}
 	float ld[3];
 	v3_normalize(ld, ic);
 	float invZ = 1.0f / ld[2];
@@ -743,10 +899,10 @@ static void camera_generate_ray(const mtsgpu_camera *cam, const float dirSample[
 	/* Transform::operator()(Ray, Ray&) (transform.h:219-235): o as point, d as vector */
 	float o[3], d[3];
 	for (int i = 0; i < 3; ++i) {
-		o[i] = w[i][0] * 0.0f + w[i][1] * 0.0f + w[i][2] * 0.0f + w[i][3];
+		o[i] = w[i][0] * lo[0] + w[i][1] * lo[1] + w[i][2] * lo[2] + w[i][3];
 		d[i] = w[i][0] * ld[0] + w[i][1] * ld[1] + w[i][2] * ld[2];
 	}
-	float wv2 = w[3][0] * 0.0f + w[3][1] * 0.0f + w[3][2] * 0.0f + w[3][3];
+	float wv2 = w[3][0] * lo[0] + w[3][1] * lo[1] + w[3][2] * lo[2] + w[3][3];
 	if (wv2 != 1.0f)
 		v3_div(o, o, wv2);
 	ray_init(ray, o, d);
@@ -823,8 +979,9 @@ static void path_li(const mtsgpu_scene *sc, const orc_render_params *prm, const 
 			bsdfVal[0] *= ac; bsdfVal[1] *= ac; bsdfVal[2] *= ac;
 			float woDotGeoN = v3_dot(its.geoN, wo);
 			if (!spec_is_zero(bsdfVal) && (!strictNormals || woDotGeoN * woL[2] > 0)) {
-				/* both luminaire plugins are intersectable or background */
-				float bsdfPdf = orc_bsdf_pdf(btype, BP, its.wi, woL);
+				/* Luminaire::isIntersectable() || isBackgroundLuminaire() (path.cpp:118-120): false for delta lights */
+				const uint32_t lt = sc->lum_type[lRec.lum];
+				float bsdfPdf = (lt == MTSGPU_LUM_AREA || lt == MTSGPU_LUM_CONSTANT) ? orc_bsdf_pdf(btype, BP, its.wi, woL) : 0;
 				const float weight = mi_weight(lRec.pdf, bsdfPdf);
 				for (int i = 0; i < 3; ++i)
 					Li[i] += pathThroughput[i] * lRec.value[i] * bsdfVal[i] * weight;
@@ -1008,11 +1165,12 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 					smp.kind = isLD ? 1 : 0;
 					smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 					smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm;
-					float sample[2];
+					float sample[2], lens[2] = { 0, 0 };
+					if (cam->aperture_radius > 0.0f) sampler_next2d(&smp, lens);     /* needsLensSample (integrator.cpp:156-157) */
 					sampler_next2d(&smp, sample);
 					sample[0] += x; sample[1] += y;
 					ray_t eyeRay;
-					camera_generate_ray(cam, sample, &eyeRay);
+					camera_generate_ray(cam, sample, lens, &eyeRay);
 					li_result res;
 					path_li(sc, prm, &eyeRay, &smp, &res, &st);
 					put_sample(film, W, H, &filter, sample[0], sample[1], res.Li, res.alpha);
@@ -1047,11 +1205,12 @@ void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_
 		smp.kind = isLD ? 1 : 0;
 		smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 		smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm;
-		float sample[2];
+		float sample[2], lens[2] = { 0, 0 };
+		if (cam->aperture_radius > 0.0f) sampler_next2d(&smp, lens);
 		sampler_next2d(&smp, sample);
 		sample[0] += x; sample[1] += y;
 		ray_t eyeRay;
-		camera_generate_ray(cam, sample, &eyeRay);
+		camera_generate_ray(cam, sample, lens, &eyeRay);
 		li_result res;
 		path_li(sc, prm, &eyeRay, &smp, &res, NULL);
 		float *o = out + 8 * (size_t) i;
@@ -1082,11 +1241,12 @@ void orc_render_rect_mt(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const 
 				smp.kind = kind == 1 ? 3 : 2;
 				smp.mt = &rnd;
 				smp.depth = depth; smp.spp = spp; smp.index = j; smp.t1d = t1d; smp.t2d = t2d;
-				float sample[2];
+				float sample[2], lens[2] = { 0, 0 };
+				if (cam->aperture_radius > 0.0f) sampler_next2d(&smp, lens);
 				sampler_next2d(&smp, sample);
 				sample[0] += x; sample[1] += y;
 				ray_t eyeRay;
-				camera_generate_ray(cam, sample, &eyeRay);
+				camera_generate_ray(cam, sample, lens, &eyeRay);
 				li_result res;
 				path_li(sc, prm, &eyeRay, &smp, &res, NULL);
 				put_sample(film, W, H, &filter, sample[0], sample[1], res.Li, res.alpha);
@@ -1178,11 +1338,12 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 					s.kind = isLD ? 1 : 0;
 					s.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 					s.depth = depth; s.spp = spp; s.index = j; s.scr = scr; s.perm = perm;
-					float sample[2];
+					float sample[2], lens[2] = { 0, 0 };
+					if (cam->aperture_radius > 0.0f) sampler_next2d(&s, lens);
 					sampler_next2d(&s, sample);
 					sample[0] += x0 + px; sample[1] += y0 + py;
 					ray_t eyeRay;
-					camera_generate_ray(cam, sample, &eyeRay);
+					camera_generate_ray(cam, sample, lens, &eyeRay);
 					li_result res;
 					path_li(sc, prm, &eyeRay, &s, &res, &st);
 					tsample_t *o = &smp[((size_t) py * w + px) * spp + j];

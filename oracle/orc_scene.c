@@ -200,6 +200,14 @@ int orc_flatten(const mtsgpu_scene_desc *d, const mtsgpu_kd_params *kdp, orc_fla
 			}
 			P[3] = bc[0]; P[4] = bc[1]; P[5] = bc[2]; P[6] = br;
 			background = (int32_t) l;
+		} else if (fs->lum_type[l] == MTSGPU_LUM_DIRECTIONAL) {
+			/* DirectionalLuminaire::preprocess (directional.cpp:65-72): m_diskRadius = scene bsphere radius */
+			P[6] = radius;
+		} else if (fs->lum_type[l] == MTSGPU_LUM_SPOT) {
+			/* SpotLuminaire::configure (spot.cpp:56-62): host libm, as the reference */
+			P[6] = cosf(P[19]);
+			P[7] = cosf(P[8]);
+			P[9] = 1.0f / (P[8] - P[19]);
 		}
 	}
 	/* Scene::initialize luminaire PDF (scene.cpp:320-330): weight 1.0 each */
@@ -375,5 +383,6 @@ int orc_make_camera(const float origin[3], const float target[3], const float up
 	memcpy(out->camera_to_world, c2w, sizeof(float) * 16);
 	out->near_clip = nearClip; out->far_clip = farClip;
 	out->width = width; out->height = height;
+	out->aperture_radius = 0.0f; out->focus_depth = farClip;    /* camera.cpp:164-166 defaults */
 	return 0;
 }

@@ -232,3 +232,59 @@ def test_bordered_tiles_and_gaussian_filter(mts, orc):
     size = np.zeros(2, dtype=np.float32); vals = np.zeros(256, dtype=np.float32)
     assert mts.lib().mtsgpu_tabulate_filter(1, 2.0, 0.5, mts.abi.ptr(size, mts.abi.f32p), mts.abi.ptr(vals, mts.abi.f32p)) == 0
     assert np.array_equal(vals.reshape(16, 16).view(np.uint32), tab.view(np.uint32)) and size[0] == 2.0
+
+
+def test_phong_chi_square_and_twosided(orc):
+    """phong is in the reference's own chi-square list (data/tests/test_bsdf.xml); twosided mirrors the lobe"""
+    import ctypes as C
+    P = np.zeros(16, dtype=np.float32)
+    # exponent 20, kd = ks = 1 (no renormalisation needed), rd .4, rs .3 -> sampling weights as Phong::configure
+    ssw = np.float32(0.3) / np.float32(0.7)
+    P[:11] = [20, 1, 1, ssw, np.float32(1) - ssw, .4, .4, .4, .3, .3, .3]
+    p, frac = _chi2_bsdf(orc, 5, P[:11], (0.4, 0.1, 0.85), n=40000)
+    assert frac > 0.9 and p > 0.005, p
+    L = orc.lib()
+    wi = np.array([0.3, -0.2, 0.8], dtype=np.float32); wi /= np.linalg.norm(wi)
+    wo = np.array([-0.1, 0.4, 0.7], dtype=np.float32); wo /= np.linalg.norm(wo)
+    f1 = np.zeros(3, dtype=np.float32); f2 = np.zeros(3, dtype=np.float32)
+    L.orc_bsdf_f(5 | 0x100, _p(P), _p(wi), _p(wo), _p(f1))
+    nwi, nwo = wi * np.float32([1, 1, -1]), wo * np.float32([1, 1, -1])
+    L.orc_bsdf_f(5 | 0x100, _p(P), _p(nwi), _p(nwo), _p(f2))
+    assert np.array_equal(f1, f2) and f1.max() > 0
+    L.orc_bsdf_f(5, _p(P), _p(nwi), _p(nwo), _p(f2))
+    assert f2.max() == 0                                            # one-sided without the adapter
+
+
+def test_pow_acos_disk_are_faithful(orc):
+    L = orc.lib()
+    import ctypes as C
+    L.orc_powf.argtypes = [C.c_float, C.c_float]; L.orc_powf.restype = C.c_float
+    L.orc_acosf.argtypes = [C.c_float]; L.orc_acosf.restype = C.c_float
+    rng = np.random.RandomState(2)
+    for x, y in zip(rng.rand(3000).astype(np.float32), (rng.rand(3000) * 40).astype(np.float32)):
+        got, exp = np.float32(L.orc_powf(float(x), float(y))), np.float32(np.float64(x) ** np.float64(y))
+        assert abs(np.float64(got) - np.float64(exp)) <= np.spacing(np.abs(exp)) or exp < 1e-37
+    assert L.orc_powf(0.0, 3.0) == 0 and L.orc_powf(5.0, 0.0) == 1
+    for x in np.concatenate([rng.rand(2000) * 2 - 1, [1.0, -1.0, 0.0]]).astype(np.float32):
+        got, exp = np.float32(L.orc_acosf(float(x))), np.float32(np.arccos(np.float64(x)))
+        assert abs(np.float64(got) - np.float64(exp)) <= 2 * np.spacing(np.abs(exp)) + 1e-30
+    out = np.zeros(2, dtype=np.float32)
+    for s in rng.rand(500, 2).astype(np.float32):
+        L.orc_square_to_disk_concentric(_p(np.ascontiguousarray(s)), _p(out))
+        assert out[0] ** 2 + out[1] ** 2 <= 1 + 1e-6
+
+
+def test_point_light_direct_illumination_is_analytic(mts, orc):
+    """one delta luminaire, maxDepth 2: Li = rho/pi * I/d^2 * cos(theta) (point.cpp:55-63, weight 1 for delta lights)"""
+    sd = mts.scenes.SceneDescription("floor")
+    pos, tri = mts.scenes._quad((-5, 0, -5), (10, 0, 0), (0, 0, 10), (0, 1, 0))
+    sd.add_mesh(pos, tri, bsdf=sd.lambertian(0.5), face_normals=True)
+    sd.point_light((0.0, 2.0, 0.0), 10.0)
+    sd.camera = dict(origin=(0.0, 3.0, 0.001), target=(0.0, 0.0, 0.0), up=(0.0, 0.0, -1.0), fov=30.0)
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 33, 33)
+    f, _ = orc.render(fs.scene, cam, orc.render_params(2, spp=4))
+    img = orc.develop(f)
+    centre = img[16, 16, 0]
+    assert abs(centre - 0.5 / np.pi * 10.0 / 4.0) < 2e-3            # straight below the light: d = 2, cos = 1
+    assert img[0, 0, 0] < centre
