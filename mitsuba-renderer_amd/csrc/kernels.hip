@@ -299,6 +299,9 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 			while (true) {
 				uint2 nd = sc.nodes[cur];
 				while (!(nd.x & 0x80000000u)) {
+					// One step of rayIntersectHavran's inner loop (sahkdtree3.h:196-252), written without
+					// branches: this loop is bound by instruction issue (exec-mask bookkeeping of a branchy
+					// version costs more than the arithmetic), not by memory.
 					const float split = __uint_as_float(nd.y);
 					const int axis = (int) (nd.x & 3u);
 					const uint32_t left = cur + ((nd.x & 0x3FFFFFFCu) >> 2);
@@ -307,24 +310,28 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 					// stack[].p[axis]: ray(t) with the pushed axis overwritten by its split (sahkdtree3.h:248-249)
 					const float pen = (axis == en_axis) ? en_split : (oa + en_t * da);
 					const float pex = (axis == ex_axis) ? ex_split : (oa + ex_t * da);
-					uint32_t farRight;
-					if (pen <= split) {
-						if (pex <= split) { cur = left; nd = sc.nodes[cur]; continue; }         // N1-N3, P5, Z2, Z3
-						if (pen == split) { cur = left + 1; nd = sc.nodes[cur]; continue; }     // Z1
-						farRight = 1u;                                                          // N4
-					} else {
-						if (split < pex) { cur = left + 1; nd = sc.nodes[cur]; continue; }      // P1-P3, N5
-						farRight = 0u;                                                          // P4
+					const bool A = pen <= split, B = pex <= split, C = pen == split, D = split < pex;
+					//   A &&  B        : left only            (N1-N3, P5, Z2, Z3)
+					//   A && !B &&  C  : right only           (Z1)
+					//   A && !B && !C  : near left, far right (N4)  -> push
+					//  !A &&  D        : right only           (P1-P3, N5)
+					//  !A && !D        : near right, far left (P4)  -> push
+					const uint32_t side = A ? ((!B && C) ? 1u : 0u) : 1u;
+					const bool push = A ? (!B && !C) : !D;
+					if (push) {
+						// push the current exit point's reference; (cur, far child) becomes the exit point
+						if (sp < kStackLDS) s_stack[sp][tid] = ex_ref;
+						else q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref;
 					}
+					const uint32_t farRight = A ? 1u : 0u;
 					const float distToSplit = (split - oa) * sel3(rx, ry, rz, axis);
-					// push the current exit point's reference, make (cur, far) the new exit point
-					if (sp < kStackLDS) s_stack[sp][tid] = ex_ref;
-					else q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref;
-					++sp;
-					ex_ref = (cur << 1) | farRight;
-					ex_t = distToSplit; ex_axis = axis; ex_split = split;
-					ex_node = left + farRight;
-					cur = left + (1u - farRight);
+					sp += push ? 1 : 0;
+					ex_ref = push ? ((cur << 1) | farRight) : ex_ref;
+					ex_t = push ? distToSplit : ex_t;
+					ex_axis = push ? axis : ex_axis;
+					ex_split = push ? split : ex_split;
+					ex_node = push ? (left + farRight) : ex_node;
+					cur = left + side;
 					nd = sc.nodes[cur];
 				}
 
