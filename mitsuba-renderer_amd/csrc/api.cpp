@@ -400,13 +400,14 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 			}
 		}
 		const uint32_t total = std::max<uint32_t>(pos, 2u);
+		if (total >= (1u << 29)) return fail(c, MTSGPU_EINVAL, "kd-tree too large");
 		std::vector<uint32_t> dev(2 * (size_t) total, 0u);
 		dev[2] = 0x80000000u; dev[3] = 0u;           // padding slot: empty leaf, never referenced
 		for (uint32_t i = 0; i < N; ++i) {
 			const uint32_t a = sc->kd_nodes[2 * (size_t) i], b = sc->kd_nodes[2 * (size_t) i + 1];
 			uint32_t *o = &dev[2 * (size_t) newIndex[i]];
 			if (a & 0x80000000u) { o[0] = a; o[1] = b; }
-			else { o[0] = (a & 3u) | ((newIndex[leftOf(i)] - newIndex[i]) << 2); o[1] = b; }
+			else { o[0] = (a & 3u) | (newIndex[leftOf(i)] << 2); o[1] = b; }     // absolute left-child index (< 2^29)
 		}
 		rc |= upload(c, (const uint32_t **) &d.nodes, dev.data(), dev.size());
 	}

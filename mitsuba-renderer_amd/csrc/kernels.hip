@@ -235,8 +235,8 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 		uint32_t id = 0;
 		float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, rx = 1, ry = 1, rz = 1;
 		float mint = 0, maxt = 0, tmax0 = 0;
-		float en_t = 0, en_split = 0, ex_t = 0, ex_split = 0;
-		int en_axis = 3, ex_axis = 3, sp = 0;
+		float enx = 0, eny = 0, enz = 0, exx = 0, exy = 0, exz = 0, ex_t = 0;   // stack[enPt].p, stack[exPt].p, stack[exPt].t
+		int sp = 0;
 		uint32_t ex_node = kNullNode, ex_ref = kSentinel, cur = 0;
 		float best_t = MG_INF, best_u = 0, best_v = 0;
 		uint32_t best_prim = kNoPrim, best_shape = 0;
@@ -286,9 +286,10 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 				#pragma unroll
 				for (int i = 0; i < 8; ++i) s_mbox[i][tid] = 0xFFFFFFFFu;
 				// entry point (stack[enPt]) and current exit point (stack[exPt]) in registers
-				en_t = mint; en_split = 0.0f; en_axis = 3;
+				enx = ox + mint * dx; eny = oy + mint * dy; enz = oz + mint * dz;      // stack[enPt].p = ray(mint)
 				tmax0 = maxt;
-				ex_t = maxt; ex_split = 0.0f; ex_axis = 3; ex_node = kNullNode; ex_ref = kSentinel;
+				ex_t = maxt; exx = ox + maxt * dx; exy = oy + maxt * dy; exz = oz + maxt * dz;
+				ex_node = kNullNode; ex_ref = kSentinel;
 				sp = 0; cur = 0;
 				has = true;
 			}
@@ -301,36 +302,38 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 				while (!(nd.x & 0x80000000u)) {
 					// One step of rayIntersectHavran's inner loop (sahkdtree3.h:196-252), written without
 					// branches: this loop is bound by instruction issue (exec-mask bookkeeping of a branchy
-					// version costs more than the arithmetic), not by memory.
+					// version costs more than the arithmetic), not by memory.  The entry / exit points are
+					// kept as the 3-vectors the reference stores (ray(t) with the split axis overwritten).
 					const float split = __uint_as_float(nd.y);
 					const int axis = (int) (nd.x & 3u);
-					const uint32_t left = cur + ((nd.x & 0x3FFFFFFCu) >> 2);
+					const uint32_t left = nd.x >> 2;            // device nodes hold the absolute index of the left child
 					if (COUNT) c_inner++;
-					const float oa = sel3(ox, oy, oz, axis), da = sel3(dx, dy, dz, axis);
-					// stack[].p[axis]: ray(t) with the pushed axis overwritten by its split (sahkdtree3.h:248-249)
-					const float pen = (axis == en_axis) ? en_split : (oa + en_t * da);
-					const float pex = (axis == ex_axis) ? ex_split : (oa + ex_t * da);
+					const float pen = sel3(enx, eny, enz, axis), pex = sel3(exx, exy, exz, axis);
 					const bool A = pen <= split, B = pex <= split, C = pen == split, D = split < pex;
 					//   A &&  B        : left only            (N1-N3, P5, Z2, Z3)
 					//   A && !B &&  C  : right only           (Z1)
 					//   A && !B && !C  : near left, far right (N4)  -> push
 					//  !A &&  D        : right only           (P1-P3, N5)
 					//  !A && !D        : near right, far left (P4)  -> push
-					const uint32_t side = A ? ((!B && C) ? 1u : 0u) : 1u;
-					const bool push = A ? (!B && !C) : !D;
+					// the case logic is done on wave masks (SALU) to keep it off the vector pipe
+					const uint64_t mA = __builtin_amdgcn_ballot_w64(A), mB = __builtin_amdgcn_ballot_w64(B);
+					const uint64_t mC = __builtin_amdgcn_ballot_w64(C), mD = __builtin_amdgcn_ballot_w64(D);
+					const bool side1 = __builtin_amdgcn_inverse_ballot_w64(~mA | (~mB & mC));   // go to the right child now
+					const bool push = __builtin_amdgcn_inverse_ballot_w64((mA & ~mB & ~mC) | (~mA & ~mD));
+					const uint32_t side = side1 ? 1u : 0u;
 					if (push) {
 						// push the current exit point's reference; (cur, far child) becomes the exit point
 						if (sp < kStackLDS) s_stack[sp][tid] = ex_ref;
 						else q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref;
+						++sp;
+						const uint32_t farRight = A ? 1u : 0u;
+						const float distToSplit = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
+						ex_ref = (cur << 1) | farRight;
+						ex_t = distToSplit;
+						exx = ox + distToSplit * dx; exy = oy + distToSplit * dy; exz = oz + distToSplit * dz;
+						if (axis == 0) exx = split; else if (axis == 1) exy = split; else exz = split;
+						ex_node = left + farRight;
 					}
-					const uint32_t farRight = A ? 1u : 0u;
-					const float distToSplit = (split - oa) * sel3(rx, ry, rz, axis);
-					sp += push ? 1 : 0;
-					ex_ref = push ? ((cur << 1) | farRight) : ex_ref;
-					ex_t = push ? distToSplit : ex_t;
-					ex_axis = push ? axis : ex_axis;
-					ex_split = push ? split : ex_split;
-					ex_node = push ? (left + farRight) : ex_node;
 					cur = left + side;
 					nd = sc.nodes[cur];
 				}
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 				else if (ex_t > maxt) finished = true;
 				else {
 					// --- pop: the exit point becomes the entry point ---
-					en_t = ex_t; en_axis = ex_axis; en_split = ex_split;
+					enx = exx; eny = exy; enz = exz;
 					cur = ex_node;
 					if (cur == kNullNode) {
 						finished = true;
@@ -402,15 +405,18 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 						const uint32_t ref = (sp < kStackLDS) ? s_stack[sp][tid]
 						                                      : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
 						if (ref == kSentinel) {
-							ex_t = tmax0; ex_axis = 3; ex_split = 0.0f; ex_node = kNullNode; ex_ref = kSentinel;
+							ex_t = tmax0; exx = ox + tmax0 * dx; exy = oy + tmax0 * dy; exz = oz + tmax0 * dz;
+							ex_node = kNullNode; ex_ref = kSentinel;
 						} else {
 							const uint32_t parent = ref >> 1;
 							const uint2 pn = sc.nodes[parent];
 							const int axis = (int) (pn.x & 3u);
 							const float split = __uint_as_float(pn.y);
-							ex_node = parent + ((pn.x & 0x3FFFFFFCu) >> 2) + (ref & 1u);
+							ex_node = (pn.x >> 2) + (ref & 1u);
 							ex_t = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
-							ex_axis = axis; ex_split = split; ex_ref = ref;
+							exx = ox + ex_t * dx; exy = oy + ex_t * dy; exz = oz + ex_t * dz;
+							if (axis == 0) exx = split; else if (axis == 1) exy = split; else exz = split;
+							ex_ref = ref;
 						}
 					}
 				}
