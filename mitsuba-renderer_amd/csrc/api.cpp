@@ -117,11 +117,17 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	rc |= devAlloc(c, &c->queueA, cap, o); rc |= devAlloc(c, &c->queueB, cap, o);
 	rc |= devAlloc(c, &c->q.shadow, cap, o);
 	rc |= devAlloc(c, &c->q.counters, kNumCounters * kCounterStride, o);
-	rc |= devAlloc(c, &c->q.trace_counts, 4, o);
+	rc |= devAlloc(c, &c->q.trace_counts, 8, o);
 	rc |= devAlloc(c, &c->q.spill, (size_t) kTraceGridBlocks * kTraceBlock * trace_spill_levels(), o);
 	if (rc) return rc;
 	c->q.spill_stride = kTraceGridBlocks * kTraceBlock;
-	HIPCHK(c, hipMemset(c->q.trace_counts, 0, 4 * sizeof(unsigned long long)));
+	c->q.refill_min = 32;
+	c->q.desc_min = 8;
+	c->q.leaf_min = 8;
+	if (const char *e = getenv("MTSGPU_LEAFMIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->q.leaf_min = (uint32_t) v; }
+	if (const char *e = getenv("MTSGPU_DESCMIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->q.desc_min = (uint32_t) v; }
+	if (const char *e = getenv("MTSGPU_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) c->q.refill_min = (uint32_t) v; }
+	HIPCHK(c, hipMemset(c->q.trace_counts, 0, 8 * sizeof(unsigned long long)));
 	c->pathCap = cap;
 	return 0;
 }
@@ -246,9 +252,13 @@ void collectTimings(mtsgpu_ctx *c) {
 }
 
 int fetchTraceCounts(mtsgpu_ctx *c) {
-	unsigned long long h[4];
+	unsigned long long h[8];
 	HIPCHK(c, hipMemcpy(h, c->q.trace_counts, sizeof(h), hipMemcpyDeviceToHost));
 	c->stats.n_inner = h[0]; c->stats.n_leaf = h[1]; c->stats.n_idx = h[2]; c->stats.n_tri_tested = h[3];
+	if (getenv("MTSGPU_DEBUG"))     // SIMD utilisation of the traversal loops: lane steps / lane slots issued
+		fprintf(stderr, "[mtsgpu] lanes: inner %llu/%llu (%.3f)  leaf-prims %llu/%llu (%.3f)  outer %llu/%llu (%.3f)  batch slots %llu\n",
+		        h[0], h[4], h[4] ? (double) h[0] / h[4] : 0.0, h[2], h[5], h[5] ? (double) h[2] / h[5] : 0.0,
+		        h[1], h[6], h[6] ? (double) h[1] / h[6] : 0.0, h[7]);
 	return 0;
 }
 
@@ -592,7 +602,7 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 		rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, slotsPerPass * 3 * c->ldDepth); if (rc) return rc;
 		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, slotsPerPass * 2 * c->ldDepth * spp); if (rc) return rc;
 	}
-	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 4 * sizeof(unsigned long long), c->stream));
+	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 8 * sizeof(unsigned long long), c->stream));
 	const DConfig cfg = makeConfig(c, false);
 	const size_t fullBlock = (size_t) (bs + 2 * c->filtBorder) * (bs + 2 * c->filtBorder) * 5;
 	if (wideFilter) {
@@ -684,7 +694,7 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 	}
 	launch_iota(c->stream, c->queueA, n);
-	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 4 * sizeof(unsigned long long), c->stream));
+	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 8 * sizeof(unsigned long long), c->stream));
 	hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
 	if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
 	launch_trace(c->stream, shadow ? 2 : 0, c->countTraversal, false, c->dsc, c->paths, c->q, c->queueA, n);

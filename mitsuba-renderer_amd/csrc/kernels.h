@@ -96,9 +96,12 @@ struct DQueues {
 	uint32_t *next;               // paths that continue (input of the next closest-hit launch)
 	uint32_t *shadow;             // paths with a pending shadow ray
 	uint32_t *counters;           // [i * kCounterStride]: i = b * kBinShards + shard for the bins, then next, shadow
-	unsigned long long *trace_counts;  // n_inner, n_leaf, n_idx, n_tri_tested (u64 x 4)
+	unsigned long long *trace_counts;  // n_inner, n_leaf, n_idx, n_tri_tested + lane slots of the three loops and batches (u64 x 8)
 	uint32_t *spill;              // traversal stack overflow: [level][thread]
 	uint32_t spill_stride;
+	uint32_t desc_min;                 // k_trace leaves its descent loop when fewer lanes than this are on inner nodes (>= 1)
+	uint32_t leaf_min;                 // ... and its primitive loop when fewer lanes than this have leaf entries left (>= 1)
+	uint32_t refill_min;               // k_trace refills its idle lanes once this many are idle (1..64)
 };
 
 // --- launchers (kernels.hip) -------------------------------------------------

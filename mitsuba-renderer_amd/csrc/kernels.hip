@@ -210,11 +210,14 @@ constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 
 size_t trace_spill_levels() { return kSpillLevels; }
 
-// Persistent waves: the grid is sized to fill the chip once and every wave walks the queue in
-// 64-ray batches with a fixed stride (no work-queue atomic: a single head word saturates at
-// ~88 fetches/us, MI355X_MICROARCH.md "dequeue").  64 consecutive queue entries per wave keep the
-// coherence of neighbouring camera samples; a measured alternative that refilled idle lanes
-// mid-batch lost 45 % to the coherence it destroys.
+// Persistent waves: the grid is sized to fill the chip once and every wave walks its own 64-ray
+// batches of the queue with a private cursor (no work-queue atomic: a single head word saturates at
+// ~88 fetches/us, MI355X_MICROARCH.md "dequeue").  The kernel is bound by instruction issue under
+// SIMD divergence (measured lane utilisation in DESIGN.md section 6), which three scheduling rules
+// attack: idle lanes are refilled from the wave's next batch once q.refill_min of them are idle, and
+// the descent / primitive loops are left as soon as fewer than q.desc_min / q.leaf_min lanes still
+// need them (the others stop waiting; stragglers resume in the next round).  None of this changes
+// what is computed for a ray.
 template <int MODE, bool COUNT, bool BIN>
 __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, DQueues q,
                                                           const uint32_t *queue, uint32_t n) {
@@ -227,79 +230,160 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 	const uint32_t shard = blockIdx.x % kBinShards;     // contention on a bin counter is spread over kBinShards words
 
 	uint32_t c_inner = 0, c_leaf = 0, c_idx = 0, c_tri = 0;
+	uint32_t w_inner = 0, w_leaf = 0, w_outer = 0, w_batch = 0;   // COUNT: lane slots issued per loop (64 per wave iteration)
+#define MG_WSLOT(w) do { if (COUNT && lane == (uint32_t) __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) (w) += 64u; } while (0)
 
-	// each wave owns the batches (64 consecutive queue entries) wave_id, wave_id + n_waves, ...
-	for (uint32_t batch = blockIdx.x * kTraceBlock + (tid & ~63u); batch < n; batch += stride) {
-		const uint32_t my = batch + lane;
-		const bool active = my < n;
-		uint32_t id = 0;
-		float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, rx = 1, ry = 1, rz = 1;
-		float mint = 0, maxt = 0, tmax0 = 0;
-		float enx = 0, eny = 0, enz = 0, exx = 0, exy = 0, exz = 0, ex_t = 0;   // stack[enPt].p, stack[exPt].p, stack[exPt].t
-		int sp = 0;
-		uint32_t ex_node = kNullNode, ex_ref = kSentinel, cur = 0;
-		float best_t = MG_INF, best_u = 0, best_v = 0;
-		uint32_t best_prim = kNoPrim, best_shape = 0;
-		bool found = false, has = false;
+	// Each wave owns the batches (64 consecutive queue entries) wave_id, wave_id + n_waves, ... and walks
+	// them with a private cursor (no work-queue atomic).  A lane whose ray has finished stays idle until
+	// at least q.refill_min lanes of the wave are idle; then the finished rays are retired together (one
+	// hit store + one binning step) and the idle lanes take the next rays of the wave's own batches.
+	const uint32_t first = blockIdx.x * kTraceBlock + (tid & ~63u);
+	uint32_t total = 0;                     // rays owned by this wave (uniform)
+	if (first < n) {
+		const uint32_t nb = (n - first - 1u) / stride + 1u;
+		const uint32_t lastBase = first + (nb - 1u) * stride;
+		total = (nb - 1u) * 64u + (n - lastBase < 64u ? n - lastBase : 64u);
+	}
+	uint32_t cursor = 0;                    // next unowned ray of the wave (uniform)
+	const uint32_t refill_min = q.refill_min, desc_min = q.desc_min, leaf_min = q.leaf_min;
 
-		if (active) {
-			id = queue[my];
-			float4 a, b;
-			float rmint, rmaxt;
-			if (MODE == 1) {
-				a = ps.sh_o(id); b = ps.sh_d(id);
-				rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
-			} else {
-				a = ps.ray_o(id); b = ps.ray_d(id);
-				rmint = a.w; rmaxt = b.w;
-			}
-			ox = a.x; oy = a.y; oz = a.z; dx = b.x; dy = b.y; dz = b.z;
-			rx = 1.0f / dx; ry = 1.0f / dy; rz = 1.0f / dz;          // Ray::dRcp (ray.h:63-74)
-			// AABB::rayIntersect (aabb.h:349-382) + adaptive epsilon (skdtree.cpp:114-122)
-			bool go = true;
-			mint = -MG_INF; maxt = MG_INF;
-			#pragma unroll
-			for (int i = 0; i < 3; ++i) {
-				const float direction = sel3(dx, dy, dz, i), origin = sel3(ox, oy, oz, i);
-				const float minVal = sc.aabb_min[i], maxVal = sc.aabb_max[i];
-				if (direction == 0) {
-					if (origin < minVal || origin > maxVal) go = false;
-				} else {
-					const float rc = sel3(rx, ry, rz, i);
-					float t1 = (minVal - origin) * rc, t2 = (maxVal - origin) * rc;
-					if (t1 > t2) { const float tmp = t1; t1 = t2; t2 = tmp; }
-					mint = smax(mint, t1);
-					maxt = smin(maxt, t2);
-					if (mint > maxt) go = false;
+	uint32_t id = 0;
+	float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, rx = 1, ry = 1, rz = 1;
+	float mint = 0, maxt = 0, tmax0 = 0;
+	float enx = 0, eny = 0, enz = 0, exx = 0, exy = 0, exz = 0, ex_t = 0;   // stack[enPt].p, stack[exPt].p, stack[exPt].t
+	int sp = 0;
+	uint32_t ex_node = kNullNode, ex_ref = kSentinel, cur = 0;
+	float best_t = MG_INF, best_u = 0, best_v = 0;
+	uint32_t best_prim = kNoPrim, best_shape = 0;
+	uint32_t e_cont = kNoPrim;              // position inside an interrupted leaf
+	bool found = false;
+	bool has = false;                       // this lane is traversing a ray
+	bool done = false;                      // this lane holds a finished ray that has not been retired yet
+
+	while (true) {
+		const uint64_t liveMask = __builtin_amdgcn_ballot_w64(has);
+		const uint32_t nlive = (uint32_t) __popcll(liveMask);
+		const uint32_t remaining = total - cursor;
+		if (nlive == 0u || (remaining != 0u && 64u - nlive >= refill_min)) {
+			// ---- retire the finished rays (all lanes take part in the ballots) ----
+			if (MODE == 0) {
+				int bin = -1;
+				if (done) {
+					ps.hit(id) = make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim);
+					if (BIN) {
+						bin = kNumBins - 1;
+						if (found) {
+							const int b = sc.shape_bsdf[sc.leaf_ta[3 * (size_t) best_shape + 2].z];   // shape of the hit record
+							if (b >= 0) bin = (int) (sc.bsdf_type[b] & 0xFFu);
+						}
+					}
 				}
+				if (BIN) {
+					// material sort: one ballot + prefix popcount per bin; lane b reserves the slots of bin b,
+					// so the wave issues ONE returning atomic instruction for all bins
+					uint32_t cnt = 0, rank = 0;
+					#pragma unroll
+					for (int b = 0; b < kNumBins; ++b) {
+						const uint64_t m = __builtin_amdgcn_ballot_w64(bin == b);
+						if (lane == (uint32_t) b) cnt = (uint32_t) __popcll(m);
+						if (bin == b) rank = (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+					}
+					uint32_t base = 0;
+					if (lane < (uint32_t) kNumBins && cnt != 0u)
+						base = atomicAdd(&q.counters[(lane * kBinShards + shard) * kCounterStride], cnt);
+					base = __shfl(base, bin < 0 ? 0 : bin);
+					#pragma unroll
+					for (int b = 0; b < kNumBins; ++b)
+						if (bin == b) q.bins[b][(size_t) shard * q.bin_seg_cap + base + rank] = id;
+				}
+			} else if (MODE == 1) {
+				// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
+				if (done && !found) {
+					float4 L = ps.Li(id);
+					const float4 c = ps.nee(id);
+					L.x += c.x; L.y += c.y; L.z += c.z;
+					ps.Li(id) = L;
+				}
+			} else {
+				if (done)
+					ps.hit(id) = make_uint4(0u, 0u, 0u, found ? 1u : 0u);
 			}
-			float rayMinT = rmint;
-			if (rayMinT == kEpsilon) {
-				float m = smax(smax(fabsf(ox), fabsf(oy)), fabsf(oz));
-				if (MODE == 0) m = smax(m, kEpsilon);    // only the (ray, its) variant has the inner max
-				rayMinT *= m;
-			}
-			if (rayMinT > mint) mint = rayMinT;
-			if (rmaxt < maxt) maxt = rmaxt;
-			if (!(maxt > mint)) go = false;
-			if (go) {
+			done = false;
+			if (remaining == 0u)
+				break;          // nlive == 0 and nothing left: the wave is finished
+
+			// ---- refill: idle lane number r takes ray cursor + r ----
+			const uint32_t r = (uint32_t) __popcll(~liveMask & ((1ull << lane) - 1ull));
+			const uint32_t j = cursor + r;
+			const bool take = !has && j < total;
+			cursor += (64u - nlive < remaining) ? 64u - nlive : remaining;
+			MG_WSLOT(w_batch);
+			if (take) {
+				const uint32_t my = first + (j >> 6) * stride + (j & 63u);
+				id = queue[my];
+				float4 a, b;
+				float rmint, rmaxt;
+				if (MODE == 1) {
+					a = ps.sh_o(id); b = ps.sh_d(id);
+					rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
+				} else {
+					a = ps.ray_o(id); b = ps.ray_d(id);
+					rmint = a.w; rmaxt = b.w;
+				}
+				ox = a.x; oy = a.y; oz = a.z; dx = b.x; dy = b.y; dz = b.z;
+				rx = 1.0f / dx; ry = 1.0f / dy; rz = 1.0f / dz;          // Ray::dRcp (ray.h:63-74)
+				// AABB::rayIntersect (aabb.h:349-382) + adaptive epsilon (skdtree.cpp:114-122)
+				bool go = true;
+				mint = -MG_INF; maxt = MG_INF;
 				#pragma unroll
-				for (int i = 0; i < 8; ++i) s_mbox[i][tid] = 0xFFFFFFFFu;
-				// entry point (stack[enPt]) and current exit point (stack[exPt]) in registers
-				enx = ox + mint * dx; eny = oy + mint * dy; enz = oz + mint * dz;      // stack[enPt].p = ray(mint)
-				tmax0 = maxt;
-				ex_t = maxt; exx = ox + maxt * dx; exy = oy + maxt * dy; exz = oz + maxt * dz;
-				ex_node = kNullNode; ex_ref = kSentinel;
-				sp = 0; cur = 0;
-				has = true;
+				for (int i = 0; i < 3; ++i) {
+					const float direction = sel3(dx, dy, dz, i), origin = sel3(ox, oy, oz, i);
+					const float minVal = sc.aabb_min[i], maxVal = sc.aabb_max[i];
+					if (direction == 0) {
+						if (origin < minVal || origin > maxVal) go = false;
+					} else {
+						const float rc = sel3(rx, ry, rz, i);
+						float t1 = (minVal - origin) * rc, t2 = (maxVal - origin) * rc;
+						if (t1 > t2) { const float tmp = t1; t1 = t2; t2 = tmp; }
+						mint = smax(mint, t1);
+						maxt = smin(maxt, t2);
+						if (mint > maxt) go = false;
+					}
+				}
+				float rayMinT = rmint;
+				if (rayMinT == kEpsilon) {
+					float m = smax(smax(fabsf(ox), fabsf(oy)), fabsf(oz));
+					if (MODE == 0) m = smax(m, kEpsilon);    // only the (ray, its) variant has the inner max
+					rayMinT *= m;
+				}
+				if (rayMinT > mint) mint = rayMinT;
+				if (rmaxt < maxt) maxt = rmaxt;
+				if (!(maxt > mint)) go = false;
+				best_t = MG_INF; best_u = 0; best_v = 0; best_prim = kNoPrim; best_shape = 0;
+				found = false;
+				done = !go;       // a ray that misses the scene's box is finished at once
+				has = go;
+				if (go) {
+					#pragma unroll
+					for (int i = 0; i < 8; ++i) s_mbox[i][tid] = 0xFFFFFFFFu;
+					// entry point (stack[enPt]) and current exit point (stack[exPt]) in registers
+					enx = ox + mint * dx; eny = oy + mint * dy; enz = oz + mint * dz;      // stack[enPt].p = ray(mint)
+					tmax0 = maxt;
+					ex_t = maxt; exx = ox + maxt * dx; exy = oy + maxt * dy; exz = oz + maxt * dz;
+					ex_node = kNullNode; ex_ref = kSentinel;
+					sp = 0; cur = 0; e_cont = kNoPrim;
+				}
 			}
 		}
 
-		// ---- traverse ----
+		// ---- one leaf visit of every live lane: descend, test the leaf, pop ----
 		if (has) {
-			while (true) {
+			{
 				uint2 nd = sc.nodes[cur];
-				while (!(nd.x & 0x80000000u)) {
+				bool inner = !(nd.x & 0x80000000u);
+				// The descent stops as soon as fewer than q.desc_min lanes are still on inner nodes: the lanes
+				// that wait in a leaf go on, the few stragglers resume their descent in the next round.
+				do { if (inner) {
 					// One step of rayIntersectHavran's inner loop (sahkdtree3.h:196-252), written without
 					// branches: this loop is bound by instruction issue (exec-mask bookkeeping of a branchy
 					// version costs more than the arithmetic), not by memory.  The entry / exit points are
@@ -308,6 +392,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 					const int axis = (int) (nd.x & 3u);
 					const uint32_t left = nd.x >> 2;            // device nodes hold the absolute index of the left child
 					if (COUNT) c_inner++;
+					MG_WSLOT(w_inner);
 					const float pen = sel3(enx, eny, enz, axis), pex = sel3(exx, exy, exz, axis);
 					const bool A = pen <= split, B = pex <= split, C = pen == split, D = split < pex;
 					//   A &&  B        : left only            (N1-N3, P5, Z2, Z3)
@@ -336,24 +421,31 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 					}
 					cur = left + side;
 					nd = sc.nodes[cur];
-				}
+					inner = !(nd.x & 0x80000000u);
+				} } while ((uint32_t) __popcll(__builtin_amdgcn_ballot_w64(inner)) >= desc_min);
 
+				if (!inner) {
 				// --- leaf: test the primitives (sahkdtree3.h:262-288, skdtree.h:244-336) ---
-				if (COUNT) c_leaf++;
-				bool hitShadow = false;
+				if (COUNT && e_cont == kNoPrim) c_leaf++;      // a resumed leaf was counted already
+				MG_WSLOT(w_outer);
+				bool hitShadow = false, more = false;
 				{
-					uint32_t e = nd.x & 0x7FFFFFFFu;
+					uint32_t e = (e_cont != kNoPrim) ? e_cont : (nd.x & 0x7FFFFFFFu);     // resume an interrupted leaf
 					const uint32_t last = nd.y;
 					// record = 3 x 16 B: A = (k<<30 | non-occluder<<29 | prim, n_u, n_v, n_d), B = (a_u, a_v, b_nu, b_nv),
 					// C = (c_nu, c_nv, shape, -).  A alone decides the mailbox test and the plane distance t; B and C
 					// are only fetched for primitives whose t lies inside [mint, maxt] (triaccel.h:141-149).
 					uint4 A;
-					if (e != last) A = sc.leaf_ta[3 * (size_t) e];
-					while (e != last) {
+					more = e != last;
+					if (more) A = sc.leaf_ta[3 * (size_t) e];
+					// like the descent, the primitive loop stops when fewer than q.leaf_min lanes have entries left;
+					// those lanes keep their position (e_cont) and go on in the next round
+					do { if (more) {
 						uint4 An = A;
 						if (e + 1 != last) An = sc.leaf_ta[3 * (size_t) (e + 1)];      // next record's head in flight
 						const uint32_t prim = A.x & 0x1FFFFFFFu, k = A.x >> 30;
 						if (COUNT) c_idx++;
+						MG_WSLOT(w_leaf);
 						if (s_mbox[prim & 7u][tid] != prim) {
 							if (COUNT) c_tri++;
 							const float n_u = __uint_as_float(A.y), n_v = __uint_as_float(A.z), n_d = __uint_as_float(A.w);
@@ -378,7 +470,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 									const float u = hv * b_nu + hu * b_nv;
 									const float v = hu * c_nu + hv * c_nv;
 									if (u >= 0 && v >= 0 && u + v <= 1.0f) {
-										if (MODE != 0) { hitShadow = true; break; }
+										if (MODE != 0) hitShadow = true;
 										maxt = t;      // a later hit with equal t replaces this one (t > maxt rejects)
 										best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = e;
 										found = true;
@@ -389,10 +481,13 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 						}
 						A = An;
 						++e;
-					}
+						more = (e != last) && !hitShadow;
+					} } while ((uint32_t) __popcll(__builtin_amdgcn_ballot_w64(more)) >= leaf_min);
+					e_cont = more ? e : kNoPrim;
 				}
 				bool finished = false;
 				if (hitShadow) { found = true; finished = true; }
+				else if (more) { /* leaf not finished yet */ }
 				else if (ex_t > maxt) finished = true;
 				else {
 					// --- pop: the exit point becomes the entry point ---
@@ -420,52 +515,17 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 						}
 					}
 				}
-				if (finished)
-					break;
-			}
-		}
-
-		// ---- results of this batch (all lanes take part in the ballots) ----
-		if (MODE == 0) {
-			int bin = -1;
-			if (active) {
-				ps.hit(id) = make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim);
-				if (BIN) {
-					bin = kNumBins - 1;
-					if (found) {
-						const int b = sc.shape_bsdf[sc.leaf_ta[3 * (size_t) best_shape + 2].z];   // shape of the hit record
-						if (b >= 0) bin = (int) (sc.bsdf_type[b] & 0xFFu);
-					}
+				if (finished) { has = false; done = true; }
 				}
 			}
-			if (BIN) {
-				// material sort: one ballot + prefix popcount per bin, one atomic per wave and bin
-				#pragma unroll
-				for (int b = 0; b < kNumBins; ++b) {
-					const bool mine = (bin == b);
-					const uint32_t pos = wave_append(mine, &q.counters[(b * kBinShards + shard) * kCounterStride]);
-					if (mine) q.bins[b][(size_t) shard * q.bin_seg_cap + pos] = id;
-				}
-			}
-		} else if (MODE == 1) {
-			// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
-			if (active && !found) {
-				float4 L = ps.Li(id);
-				const float4 c = ps.nee(id);
-				L.x += c.x; L.y += c.y; L.z += c.z;
-				ps.Li(id) = L;
-			}
-		} else {
-			if (active)
-				ps.hit(id) = make_uint4(0u, 0u, 0u, found ? 1u : 0u);
 		}
 	}
 
 	if (COUNT) {
 		// wave reduction, then one atomic per wave and counter
-		unsigned long long v[4] = { c_inner, c_leaf, c_idx, c_tri };
+		unsigned long long v[8] = { c_inner, c_leaf, c_idx, c_tri, w_inner, w_leaf, w_outer, w_batch };
 		#pragma unroll
-		for (int k = 0; k < 4; ++k) {
+		for (int k = 0; k < 8; ++k) {
 			unsigned long long x = v[k];
 			for (int off = 32; off > 0; off >>= 1)
 				x += __shfl_down(x, off);
@@ -1297,7 +1357,12 @@ template <int MODE, bool COUNT, bool BIN>
 static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n) {
 	// persistent grid: enough workgroups to fill every CU, never more than there are rays
 	const unsigned blocks = std::min<unsigned>(blocks_for(n, kTraceBlock), kTraceGridBlocks);
-	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, sc, ps, q, queue, n);
+	DQueues qq = q;
+	// the early loop exits trade the latency of a few straggling rays for throughput; with only a few
+	// batches per wave the stragglers are the critical path, so small launches run the plain loops
+	if (n < 8u * kTraceGridBlocks * kTraceBlock)
+		qq.desc_min = qq.leaf_min = 1;
+	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, sc, ps, qq, queue, n);
 }
 
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
