@@ -446,39 +446,36 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 						const uint32_t prim = A.x & 0x1FFFFFFFu, k = A.x >> 30;
 						if (COUNT) c_idx++;
 						MG_WSLOT(w_leaf);
-						if (s_mbox[prim & 7u][tid] != prim) {
-							if (COUNT) c_tri++;
-							const float n_u = __uint_as_float(A.y), n_v = __uint_as_float(A.z), n_d = __uint_as_float(A.w);
-							float o_u, o_v, o_k, d_u, d_v, d_k;
-							bool ok = true;
-							if (k == 0u) { o_u = oy; o_v = oz; o_k = ox; d_u = dy; d_v = dz; d_k = dx; }
-							else if (k == 1u) { o_u = oz; o_v = ox; o_k = oy; d_u = dz; d_v = dx; d_k = dy; }
-							else if (k == 2u) { o_u = ox; o_v = oy; o_k = oz; d_u = dx; d_v = dy; d_k = dz; }
-							else { ok = false; o_u = o_v = o_k = d_u = d_v = d_k = 0.0f; }
-							if (MODE != 0 && (A.x & 0x20000000u)) ok = false;    // shape->isOccluder() (skdtree.h:318-333)
-							if (ok) {
-								const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
-								const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
-								if (!(t < mint || t > maxt)) {
-									const uint4 B = sc.leaf_ta[3 * (size_t) e + 1];
-									const uint2 C = *reinterpret_cast<const uint2 *>(sc.leaf_ta + 3 * (size_t) e + 2);
-									const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
-									const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
-									const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
-									const float hu = o_u + t * d_u - a_u;
-									const float hv = o_v + t * d_v - a_v;
-									const float u = hv * b_nu + hu * b_nv;
-									const float v = hu * c_nu + hv * c_nv;
-									if (u >= 0 && v >= 0 && u + v <= 1.0f) {
-										if (MODE != 0) hitShadow = true;
-										maxt = t;      // a later hit with equal t replaces this one (t > maxt rejects)
-										best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = e;
-										found = true;
-									}
-								}
+						// Flat form of the mailbox test + TriAccel::rayIntersect: the plane distance t is computed for
+						// every entry (selects, no branches) and masked afterwards; only the barycentric part, which
+						// needs the rest of the record, is conditional.
+						uint32_t *mslot = &s_mbox[prim & 7u][tid];
+						bool ok = (*mslot != prim) && (k != 3u);                  // not in the mailbox, not degenerate
+						if (MODE != 0 && (A.x & 0x20000000u)) ok = false;         // shape->isOccluder() (skdtree.h:318-333)
+						if (COUNT && *mslot != prim) c_tri++;
+						const bool k0 = k == 0u, k1 = k == 1u;
+						const float n_u = __uint_as_float(A.y), n_v = __uint_as_float(A.z), n_d = __uint_as_float(A.w);
+						const float o_u = k0 ? oy : (k1 ? oz : ox), o_v = k0 ? oz : (k1 ? ox : oy), o_k = k0 ? ox : (k1 ? oy : oz);
+						const float d_u = k0 ? dy : (k1 ? dz : dx), d_v = k0 ? dz : (k1 ? dx : dy), d_k = k0 ? dx : (k1 ? dy : dz);
+						const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
+						const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
+						if (ok && !(t < mint || t > maxt)) {
+							const uint4 B = sc.leaf_ta[3 * (size_t) e + 1];
+							const uint2 C = *reinterpret_cast<const uint2 *>(sc.leaf_ta + 3 * (size_t) e + 2);
+							const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
+							const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
+							const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
+							const float hu = o_u + t * d_u - a_u;
+							const float hv = o_v + t * d_v - a_v;
+							const float u = hv * b_nu + hu * b_nv;
+							const float v = hu * c_nu + hv * c_nv;
+							if (u >= 0 && v >= 0 && u + v <= 1.0f) {
+								if (MODE != 0) hitShadow = true;
+								maxt = t;      // a later hit with equal t replaces this one (t > maxt rejects)
+								best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = e;
 							}
-							s_mbox[prim & 7u][tid] = prim;
 						}
+						*mslot = prim;         // (re)writing an entry that is already there changes nothing
 						A = An;
 						++e;
 						more = (e != last) && !hitShadow;
@@ -486,7 +483,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 					e_cont = more ? e : kNoPrim;
 				}
 				bool finished = false;
-				if (hitShadow) { found = true; finished = true; }
+				if (hitShadow) finished = true;
 				else if (more) { /* leaf not finished yet */ }
 				else if (ex_t > maxt) finished = true;
 				else {
@@ -515,7 +512,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 						}
 					}
 				}
-				if (finished) { has = false; done = true; }
+				if (finished) { has = false; done = true; found = (MODE == 0) ? (best_prim != kNoPrim) : hitShadow; }
 				}
 			}
 		}
