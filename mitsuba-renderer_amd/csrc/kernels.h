@@ -8,7 +8,8 @@ namespace mg {
 constexpr int kNumBsdfTypes = 6;      // lambertian, dielectric, roughmetal, microfacet, mirror, phong
 constexpr int kNumBins = kNumBsdfTypes + 1;   // + "terminal" (miss / no BSDF)
 constexpr int kTraceBlock = 256;
-constexpr unsigned kTraceGridBlocks = 256 * 6;   // persistent traversal grid: 256 CUs x resident workgroups
+constexpr unsigned kTraceGridBlocks = 256 * 8;   // largest persistent traversal grid: 256 CUs x resident workgroups
+constexpr unsigned trace_blocks_per_cu(int mode) { return mode == 0 ? 7u : 8u; }   // closest-hit state needs 72 VGPRs, shadow rays 64
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 constexpr int kCounterStride = 32;    // one 128-byte line per queue counter (atomics on one line serialise)
 constexpr int kBinShards = 16;        // the closest-hit kernel appends to bins[b] through 16 independent segments

@@ -203,8 +203,8 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 // free), levels beyond kStackLDS spill to HBM.  The 8-entry hashed mailbox
 // (sahkdtree3.h:130-144) is kept (LDS) because it decides equal-t ties.
 // ===========================================================================
-constexpr int kStackLDS = 16;
-constexpr int kSpillLevels = 36;      // 16 + 36 >= MTS_KD_MAXDEPTH (48) + 2
+constexpr int kStackLDS = 12;
+constexpr int kSpillLevels = 40;      // 12 + 40 >= MTS_KD_MAXDEPTH (48) + 2
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 
@@ -219,7 +219,7 @@ size_t trace_spill_levels() { return kSpillLevels; }
 // need them (the others stop waiting; stragglers resume in the next round).  None of this changes
 // what is computed for a ray.
 template <int MODE, bool COUNT, bool BIN>
-__global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, DQueues q,
+__global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trace(DScene sc, DPaths ps, DQueues q,
                                                           const uint32_t *queue, uint32_t n) {
 	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
 	__shared__ uint32_t s_mbox[8][kTraceBlock];
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 	float best_t = MG_INF, best_u = 0, best_v = 0;
 	uint32_t best_prim = kNoPrim, best_shape = 0;
 	uint32_t e_cont = kNoPrim;              // position inside an interrupted leaf
+	uint2 nd = make_uint2(0u, 0u);          // sc.nodes[cur], fetched as soon as cur is known
 	bool found = false;
 	bool has = false;                       // this lane is traversing a ray
 	bool done = false;                      // this lane holds a finished ray that has not been retired yet
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 					ex_t = maxt; exx = ox + maxt * dx; exy = oy + maxt * dy; exz = oz + maxt * dz;
 					ex_node = kNullNode; ex_ref = kSentinel;
 					sp = 0; cur = 0; e_cont = kNoPrim;
+					nd = sc.nodes[0];
 				}
 			}
 		}
@@ -379,8 +381,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 		// ---- one leaf visit of every live lane: descend, test the leaf, pop ----
 		if (has) {
 			{
-				uint2 nd = sc.nodes[cur];
-				bool inner = !(nd.x & 0x80000000u);
+				bool inner = !(nd.x & 0x80000000u);     // nd = sc.nodes[cur] is part of the lane's state
 				// The descent stops as soon as fewer than q.desc_min lanes are still on inner nodes: the lanes
 				// that wait in a leaf go on, the few stragglers resume their descent in the next round.
 				do { if (inner) {
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(kTraceBlock, 6) void k_trace(DScene sc, DPaths ps, 
 						finished = true;
 					} else {
 						--sp;
+						nd = sc.nodes[cur];          // in flight together with the parent's node below
 						const uint32_t ref = (sp < kStackLDS) ? s_stack[sp][tid]
 						                                      : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
 						if (ref == kSentinel) {
@@ -1353,7 +1355,7 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 template <int MODE, bool COUNT, bool BIN>
 static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n) {
 	// persistent grid: enough workgroups to fill every CU, never more than there are rays
-	const unsigned blocks = std::min<unsigned>(blocks_for(n, kTraceBlock), kTraceGridBlocks);
+	const unsigned blocks = std::min<unsigned>(blocks_for(n, kTraceBlock), 256u * trace_blocks_per_cu(MODE));
 	DQueues qq = q;
 	// the early loop exits trade the latency of a few straggling rays for throughput; with only a few
 	// batches per wave the stragglers are the critical path, so small launches run the plain loops
