@@ -423,8 +423,8 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	}
 	{
 		// TriAccel records re-laid out in leaf order (one contiguous run per leaf, no index
-		// indirection on the device); bit 31 of the shape dword marks non-occluders
-		// (Shape::isOccluder == has a BSDF, shape.h:324), dword 11 carries the global primitive id
+		// indirection on the device); non-occluders are shapes without a BSDF
+		// (Shape::isOccluder, shape.h:324)
 		std::vector<uint32_t> ta(12 * (size_t) sc->n_indices + 12, 0u);
 		for (uint32_t e = 0; e < sc->n_indices; ++e) {
 			const uint32_t prim = sc->kd_indices[e];

@@ -18,10 +18,10 @@ constexpr int kShadeBlock = 512;
 
 // Scene in HBM (all pointers are device pointers); see DESIGN.md section 3
 struct DScene {
-	const uint2    *nodes;        // KDNode, 8 B
+	const uint2    *nodes;        // 8 B: (left child index << 2 | axis, split) or (1 << 31 | first record, end record)
 	// TriAccel records in LEAF ORDER: entry e of the kd-tree index list holds the 48-byte
-	// TriAccel of primitive kd_indices[e] (dword 10 = shape | bit31 "not an occluder",
-	// dword 11 = global primitive id), so a leaf's primitives are one contiguous run
+	// TriAccel of primitive kd_indices[e] (dword 0 = k << 30 | "not an occluder" << 29 | global
+	// primitive id, dword 10 = shape), so a leaf's primitives are one contiguous run
 	const uint4    *leaf_ta;
 	// per-primitive gather records (3 x 16 B each): p0.xyz p1.xyz p2.xyz | shape, flags, 0   and
 	// n0.xyz n1.xyz n2.xyz | 0 0 0 -- one line instead of 3 index + 9 scattered vertex fetches
