@@ -179,6 +179,10 @@ int  mtsgpu_set_tiles(mtsgpu_ctx *ctx, int block_size, int part, int n_parts);
  * holds.  values == NULL selects the box filter (src/rfilters/box.cpp).  Filters wider than half a
  * pixel make every ImageBlock carry a border of ceil(size - 0.5) pixels (renderproc.cpp:143-144). */
 int  mtsgpu_set_rfilter(mtsgpu_ctx *ctx, float size_x, float size_y, const float *values);
+/* Film property `highQualityEdges` (src/librender/film.cpp:51): the rendered rectangle grows by the filter
+ * border on every side (renderproc.cpp:146-153), so pixels at the film's edge receive their full filter
+ * support; the extra samples only land in block borders and are clipped by Film::putImageBlock. */
+int  mtsgpu_set_film_edges(mtsgpu_ctx *ctx, int high_quality_edges);
 /* Optional: render into a caller-owned device buffer [H][W][5] f32 (spec rgb, alpha, weight) */
 int  mtsgpu_set_film_buffer(mtsgpu_ctx *ctx, void *device_ptr);
 /* Tuning knobs (0 = default): paths in flight per pass; enable traversal counters */

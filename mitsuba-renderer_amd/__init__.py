@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "libmtsgpu.so")
 EXPORTS = [
     "mtsgpu_create", "mtsgpu_destroy", "mtsgpu_last_error", "mtsgpu_abi_version", "mtsgpu_abi_sizeof", "mtsgpu_set_stream",
     "mtsgpu_upload_scene", "mtsgpu_set_camera", "mtsgpu_set_integrator", "mtsgpu_set_sampler",
-    "mtsgpu_set_tiles", "mtsgpu_set_rfilter", "mtsgpu_tabulate_filter", "mtsgpu_set_film_buffer", "mtsgpu_set_options", "mtsgpu_render", "mtsgpu_sync",
+    "mtsgpu_set_tiles", "mtsgpu_set_rfilter", "mtsgpu_set_film_edges", "mtsgpu_tabulate_filter", "mtsgpu_set_film_buffer", "mtsgpu_set_options", "mtsgpu_render", "mtsgpu_sync",
     "mtsgpu_read_film", "mtsgpu_clear_film", "mtsgpu_get_stats", "mtsgpu_trace_rays", "mtsgpu_ld_tables",
     "mtsgpu_li_samples", "mtsgpu_flatten", "mtsgpu_flat_scene_get", "mtsgpu_flat_scene_free",
     "mtsgpu_flat_scene_kdstats", "mtsgpu_make_camera",
@@ -68,6 +68,7 @@ def lib():
     L.mtsgpu_set_tiles.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.mtsgpu_set_film_buffer.argtypes = [vp, vp]
     L.mtsgpu_set_rfilter.argtypes = [vp, C.c_float, C.c_float, f32p]
+    L.mtsgpu_set_film_edges.argtypes = [vp, C.c_int]
     L.mtsgpu_tabulate_filter.argtypes = [C.c_int, C.c_float, C.c_float, f32p, f32p]
     L.mtsgpu_set_options.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
     L.mtsgpu_render.argtypes = [vp, C.POINTER(C.c_int)]
@@ -202,6 +203,10 @@ class MIPathTracer:
             raise MtsGpuError("mtsgpu_tabulate_filter: %s" % lib().mtsgpu_last_error(None).decode())
         self._chk(lib().mtsgpu_set_rfilter(self._ctx, float(size[0]), float(size[1]), abi.ptr(values, abi.f32p)), "set_rfilter")
         return size, values.reshape(16, 16)
+
+    def set_film_edges(self, highQualityEdges=False):
+        """Film property `highQualityEdges` (src/librender/film.cpp:51, renderproc.cpp:146-153)"""
+        self._chk(lib().mtsgpu_set_film_edges(self._ctx, int(bool(highQualityEdges))), "set_film_edges")
 
     def set_options(self, max_paths=0, count_traversal=False, time_kernels=False):
         self._chk(lib().mtsgpu_set_options(self._ctx, int(max_paths), int(count_traversal), int(time_kernels)), "set_options")

@@ -41,6 +41,7 @@ struct mtsgpu_ctx {
 	// film
 	float *film = nullptr; bool ownFilm = false; size_t filmPixels = 0;
 	float filtSizeX = 0.5f, filtSizeY = 0.5f; int filtBorder = 0;
+	bool hqEdges = false;
 	float *filtValues = nullptr;           // device [16][16]
 	TileMeta *tileMeta = nullptr; size_t tileMetaCap = 0;
 	float *blocks = nullptr; size_t blocksCap = 0;
@@ -149,6 +150,7 @@ DConfig makeConfig(const mtsgpu_ctx *c, bool slotPerPath) {
 	cfg.near_clip = c->cam.near_clip; cfg.far_clip = c->cam.far_clip;
 	cfg.aperture_radius = c->cam.aperture_radius; cfg.focus_depth = c->cam.focus_depth;
 	cfg.width = c->cam.width; cfg.height = c->cam.height;
+	cfg.pix_w = c->cam.width; cfg.pix_off = 0;
 	cfg.max_depth = c->maxDepth; cfg.rr_depth = c->rrDepth; cfg.strict_normals = c->strictNormals;
 	cfg.sampler_kind = c->samplerKind;
 	cfg.spp = effectiveSpp(c); cfg.ld_depth = c->ldDepth; cfg.seed = c->seed;
@@ -520,6 +522,12 @@ int mtsgpu_set_rfilter(mtsgpu_ctx *c, float size_x, float size_y, const float *v
 	return 0;
 }
 
+int mtsgpu_set_film_edges(mtsgpu_ctx *c, int high_quality_edges) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	c->hqEdges = high_quality_edges != 0;
+	return 0;
+}
+
 int mtsgpu_tabulate_filter(int kind, float half_size, float stddev, float *size_xy, float *values) {
 	if (!size_xy || !values || (kind != 0 && kind != 1)) return fail(nullptr, MTSGPU_EINVAL, "bad filter arguments");
 	tabulateFilter(kind, half_size, stddev, size_xy, values);
@@ -572,18 +580,21 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	// ImageBlock work units (imageproc.cpp:43-78) owned by this context: tile t -> part t % n_parts
 	std::vector<uint32_t> pixels;
 	std::vector<TileMeta> tiles;
-	const int tx = (W + bs - 1) / bs, ty = (H + bs - 1) / bs;
+	// Film::hasHighQualityEdges: the rendered rectangle grows by the filter border (renderproc.cpp:146-153)
+	const int off = c->hqEdges ? -c->filtBorder : 0;
+	const int RW = W - 2 * off, RH = H - 2 * off;
+	const int tx = (RW + bs - 1) / bs, ty = (RH + bs - 1) / bs;
 	for (int t = 0; t < tx * ty; ++t) {
 		if (t % c->nParts != c->part) continue;
-		const int x0 = (t % tx) * bs, y0 = (t / tx) * bs;
+		const int x0 = off + (t % tx) * bs, y0 = off + (t / tx) * bs;
 		TileMeta tm{};
-		tm.x0 = x0; tm.y0 = y0; tm.w = std::min(bs, W - x0); tm.h = std::min(bs, H - y0);
+		tm.x0 = x0; tm.y0 = y0; tm.w = std::min(bs, off + RW - x0); tm.h = std::min(bs, off + RH - y0);
 		tm.slot_base = (uint32_t) pixels.size(); tm.block_index = (uint32_t) tiles.size();
 		tm.colour = (uint32_t) (((t % tx) & 1) + 2 * ((t / tx) & 1));
 		tiles.push_back(tm);
 		for (int y = y0; y < y0 + tm.h; ++y)
 			for (int x = x0; x < x0 + tm.w; ++x)
-				pixels.push_back((uint32_t) y * (uint32_t) W + (uint32_t) x);
+				pixels.push_back((uint32_t) (y - off) * (uint32_t) RW + (uint32_t) (x - off));   // id inside the rendered rectangle
 	}
 	std::memset(&c->stats, 0, sizeof(c->stats));
 	c->traceEvUsed = c->shadeEvUsed = 0;
@@ -603,7 +614,8 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, slotsPerPass * 2 * c->ldDepth * spp); if (rc) return rc;
 	}
 	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 8 * sizeof(unsigned long long), c->stream));
-	const DConfig cfg = makeConfig(c, false);
+	DConfig cfg = makeConfig(c, false);
+	cfg.pix_w = RW; cfg.pix_off = off;
 	const size_t fullBlock = (size_t) (bs + 2 * c->filtBorder) * (bs + 2 * c->filtBorder) * 5;
 	if (wideFilter) {
 		rc = ensureBuf(c, &c->tileMeta, &c->tileMetaCap, tiles.size()); if (rc) return rc;

@@ -78,6 +78,7 @@ struct DConfig {
 	float near_clip, far_clip;
 	float aperture_radius, focus_depth;   // thin lens (perspective.cpp:90-103); 0 = pinhole
 	int32_t width, height;
+	int32_t pix_w, pix_off;            // rendered rectangle: pixel ids index a pix_w-wide grid whose origin is (pix_off, pix_off)
 	int32_t max_depth, rr_depth, strict_normals;
 	int32_t sampler_kind;
 	uint32_t spp; int32_t ld_depth;

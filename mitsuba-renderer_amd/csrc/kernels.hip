@@ -133,7 +133,9 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 		j = id - slot * cfg.spp;
 		pixel = pixel_list[slot];
 	}
-	const uint32_t px = pixel % (uint32_t) cfg.width, py = pixel / (uint32_t) cfg.width;
+	int px, py;       // pixel position; negative / beyond the film with highQualityEdges (renderproc.cpp:146-153)
+	if (explicit_samples) { px = (int) (pixel % (uint32_t) cfg.width); py = (int) (pixel / (uint32_t) cfg.width); }
+	else { px = (int) (pixel % (uint32_t) cfg.pix_w) + cfg.pix_off; py = (int) (pixel / (uint32_t) cfg.pix_w) + cfg.pix_off; }
 
 	PathSampler smp;
 	smp.stream = keyedInit(cfg.seed, pixel, 1 + (uint64_t) j);

@@ -135,7 +135,7 @@ void orc_tabulate_filter(int kind, float half_size, float stddev, orc_tabfilter 
  * Summation order is fixed: inside a block by (pixel row-major, sample index),
  * blocks by (tx%2 + 2*(ty%2)) colour. */
 void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *p,
-                      const orc_tabfilter *filter, int block_size, int part, int n_parts,
+                      const orc_tabfilter *filter, int block_size, int part, int n_parts, int hq_edges,
                       float *film, mtsgpu_stats *stats);
 
 /* BSDF entry points for the chi-square self-consistency test (test_chisquare.cpp:299-420).

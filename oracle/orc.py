@@ -94,7 +94,7 @@ def lib():
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
     L.orc_tabulate_filter.argtypes = [C.c_int, C.c_float, C.c_float, C.POINTER(TabFilter)]
     L.orc_render_tiles.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(RenderParams), C.POINTER(TabFilter),
-                                   C.c_int, C.c_int, C.c_int, f32p, C.POINTER(abi.Stats)]
+                                   C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(abi.Stats)]
     L.orc_bsdf_f.argtypes = [C.c_uint32, f32p, f32p, f32p, f32p]
     L.orc_bsdf_pdf.argtypes = [C.c_uint32, f32p, f32p, f32p]; L.orc_bsdf_pdf.restype = C.c_float
     L.orc_bsdf_sample.argtypes = [C.c_uint32, f32p, f32p, f32p, f32p, f32p, u32p, f32p]
@@ -191,9 +191,9 @@ def tabulate_filter(kind="gaussian", half_size=2.0, stddev=0.5):
     return f
 
 
-def render_tiles(scene_ptr, cam, params, filt, block_size=32, part=0, n_parts=1):
+def render_tiles(scene_ptr, cam, params, filt, block_size=32, part=0, n_parts=1, hq_edges=False):
     film = np.zeros((cam.height, cam.width, 5), dtype=np.float32)
     st = abi.Stats()
-    lib().orc_render_tiles(scene_ptr, C.byref(cam), C.byref(params), C.byref(filt), block_size, part, n_parts,
+    lib().orc_render_tiles(scene_ptr, C.byref(cam), C.byref(params), C.byref(filt), block_size, part, n_parts, int(bool(hq_edges)),
                            abi.ptr(film, abi.f32p), C.byref(st))
     return film, st

@@ -1299,15 +1299,19 @@ void orc_tabulate_filter(int kind, float half_size, float stddev, orc_tabfilter 
 typedef struct { float L[3], alpha, sx, sy; int valid; } tsample_t;
 
 void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *prm,
-                      const orc_tabfilter *filter, int bs, int part, int n_parts,
+                      const orc_tabfilter *filter, int bs, int part, int n_parts, int hq_edges,
                       float *film, mtsgpu_stats *stats) {
 	const uint32_t spp = effective_spp(prm);
 	const int W = cam->width, H = cam->height;
 	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED;
 	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
-	const int tx = (W + bs - 1) / bs, ty = (H + bs - 1) / bs, nTiles = tx * ty;
 	/* m_borderSize (renderproc.cpp:143-144) */
 	const int border = (int) ceilf(fmaxf_(filter->size_x, filter->size_y) - (float) 0.5);
+	/* Film::hasHighQualityEdges: the rendered rectangle grows by the border on every side
+	   (renderproc.cpp:146-153); samples outside the film still reach the pixels inside */
+	const int off = hq_edges ? -border : 0;
+	const int RW = W - 2 * off, RH = H - 2 * off;      /* size of the rendered rectangle */
+	const int tx = (RW + bs - 1) / bs, ty = (RH + bs - 1) / bs, nTiles = tx * ty;
 	const int full = bs + 2 * border;
 	const float factorX = FILTER_RESOLUTION / filter->size_x, factorY = FILTER_RESOLUTION / filter->size_y;
 	const int RX = (int) ceilf(filter->size_x + 0.5f), RY = (int) ceilf(filter->size_y + 0.5f);
@@ -1327,11 +1331,12 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 #endif
 		for (int t = 0; t < nTiles; ++t) {
 			if (t % n_parts != part) continue;
-			const int x0 = (t % tx) * bs, y0 = (t / tx) * bs;
-			const int w = (x0 + bs <= W ? bs : W - x0), h = (y0 + bs <= H ? bs : H - y0);
+			const int x0 = off + (t % tx) * bs, y0 = off + (t / tx) * bs;
+			const int w = (x0 + bs <= off + RW ? bs : off + RW - x0), h = (y0 + bs <= off + RH ? bs : off + RH - y0);
 			/* 1. the camera samples of the tile (integrator.cpp:150-169) */
 			for (int py = 0; py < h; ++py) for (int px = 0; px < w; ++px) {
-				const uint32_t pixelKey = (uint32_t) (y0 + py) * (uint32_t) W + (uint32_t) (x0 + px);
+				/* sampler key = index of the pixel inside the rendered rectangle */
+				const uint32_t pixelKey = (uint32_t) (y0 + py - off) * (uint32_t) RW + (uint32_t) (x0 + px - off);
 				if (isLD) orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);
 				for (uint32_t j = 0; j < spp; ++j) {
 					sampler_t s; memset(&s, 0, sizeof(s));
@@ -1396,8 +1401,8 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 	for (int colour = 0; colour < 4; ++colour)
 		for (int t = 0; t < nTiles; ++t) {
 			if (!blocks[t] || (((t % tx) & 1) + 2 * ((t / tx) & 1)) != colour) continue;
-			const int x0 = (t % tx) * bs, y0 = (t / tx) * bs;
-			const int w = (x0 + bs <= W ? bs : W - x0), h = (y0 + bs <= H ? bs : H - y0);
+			const int x0 = off + (t % tx) * bs, y0 = off + (t / tx) * bs;
+			const int w = (x0 + bs <= off + RW ? bs : off + RW - x0), h = (y0 + bs <= off + RH ? bs : off + RH - y0);
 			for (int yl = 0; yl < h + 2 * border; ++yl) for (int xl = 0; xl < w + 2 * border; ++xl) {
 				const int X = x0 - border + xl, Y = y0 - border + yl;
 				if (X < 0 || X >= W || Y < 0 || Y >= H) continue;

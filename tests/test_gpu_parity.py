@@ -213,6 +213,13 @@ def test_gaussian_rfilter_matches_oracle(gpu_lib, mts, orc):
         it.clear_film(); it.set_tiles(32, part, 3); assert it.render()
         acc += it.film()
     assert np.allclose(acc, film, rtol=2e-6, atol=1e-7)
+    # Film::hasHighQualityEdges: tiles start at (-border, -border), samples outside the film are traced too
+    it.set_tiles(32, 0, 1); it.set_film_edges(True); it.clear_film(); assert it.render()
+    ohq, ohst = orc.render_tiles(oscene.scene, ocam, op, of, hq_edges=True)
+    assert np.array_equal(it.film().view(np.uint32), ohq.view(np.uint32))
+    assert it.stats()["camera_samples"] == ohst.camera_samples == (80 + 4) * (72 + 4) * 8
+    assert not np.array_equal(ohq.view(np.uint32), ofilm.view(np.uint32))
+    it.set_film_edges(False)
     # back to the box filter
     it.set_rfilter("box"); it.set_tiles(32, 0, 1); it.clear_film(); assert it.render()
     obox, _ = orc.render(oscene.scene, ocam, op)

@@ -234,6 +234,31 @@ def test_bordered_tiles_and_gaussian_filter(mts, orc):
     assert np.array_equal(vals.reshape(16, 16).view(np.uint32), tab.view(np.uint32)) and size[0] == 2.0
 
 
+def test_high_quality_edges(mts, orc):
+    """Film::hasHighQualityEdges (renderproc.cpp:146-153): the rendered rectangle grows by the border, so edge
+    pixels get their full filter support; the box filter has no border and is unaffected"""
+    sd = mts.scenes.cornell_c1()
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 70, 50)
+    prm = orc.render_params(4, sampler=mts.abi.SAMPLER_LD_KEYED, spp=8, seed=3)
+    g = orc.tabulate_filter("gaussian")
+    plain, st0 = orc.render_tiles(fs.scene, cam, prm, g)
+    hq, st1 = orc.render_tiles(fs.scene, cam, prm, g, hq_edges=True)
+    assert st1.camera_samples == (70 + 4) * (50 + 4) * 8 and st0.camera_samples == 70 * 50 * 8
+    # without the option the weight falls off towards the film's edge; with it the weight is flat
+    assert plain[0, :, 4].mean() < 0.9 * plain[25, :, 4].mean()
+    assert abs(hq[0, 5:-5, 4].mean() / hq[25, 5:-5, 4].mean() - 1) < 0.03
+    assert abs(hq[:, 0, 4].mean() / hq[:, 35, 4].mean() - 1) < 0.03
+    assert abs(orc.develop(hq)[5:-5, 5:-5].mean() / orc.develop(plain)[5:-5, 5:-5].mean() - 1) < 0.02
+    box = orc.tabulate_filter("box")
+    a, _ = orc.render_tiles(fs.scene, cam, prm, box)
+    b, _ = orc.render_tiles(fs.scene, cam, prm, box, hq_edges=True)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # sharding: the union of the parts' films is the whole film up to the association of border sums
+    acc = sum(orc.render_tiles(fs.scene, cam, prm, g, part=k, n_parts=2, hq_edges=True)[0] for k in range(2))
+    assert np.allclose(acc, hq, rtol=2e-6, atol=1e-7)
+
+
 def test_phong_chi_square_and_twosided(orc):
     """phong is in the reference's own chi-square list (data/tests/test_bsdf.xml); twosided mirrors the lobe"""
     import ctypes as C
