@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MTSGPU_ABI_VERSION 1
+#define MTSGPU_ABI_VERSION 2
 
 enum {
 	MTSGPU_OK = 0,
@@ -79,6 +79,18 @@ enum {
 /* shape_flags bits */
 #define MTSGPU_SHAPE_HAS_NORMALS 1u  /* TriMesh has per-vertex normals (faceNormals=false) */
 
+/* Shape plugins.  A TriMesh is expanded into one kd-tree primitive per triangle; every other shape is
+ * ONE primitive that the tree only knows by its AABB (ShapeKDTree::addShape, src/librender/skdtree.cpp:43-60);
+ * its tri_idx row is {NONE, NONE, NONE} and its TriAccel row has k = MTSGPU_KNOTRIANGLE (skdtree.cpp:92-96). */
+enum {
+	MTSGPU_SHAPE_TRIMESH = 0,
+	MTSGPU_SHAPE_SPHERE = 1   /* src/shapes/sphere.cpp; params: [0..2] m_center [3] m_radius [4] m_inverted (0/1)
+	                             [5..13] m_objectToWorld 3x3 (row major, scale removed: sphere.cpp:49-53)
+	                             [14..22] m_worldToObject 3x3 [23] m_invSurfaceArea                           */
+};
+#define MTSGPU_SHAPE_NPARAMS 24
+#define MTSGPU_KNOTRIANGLE 0xFFFFFFFFu
+
 /*
  * Flattened scene.  This is what ShapeKDTree + TriMesh + BSDF/Luminaire
  * parameter blocks look like once laid out for HBM (Appendix A of SURVEY.md).
@@ -90,7 +102,7 @@ typedef struct mtsgpu_scene {
 	uint32_t abi_version;        /* MTSGPU_ABI_VERSION                                        */
 
 	/* --- geometry (TriMesh storage, include/mitsuba/render/trimesh.h) --- */
-	uint32_t n_shapes, n_tris, n_verts;
+	uint32_t n_shapes, n_tris, n_verts;   /* n_tris = number of kd-tree primitives (triangles + other shapes) */
 	const float    *vtx_pos;     /* [n_verts][3]                                              */
 	const float    *vtx_nrm;     /* [n_verts][3]; rows of shapes without normals are ignored  */
 	const uint32_t *tri_idx;     /* [n_tris][3] indices into the global vertex pool           */
@@ -98,6 +110,8 @@ typedef struct mtsgpu_scene {
 	const int32_t  *shape_bsdf;  /* [n_shapes] index into bsdf_* or -1 (not an occluder)      */
 	const int32_t  *shape_lum;   /* [n_shapes] index into lum_* or -1                         */
 	const uint32_t *shape_flags; /* [n_shapes] MTSGPU_SHAPE_*                                 */
+	const uint32_t *shape_type;  /* [n_shapes] MTSGPU_SHAPE_TRIMESH / _SPHERE; NULL = all TriMesh */
+	const float    *shape_params;/* [n_shapes][MTSGPU_SHAPE_NPARAMS]; NULL iff shape_type is NULL  */
 
 	/* --- SAH kd-tree (KDNode, include/mitsuba/render/gkdtree.h:442-470) ---
 	 * node = 2 x u32: inner {axis | relOffsetToLeft<<2, float split},
@@ -219,6 +233,10 @@ typedef struct mtsgpu_mesh {
 	int32_t face_normals;       /* TriMesh 'faceNormals' property                 */
 	int32_t bsdf;               /* index or -1                                    */
 	int32_t lum;                /* index of the area luminaire attached, or -1    */
+	int32_t shape_type;         /* MTSGPU_SHAPE_TRIMESH, or MTSGPU_SHAPE_SPHERE (then n_verts = n_tris = 0) */
+	float   sphere_center[3];   /* `center` / `radius` properties (sphere.cpp:44-47)                       */
+	float   sphere_radius;
+	int32_t sphere_inverted;    /* `inverted` property (sphere.cpp:56)                                      */
 } mtsgpu_mesh;
 
 typedef struct mtsgpu_scene_desc {

@@ -5,7 +5,7 @@ against the sizes the C compiler reports (mtsgpu_abi_sizeof)."""
 import ctypes as C
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET, BSDF_MIRROR, BSDF_PHONG = 0, 1, 2, 3, 4, 5
 BSDF_TWOSIDED = 0x100
 BSDF_NPARAMS = 16
@@ -13,6 +13,9 @@ LUM_AREA, LUM_CONSTANT, LUM_POINT, LUM_DIRECTIONAL, LUM_SPOT = 0, 1, 2, 3, 4
 LUM_NPARAMS = 24
 SAMPLER_INDEPENDENT_KEYED, SAMPLER_LD_KEYED = 0, 1
 SHAPE_HAS_NORMALS = 1
+SHAPE_TRIMESH, SHAPE_SPHERE = 0, 1
+SHAPE_NPARAMS = 24
+KNOTRIANGLE = 0xFFFFFFFF
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
@@ -25,6 +28,7 @@ class Scene(C.Structure):
         ("n_shapes", C.c_uint32), ("n_tris", C.c_uint32), ("n_verts", C.c_uint32),
         ("vtx_pos", f32p), ("vtx_nrm", f32p), ("tri_idx", u32p),
         ("shape_tri_offset", u32p), ("shape_bsdf", i32p), ("shape_lum", i32p), ("shape_flags", u32p),
+        ("shape_type", u32p), ("shape_params", f32p),
         ("n_nodes", C.c_uint32), ("n_indices", C.c_uint32),
         ("kd_nodes", u32p), ("kd_indices", u32p), ("triaccel", u32p),
         ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
@@ -62,6 +66,8 @@ class Mesh(C.Structure):
         ("n_verts", C.c_uint32), ("n_tris", C.c_uint32),
         ("positions", f32p), ("normals", f32p), ("triangles", u32p),
         ("face_normals", C.c_int32), ("bsdf", C.c_int32), ("lum", C.c_int32),
+        ("shape_type", C.c_int32), ("sphere_center", C.c_float * 3), ("sphere_radius", C.c_float),
+        ("sphere_inverted", C.c_int32),
     ]
 
 
@@ -111,6 +117,8 @@ def scene_arrays(sc):
         "shape_bsdf": np_from(sc.shape_bsdf, (ns,), np.int32),
         "shape_lum": np_from(sc.shape_lum, (ns,), np.int32),
         "shape_flags": np_from(sc.shape_flags, (ns,), np.uint32),
+        "shape_type": np_from(sc.shape_type, (ns,), np.uint32),
+        "shape_params": np_from(sc.shape_params, (ns, SHAPE_NPARAMS), np.float32),
         "kd_nodes": np_from(sc.kd_nodes, (sc.n_nodes, 2), np.uint32),
         "kd_indices": np_from(sc.kd_indices, (sc.n_indices,), np.uint32),
         "triaccel": np_from(sc.triaccel, (nt, 12), np.uint32),

@@ -355,8 +355,31 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	}
 	for (uint32_t i = 0; i < sc->n_indices; ++i)
 		if (sc->kd_indices[i] >= sc->n_tris) return fail(c, MTSGPU_EINVAL, "kd index %u out of range", i);
-	for (size_t i = 0; i < 3 * (size_t) sc->n_tris; ++i)
-		if (sc->tri_idx[i] >= sc->n_verts) return fail(c, MTSGPU_EINVAL, "triangle vertex index out of range");
+	if ((sc->shape_type == nullptr) != (sc->shape_params == nullptr)) return fail(c, MTSGPU_EINVAL, "shape_type and shape_params must both be given or both be NULL");
+	auto shapeType = [&](uint32_t s) { return sc->shape_type ? sc->shape_type[s] : (uint32_t) MTSGPU_SHAPE_TRIMESH; };
+	for (uint32_t s = 0; s < sc->n_shapes; ++s) {
+		if (shapeType(s) > MTSGPU_SHAPE_SPHERE) return fail(c, MTSGPU_EINVAL, "shape %u: unknown shape type", s);
+		if (sc->shape_tri_offset[s] > sc->shape_tri_offset[s + 1] || sc->shape_tri_offset[s + 1] > sc->n_tris) return fail(c, MTSGPU_EINVAL, "shape_tri_offset not monotone");
+		const bool mesh = shapeType(s) == MTSGPU_SHAPE_TRIMESH;
+		if (!mesh) {
+			// any other shape is ONE kd-tree primitive (skdtree.cpp:54-57)
+			if (sc->shape_tri_offset[s + 1] - sc->shape_tri_offset[s] != 1) return fail(c, MTSGPU_EINVAL, "shape %u: a non-mesh shape must own exactly one primitive", s);
+			const float *SP = sc->shape_params + (size_t) MTSGPU_SHAPE_NPARAMS * s;
+			for (int i = 0; i < MTSGPU_SHAPE_NPARAMS; ++i) if (!std::isfinite(SP[i])) return fail(c, MTSGPU_EINVAL, "shape %u: non-finite parameter", s);
+			if (SP[3] == 0.0f) return fail(c, MTSGPU_EINVAL, "shape %u: zero radius", s);
+		}
+		for (uint32_t t = sc->shape_tri_offset[s]; t < sc->shape_tri_offset[s + 1]; ++t) {
+			const uint32_t k = sc->triaccel[12 * (size_t) t];
+			if (mesh) {
+				if (k == MTSGPU_KNOTRIANGLE) return fail(c, MTSGPU_EINVAL, "TriAccel %u: a mesh triangle is marked as a shape", t);
+				for (int j = 0; j < 3; ++j)
+					if (sc->tri_idx[3 * (size_t) t + j] >= sc->n_verts) return fail(c, MTSGPU_EINVAL, "triangle vertex index out of range");
+			} else if (k != MTSGPU_KNOTRIANGLE) {
+				return fail(c, MTSGPU_EINVAL, "TriAccel %u: the primitive of a non-mesh shape must have k = KNoTriangleFlag", t);
+			}
+			if (sc->triaccel[12 * (size_t) t + 10] != s) return fail(c, MTSGPU_EINVAL, "TriAccel %u: shape index does not match shape_tri_offset", t);
+		}
+	}
 	for (uint32_t s = 0; s < sc->n_shapes; ++s) {
 		if (sc->shape_bsdf[s] >= (int32_t) sc->n_bsdfs || sc->shape_lum[s] >= (int32_t) sc->n_lums) return fail(c, MTSGPU_EINVAL, "shape %u: bad BSDF/luminaire index", s);
 		if (sc->shape_tri_offset[s] > sc->shape_tri_offset[s + 1]) return fail(c, MTSGPU_EINVAL, "shape_tri_offset not monotone");
@@ -373,7 +396,9 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 			const int32_t s = sc->lum_shape[l];
 			if (s < 0 || s >= (int32_t) sc->n_shapes) return fail(c, MTSGPU_EINVAL, "luminaire %u: bad shape", l);
 			const uint32_t n = sc->shape_tri_offset[s + 1] - sc->shape_tri_offset[s];
-			if (sc->lum_cdf_offset[l + 1] - sc->lum_cdf_offset[l] != n + 1) return fail(c, MTSGPU_EINVAL, "luminaire %u: CDF size mismatch", l);
+			if (shapeType((uint32_t) s) != MTSGPU_SHAPE_TRIMESH) {
+				if (sc->lum_cdf_offset[l + 1] != sc->lum_cdf_offset[l]) return fail(c, MTSGPU_EINVAL, "luminaire %u: a non-mesh emitter has no triangle CDF", l);
+			} else if (sc->lum_cdf_offset[l + 1] - sc->lum_cdf_offset[l] != n + 1) return fail(c, MTSGPU_EINVAL, "luminaire %u: CDF size mismatch", l);
 		} else if (sc->lum_type[l] > MTSGPU_LUM_SPOT) {
 			return fail(c, MTSGPU_EINVAL, "luminaire %u: unknown type", l);
 		}
@@ -435,8 +460,19 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 			// dword 0 = k<<30 | non-occluder<<29 | primitive id (the head of the record decides everything
 			// up to the plane distance); dword 10 stays the shape index
 			if (prim >= (1u << 29)) return fail(c, MTSGPU_EINVAL, "more than 2^29 primitives");
+			const bool isShape = dst[0] == MTSGPU_KNOTRIANGLE;
 			dst[0] = (std::min(dst[0], 3u) << 30) | (sc->shape_bsdf[dst[10]] < 0 ? 0x20000000u : 0u) | prim;
 			dst[11] = 0;
+			if ((dst[0] >> 30) == 3u) {
+				// k == 3: a degenerate triangle (dword 1 = 0) or a non-triangle shape (dword 1 = shape type,
+				// dwords 4..7 = centre and radius of the sphere)
+				dst[1] = 0;
+				if (isShape) {
+					const float *SP = sc->shape_params + (size_t) MTSGPU_SHAPE_NPARAMS * dst[10];
+					dst[1] = shapeType(dst[10]);
+					std::memcpy(dst + 4, SP, 16);
+				}
+			}
 		}
 		rc |= upload(c, (const uint32_t **) &d.leaf_ta, ta.data(), ta.size());
 		// per-primitive position / normal records for the shading kernels
@@ -444,6 +480,13 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 		for (uint32_t s = 0; s < sc->n_shapes; ++s)
 			for (uint32_t t = sc->shape_tri_offset[s]; t < sc->shape_tri_offset[s + 1]; ++t) {
 				float *P = &triPos[12 * (size_t) t], *Nn = &triNrm[12 * (size_t) t];
+				if (shapeType(s) != MTSGPU_SHAPE_TRIMESH) {
+					// non-mesh shape: centre + radius, flag bit 31 (the rest comes from shape_params)
+					const uint32_t flags = sc->shape_flags[s] | 0x80000000u;
+					std::memcpy(P, sc->shape_params + (size_t) MTSGPU_SHAPE_NPARAMS * s, 16);
+					std::memcpy(P + 10, &s, 4); std::memcpy(P + 11, &flags, 4);
+					continue;
+				}
 				for (int k = 0; k < 3; ++k) {
 					const uint32_t v = sc->tri_idx[3 * (size_t) t + k];
 					std::memcpy(P + 3 * k, sc->vtx_pos + 3 * (size_t) v, 12);
@@ -458,6 +501,16 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	rc |= upload(c, &d.shape_bsdf, sc->shape_bsdf, sc->n_shapes);
 	rc |= upload(c, &d.shape_lum, sc->shape_lum, sc->n_shapes);
 	rc |= upload(c, &d.shape_flags, sc->shape_flags, sc->n_shapes);
+	{
+		std::vector<uint32_t> st(sc->n_shapes + 1, (uint32_t) MTSGPU_SHAPE_TRIMESH);
+		std::vector<float> sp((size_t) MTSGPU_SHAPE_NPARAMS * (sc->n_shapes + 1), 0.0f);
+		if (sc->shape_type) {
+			std::copy(sc->shape_type, sc->shape_type + sc->n_shapes, st.begin());
+			std::copy(sc->shape_params, sc->shape_params + (size_t) MTSGPU_SHAPE_NPARAMS * sc->n_shapes, sp.begin());
+		}
+		rc |= upload(c, &d.shape_type, st.data(), st.size());
+		rc |= upload(c, &d.shape_params, sp.data(), sp.size());
+	}
 	rc |= upload(c, &d.shape_tri_offset, sc->shape_tri_offset, (size_t) sc->n_shapes + 1);
 	rc |= upload(c, &d.bsdf_type, sc->bsdf_type, sc->n_bsdfs);
 	rc |= upload(c, &d.bsdf_params, sc->bsdf_params, (size_t) MTSGPU_BSDF_NPARAMS * sc->n_bsdfs);

@@ -71,7 +71,16 @@ float buildCdf(const std::vector<float> &values, float *cdf, float *pdf) {
 void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatScene &fs) {
 	const uint32_t nShapes = d.n_meshes, nLums = d.n_lums;
 	size_t nVerts = 0, nTris = 0;
-	for (uint32_t s = 0; s < nShapes; ++s) { nVerts += d.meshes[s].n_verts; nTris += d.meshes[s].n_tris; }
+	// m_shapeMap (skdtree.cpp:43-60): a TriMesh contributes its triangles, any other shape ONE primitive
+	for (uint32_t s = 0; s < nShapes; ++s) {
+		const bool sphere = d.meshes[s].shape_type == MTSGPU_SHAPE_SPHERE;
+		if (!sphere && d.meshes[s].shape_type != MTSGPU_SHAPE_TRIMESH)
+			throw std::runtime_error("flatten: unknown shape type");
+		nVerts += sphere ? 0 : d.meshes[s].n_verts; nTris += sphere ? 1 : d.meshes[s].n_tris;
+	}
+	std::vector<float> genBox(6 * nTris + 6, 0.0f);
+	fs.shapeType.assign(nShapes + 1, (uint32_t) MTSGPU_SHAPE_TRIMESH);
+	fs.shapeParams.assign((size_t) MTSGPU_SHAPE_NPARAMS * (nShapes + 1), 0.0f);
 	if (nTris >= 0x7FFFFFFFull || nVerts >= 0xFFFFFFFFull)
 		throw std::runtime_error("flatten: too many primitives");
 	fs.vtxPos.assign(3 * nVerts + 3, 0.0f);
@@ -103,6 +112,28 @@ void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatSc
 		fs.shapeTriOffset[s] = tbase;
 		fs.shapeBsdf[s] = m.bsdf;
 		fs.shapeLum[s] = m.lum;
+		if (m.lum >= 0) {
+			if (fs.lumShape[m.lum] >= 0 || fs.lumType[m.lum] != MTSGPU_LUM_AREA)
+				throw std::runtime_error("flatten: area luminaire must be attached to exactly one mesh");
+			fs.lumShape[m.lum] = (int32_t) s;
+		}
+		if (m.shape_type == MTSGPU_SHAPE_SPHERE) {
+			// Sphere::Sphere with `center` + `radius` (src/shapes/sphere.cpp:44-60): objectToWorld is a translation
+			float *P = &fs.shapeParams[(size_t) MTSGPU_SHAPE_NPARAMS * s];
+			fs.shapeType[s] = MTSGPU_SHAPE_SPHERE;
+			const float r = m.sphere_radius;
+			if (!(r != 0.0f) || !std::isfinite(r))
+				throw std::runtime_error("flatten: sphere radius must be finite and non-zero");
+			for (int i = 0; i < 3; ++i) P[i] = m.sphere_center[i];          // m_objectToWorld(Point(0,0,0))
+			P[3] = r; P[4] = m.sphere_inverted ? 1.0f : 0.0f;
+			P[5] = P[9] = P[13] = 1.0f; P[14] = P[18] = P[22] = 1.0f;
+			P[23] = 1 / (4 * kPi * r * r);                                  // m_invSurfaceArea
+			const float absRadius = std::fabs(r);                           // Sphere::getAABB (sphere.cpp:82-88)
+			for (int i = 0; i < 3; ++i) { genBox[6 * (size_t) tbase + i] = P[i] - absRadius; genBox[6 * (size_t) tbase + 3 + i] = P[i] + absRadius; }
+			for (int k = 0; k < 3; ++k) fs.triIdx[3 * (size_t) tbase + k] = MTSGPU_KNOTRIANGLE;
+			tbase += 1;
+			continue;
+		}
 		std::memcpy(&fs.vtxPos[3 * (size_t) vbase], m.positions, sizeof(float) * 3 * (size_t) m.n_verts);
 		if (!m.face_normals) {
 			fs.shapeFlags[s] |= MTSGPU_SHAPE_HAS_NORMALS;
@@ -116,21 +147,22 @@ void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatSc
 				throw std::runtime_error("flatten: triangle index out of range");
 			fs.triIdx[3 * (size_t) tbase + k] = m.triangles[k] + vbase;
 		}
-		if (m.lum >= 0) {
-			if (fs.lumShape[m.lum] >= 0 || fs.lumType[m.lum] != MTSGPU_LUM_AREA)
-				throw std::runtime_error("flatten: area luminaire must be attached to exactly one mesh");
-			fs.lumShape[m.lum] = (int32_t) s;
-		}
 		vbase += m.n_verts; tbase += m.n_tris;
 	}
 	fs.shapeTriOffset[nShapes] = tbase;
 
 	// kd-tree + TriAccel table (ShapeKDTree::build, skdtree.cpp:62-101)
-	buildKdTree(fs.vtxPos.data(), fs.triIdx.data(), tbase, kp, fs.kd);
+	buildKdTree(fs.vtxPos.data(), fs.triIdx.data(), tbase, genBox.data(), kp, fs.kd);
 	for (uint32_t s = 0; s < nShapes; ++s)
 		for (uint32_t t = fs.shapeTriOffset[s]; t < fs.shapeTriOffset[s + 1]; ++t) {
 			const uint32_t *tri = &fs.triIdx[3 * (size_t) t];
 			uint32_t *ta = &fs.triaccel[12 * (size_t) t];
+			if (fs.shapeType[s] != MTSGPU_SHAPE_TRIMESH) {
+				// a 'fake' triangle which redirects to the Shape (skdtree.cpp:92-96)
+				std::memset(ta, 0, 48);
+				ta[0] = MTSGPU_KNOTRIANGLE; ta[10] = s;
+				continue;
+			}
 			triAccelLoad(ld3(&fs.vtxPos[3 * (size_t) tri[0]]), ld3(&fs.vtxPos[3 * (size_t) tri[1]]), ld3(&fs.vtxPos[3 * (size_t) tri[2]]), ta);
 			ta[10] = s;
 			ta[11] = t - fs.shapeTriOffset[s];
@@ -149,7 +181,8 @@ void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatSc
 			if (fs.lumShape[l] < 0)
 				throw std::runtime_error("flatten: area luminaire without a mesh");
 			const uint32_t s = (uint32_t) fs.lumShape[l];
-			cdfTotal += fs.shapeTriOffset[s + 1] - fs.shapeTriOffset[s] + 1;
+			if (fs.shapeType[s] == MTSGPU_SHAPE_TRIMESH)
+				cdfTotal += fs.shapeTriOffset[s + 1] - fs.shapeTriOffset[s] + 1;
 		}
 	}
 	fs.lumCdfOffset[nLums] = cdfTotal;
@@ -159,6 +192,10 @@ void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatSc
 		float *P = &fs.lumParams[(size_t) MTSGPU_LUM_NPARAMS * l];
 		if (fs.lumType[l] == MTSGPU_LUM_AREA) {
 			const uint32_t s = (uint32_t) fs.lumShape[l];
+			if (fs.shapeType[s] == MTSGPU_SHAPE_SPHERE) {
+				fs.lumInvArea[l] = fs.shapeParams[(size_t) MTSGPU_SHAPE_NPARAMS * s + 23];
+				continue;
+			}
 			const uint32_t t0 = fs.shapeTriOffset[s], n = fs.shapeTriOffset[s + 1] - t0;
 			std::vector<float> areas(n);
 			for (uint32_t t = 0; t < n; ++t) {
@@ -208,6 +245,7 @@ void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatSc
 	sc.vtx_pos = fs.vtxPos.data(); sc.vtx_nrm = fs.vtxNrm.data(); sc.tri_idx = fs.triIdx.data();
 	sc.shape_tri_offset = fs.shapeTriOffset.data(); sc.shape_bsdf = fs.shapeBsdf.data();
 	sc.shape_lum = fs.shapeLum.data(); sc.shape_flags = fs.shapeFlags.data();
+	sc.shape_type = fs.shapeType.data(); sc.shape_params = fs.shapeParams.data();
 	sc.n_nodes = (uint32_t) (fs.kd.nodes.size() / 2); sc.n_indices = (uint32_t) fs.kd.indices.size();
 	if (fs.kd.indices.empty()) fs.kd.indices.push_back(0);
 	sc.kd_nodes = fs.kd.nodes.data(); sc.kd_indices = fs.kd.indices.data(); sc.triaccel = fs.triaccel.data();

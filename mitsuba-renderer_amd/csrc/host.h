@@ -15,7 +15,8 @@ struct KdTree {
 	double stats[6] = { 0, 0, 0, 0, 0, 0 };
 };
 
-void buildKdTree(const float *vtx, const uint32_t *tri, uint32_t nTris, const mtsgpu_kd_params *kp, KdTree &out);
+// genBox: [nTris][6] boxes, read for the primitives whose tri row is {MTSGPU_KNOTRIANGLE x 3}; may be NULL without such
+void buildKdTree(const float *vtx, const uint32_t *tri, uint32_t nTris, const float *genBox, const mtsgpu_kd_params *kp, KdTree &out);
 bool clippedTriangleBox(const float *p0, const float *p1, const float *p2, const float *bmin, const float *bmax,
                         float *omin, float *omax);
 
@@ -23,8 +24,8 @@ bool clippedTriangleBox(const float *p0, const float *p1, const float *p2, const
 struct FlatScene {
 	mtsgpu_scene sc;
 	KdTree kd;
-	std::vector<float> vtxPos, vtxNrm, bsdfParams, lumParams, lumInvArea, lumTriCdf, lumSelCdf, lumSelPdf;
-	std::vector<uint32_t> triIdx, shapeTriOffset, shapeFlags, triaccel, bsdfType, lumType, lumCdfOffset;
+	std::vector<float> vtxPos, vtxNrm, shapeParams, bsdfParams, lumParams, lumInvArea, lumTriCdf, lumSelCdf, lumSelPdf;
+	std::vector<uint32_t> triIdx, shapeTriOffset, shapeFlags, shapeType, triaccel, bsdfType, lumType, lumCdfOffset;
 	std::vector<int32_t> shapeBsdf, shapeLum, lumShape;
 };
 

@@ -143,12 +143,22 @@ struct Params {
 
 struct Geometry {
 	const float *vtx; const uint32_t *tri;
+	const float *genBox;     // [n][6] boxes of the non-triangle primitives (tri row = {NONE, NONE, NONE})
 	void box(uint32_t i, Box &b) const {
 		const uint32_t *t = tri + 3 * (size_t) i;
+		if (t[0] == MTSGPU_KNOTRIANGLE) {            // shape->getAABB() (skdtree.h:203-213)
+			for (int a = 0; a < 3; ++a) { b.mn[a] = genBox[6 * (size_t) i + a]; b.mx[a] = genBox[6 * (size_t) i + 3 + a]; }
+			return;
+		}
 		b.reset(); b.expand(vtx + 3 * (size_t) t[0]); b.expand(vtx + 3 * (size_t) t[1]); b.expand(vtx + 3 * (size_t) t[2]);
 	}
 	bool clipped(uint32_t i, const Box &to, Box &b) const {
 		const uint32_t *t = tri + 3 * (size_t) i;
+		if (t[0] == MTSGPU_KNOTRIANGLE) {            // Shape::getClippedAABB (shape.cpp:59-63): getAABB().clip(box)
+			box(i, b);
+			b.clip(to);
+			return b.valid();
+		}
 		return clippedTriangleBox(vtx + 3 * (size_t) t[0], vtx + 3 * (size_t) t[1], vtx + 3 * (size_t) t[2], to.mn, to.mx, b.mn, b.mx);
 	}
 };
@@ -572,7 +582,7 @@ int log2i(uint32_t v) { int r = 0; while (v >>= 1) r++; return r; }
 
 } // namespace
 
-void buildKdTree(const float *vtx, const uint32_t *tri, uint32_t nTris, const mtsgpu_kd_params *kp, KdTree &out) {
+void buildKdTree(const float *vtx, const uint32_t *tri, uint32_t nTris, const float *genBox, const mtsgpu_kd_params *kp, KdTree &out) {
 	Params p;
 	p.traversalCost = (kp && kp->traversal_cost > 0) ? kp->traversal_cost : 15;      // gkdtree.h:711-724
 	p.queryCost = (kp && kp->query_cost > 0) ? kp->query_cost : 20;
@@ -595,7 +605,7 @@ void buildKdTree(const float *vtx, const uint32_t *tri, uint32_t nTris, const mt
 		p.maxDepth = (uint32_t) (int) (8 + 1.3f * log2i(nTris));                       // gkdtree.h:945-947
 	p.maxDepth = std::min(p.maxDepth, 48u);
 
-	const Geometry g{ vtx, tri };
+	const Geometry g{ vtx, tri, genBox };
 	Builder b(g, p, nTris);
 	b.m_parallel = nTris > p.exactPrimThreshold;
 	Box scene; scene.reset();

@@ -28,6 +28,8 @@ struct DScene {
 	const float4   *tri_pos;
 	const float4   *tri_nrm;
 	const int32_t  *shape_bsdf, *shape_lum;
+	const uint32_t *shape_type;   // MTSGPU_SHAPE_*
+	const float    *shape_params; // [n_shapes][24]
 	const uint32_t *shape_flags, *shape_tri_offset;
 	const uint32_t *bsdf_type;
 	const float    *bsdf_params;

@@ -191,6 +191,65 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 	queue[id] = id;
 }
 
+
+// ===========================================================================
+// Sphere shape (src/shapes/sphere.cpp).  SP = shape parameter block:
+// [0..2] centre [3] radius [4] inverted [5..13] objectToWorld 3x3 [14..22] worldToObject 3x3 [23] 1/area
+// ===========================================================================
+// solveQuadratic (src/libcore/util.cpp:450-488)
+__device__ __forceinline__ bool solve_quadratic(float a, float b, float c, float &x0, float &x1) {
+	if (a == 0) {
+		if (b != 0) { x0 = x1 = -c / b; return true; }
+		return false;
+	}
+	const float discrim = b * b - 4.0f * a * c;
+	if (discrim < 0)
+		return false;
+	const float sqrtDiscrim = sqrtf(discrim);
+	float temp;
+	if (b < 0) temp = -0.5f * (b - sqrtDiscrim);
+	else       temp = -0.5f * (b + sqrtDiscrim);
+	x0 = temp / a;
+	x1 = c / temp;
+	if (x0 > x1) { const float t = x0; x0 = x1; x1 = t; }
+	return true;
+}
+// the quadratic of Sphere::rayIntersect (sphere.cpp:94-101)
+__device__ __forceinline__ bool sphere_roots(V3 center, float radius, V3 ro, V3 rd, float &nearT, float &farT) {
+	const V3 o = ro - center;
+	const float A = rd.x * rd.x + rd.y * rd.y + rd.z * rd.z;
+	const float B = 2 * (rd.x * o.x + rd.y * o.y + rd.z * o.z);
+	const float C = o.x * o.x + o.y * o.y + o.z * o.z - radius * radius;
+	return solve_quadratic(A, B, C, nearT, farT);
+}
+// Sphere::rayIntersect(ray, mint, maxt, t, tmp) (sphere.cpp:94-116)
+__device__ __forceinline__ bool sphere_intersect(V3 center, float radius, V3 ro, V3 rd, float mint, float maxt, float &t) {
+	float nearT, farT;
+	if (!sphere_roots(center, radius, ro, rd, nearT, farT))
+		return false;
+	if (nearT > maxt || farT < mint)
+		return false;
+	if (nearT < mint) {
+		if (farT > maxt)
+			return false;
+		t = farT;
+	} else {
+		t = nearT;
+	}
+	return true;
+}
+// Sphere::rayIntersect(ray, mint, maxt) (sphere.cpp:118-134)
+__device__ __forceinline__ bool sphere_occludes(V3 center, float radius, V3 ro, V3 rd, float mint, float maxt) {
+	float nearT, farT;
+	if (!sphere_roots(center, radius, ro, rd, nearT, farT))
+		return false;
+	if (nearT > maxt || farT < mint)
+		return false;
+	if (nearT < mint && farT > maxt)
+		return false;
+	return true;
+}
+
 // ===========================================================================
 // K2/K4: kd-tree traversal.
 // ShapeKDTree::rayIntersect (src/librender/skdtree.cpp:108-132, :180-199) +
@@ -453,9 +512,25 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 						// every entry (selects, no branches) and masked afterwards; only the barycentric part, which
 						// needs the rest of the record, is conditional.
 						uint32_t *mslot = &s_mbox[prim & 7u][tid];
-						bool ok = (*mslot != prim) && (k != 3u);                  // not in the mailbox, not degenerate
-						if (MODE != 0 && (A.x & 0x20000000u)) ok = false;         // shape->isOccluder() (skdtree.h:318-333)
-						if (COUNT && *mslot != prim) c_tri++;
+						const bool fresh = *mslot != prim;                        // not in the mailbox
+						const bool occl = !(MODE != 0 && (A.x & 0x20000000u));   // shape->isOccluder() (skdtree.h:318-333)
+						const bool ok = fresh && occl && (k != 3u);               // k == 3: degenerate triangle or another shape
+						if (COUNT && fresh) c_tri++;
+						if (k == 3u && A.y != 0u && fresh && occl) {
+							// a non-triangle shape (skdtree.h:287-296 / :328-332); A.y = shape type, B = centre + radius
+							const uint4 B = sc.leaf_ta[3 * (size_t) e + 1];
+							const V3 ctr(__uint_as_float(B.x), __uint_as_float(B.y), __uint_as_float(B.z));
+							const float rad = __uint_as_float(B.w);
+							if (MODE != 0) {
+								if (sphere_occludes(ctr, rad, V3(ox, oy, oz), V3(dx, dy, dz), mint, maxt)) hitShadow = true;
+							} else {
+								float ts;
+								if (sphere_intersect(ctr, rad, V3(ox, oy, oz), V3(dx, dy, dz), mint, maxt, ts)) {
+									maxt = ts;
+									best_t = ts; best_u = 0.0f; best_v = 0.0f; best_prim = prim; best_shape = e;
+								}
+							}
+						}
 						const bool k0 = k == 0u, k1 = k == 1u;
 						const float n_u = __uint_as_float(A.y), n_v = __uint_as_float(A.z), n_d = __uint_as_float(A.w);
 						const float o_u = k0 ? oy : (k1 ? oz : ox), o_v = k0 ? oz : (k1 ? ox : oy), o_k = k0 ? ox : (k1 ? oy : oz);
@@ -545,9 +620,43 @@ struct Its {
 };
 
 // fillIntersectionRecord<true> (include/mitsuba/render/skdtree.h:352-432)
-__device__ __forceinline__ void fill_its(const DScene &sc, V3 rayD, uint32_t prim, float u, float v, Its &its) {
+__device__ __forceinline__ void fill_its(const DScene &sc, V3 rayO, V3 rayD, float t, uint32_t prim, float u, float v, Its &its) {
 	const float4 *TP = sc.tri_pos + 3 * (size_t) prim;
 	const float4 t0 = TP[0], t1 = TP[1], t2 = TP[2];
+	V3 sS, sT;
+	if (__float_as_uint(t2.w) & 0x80000000u) {
+		// Sphere::fillIntersectionRecord (src/shapes/sphere.cpp:136-178): its.p = ray(t), frame from dpdu / dpdv
+		its.shape = __float_as_uint(t2.z);
+		const float *SP = sc.shape_params + 24 * (size_t) its.shape;
+		const float *O2W = SP + 5, *W2O = SP + 14;
+		const V3 center(SP[0], SP[1], SP[2]);
+		const float radius = SP[3];
+		its.p = V3(rayO.x + t * rayD.x, rayO.y + t * rayD.y, rayO.z + t * rayD.z);
+		const V3 pc = its.p - center;
+		const V3 local(W2O[0] * pc.x + W2O[1] * pc.y + W2O[2] * pc.z, W2O[3] * pc.x + W2O[4] * pc.y + W2O[5] * pc.z,
+		               W2O[6] * pc.x + W2O[7] * pc.y + W2O[8] * pc.z);
+		const float theta = dacos(smin(smax(local.z / radius, -1.0f), 1.0f));
+		const V3 du(-local.y * (2 * kPi), local.x * (2 * kPi), 0 * (2 * kPi));
+		const V3 dpdu(O2W[0] * du.x + O2W[1] * du.y + O2W[2] * du.z, O2W[3] * du.x + O2W[4] * du.y + O2W[5] * du.z,
+		              O2W[6] * du.x + O2W[7] * du.y + O2W[8] * du.z);
+		V3 n = normalize(pc);
+		const float zrad = sqrtf(local.x * local.x + local.y * local.y);
+		if (zrad > 0) {
+			const float invZRad = 1.0f / zrad, cosPhi = local.x * invZRad, sinPhi = local.y * invZRad;
+			float st, ct;
+			dsincos(theta, st, ct);
+			const V3 dv((local.z * cosPhi) * kPi, (local.z * sinPhi) * kPi, (-st * radius) * kPi);
+			const V3 dpdv(O2W[0] * dv.x + O2W[1] * dv.y + O2W[2] * dv.z, O2W[3] * dv.x + O2W[4] * dv.y + O2W[5] * dv.z,
+			              O2W[6] * dv.x + O2W[7] * dv.y + O2W[8] * dv.z);
+			sS = normalize(dpdu);
+			sT = normalize(dpdv);
+		} else {
+			coordinateSystem(n, sS, sT);
+		}
+		if (SP[4] != 0.0f)
+			n = V3(n.x * -1, n.y * -1, n.z * -1);
+		its.geoN = n; its.shN = n;
+	} else {
 	const V3 p0(t0.x, t0.y, t0.z), p1(t0.w, t1.x, t1.y), p2(t1.z, t1.w, t2.x);
 	const float bx = 1 - u - v, by = u, bz = v;
 	its.p = V3(p0.x * bx + p1.x * by + p2.x * bz, p0.y * bx + p1.y * by + p2.y * bz, p0.z * bx + p1.z * by + p2.z * bz);
@@ -565,7 +674,9 @@ __device__ __forceinline__ void fill_its(const DScene &sc, V3 rayD, uint32_t pri
 	} else {
 		its.shN = its.geoN;
 	}
-	coordinateSystem(its.shN, its.shS, its.shT);
+	coordinateSystem(its.shN, sS, sT);
+	}
+	its.shS = sS; its.shT = sT;
 	const V3 md = -rayD;
 	its.wi = V3(dot(md, its.shS), dot(md, its.shT), dot(md, its.shN));
 }
@@ -617,7 +728,54 @@ __device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s
 	const int l = dpdf_sample_reuse(sc.lum_sel_cdf, sc.n_lums, sx);
 	const float lumPdf = sc.lum_sel_pdf[l];
 	const float *LP = sc.lum_params + 24 * (size_t) l;
-	if (sc.lum_type[l] == 0u) {
+	if (sc.lum_type[l] == 0u && sc.shape_type[sc.lum_shape[l]] == 1u) {
+		// AreaLuminaire::sample (area.cpp:68-79) -> Sphere::sampleSolidAngle (src/shapes/sphere.cpp:196-237)
+		const float *SP = sc.shape_params + 24 * (size_t) sc.lum_shape[l];
+		const V3 center(SP[0], SP[1], SP[2]);
+		const float radius = SP[3];
+		const V3 w = center - p;
+		const float invDistW = 1 / length(w);
+		const float squareTerm = fabsf(radius * invDistW);
+		if (squareTerm >= 1 - kEpsilon) {
+			// inside the sphere: uniform sampling
+			const V3 d = squareToSphere(sx, sy);
+			lRec.p = V3(center.x + d.x * radius, center.y + d.y * radius, center.z + d.z * radius);
+			lRec.n = d;
+			const V3 lumToPoint = p - lRec.p;
+			const float distSquared = dot(lumToPoint, lumToPoint), dp = dot(lumToPoint, lRec.n);
+			lRec.pdf = (dp > 0) ? (SP[23] * distSquared * sqrtf(distSquared) / dp) : 0.0f;
+		} else {
+			const float cosThetaMax = sqrtf(smax(0.0f, 1 - squareTerm * squareTerm));
+			// squareToCone (util.cpp:656-662)
+			const float cosTheta = (1 - sx) + sx * cosThetaMax;
+			const float sinTheta = sqrtf(1 - cosTheta * cosTheta);
+			const float phi = sy * (2 * kPi);
+			float sphi, cphi;
+			dsincos(phi, sphi, cphi);
+			const V3 cone(cphi * sinTheta, sphi * sinTheta, cosTheta);
+			// Frame(w * invDistW).toWorld(cone)
+			const V3 fn = w * invDistW;
+			V3 fs, ft;
+			coordinateSystem(fn, fs, ft);
+			const V3 d(fs.x * cone.x + ft.x * cone.y + fn.x * cone.z, fs.y * cone.x + ft.y * cone.y + fn.y * cone.z,
+			           fs.z * cone.x + ft.z * cone.y + fn.z * cone.z);
+			float t;
+			if (!sphere_intersect(center, radius, p, d, 0.0f, MG_INF, t)) {
+				lRec.pdf = 0.0f;         // roundoff: no sample
+			} else {
+				lRec.p = V3(p.x + t * d.x, p.y + t * d.y, p.z + t * d.z);
+				lRec.n = normalize(lRec.p - center);
+				lRec.pdf = 1 / ((2 * kPi) * (1 - cosThetaMax));
+			}
+		}
+		lRec.d = p - lRec.p;
+		if (lRec.pdf > 0 && dot(lRec.d, lRec.n) > 0) {
+			lRec.value = V3(LP[0], LP[1], LP[2]);
+			lRec.d = normalize(lRec.d);
+		} else {
+			lRec.pdf = 0;
+		}
+	} else if (sc.lum_type[l] == 0u) {
 		// AreaLuminaire::sample (area.cpp:68-79) -> Shape::sampleSolidAngle (shape.cpp:65-75)
 		// -> TriMesh::sampleArea (trimesh.cpp:297-302) -> Triangle::sample (triangle.cpp:23-47)
 		const uint32_t s = (uint32_t) sc.lum_shape[l];
@@ -707,7 +865,21 @@ __device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s
 __device__ __forceinline__ float pdf_luminaire(const DScene &sc, V3 p, int lum, V3 lp, V3 ln) {
 	const float fraction = 1.0f / sc.lum_sel_sum;
 	float pdf;
-	if (sc.lum_type[lum] == 0u) {
+	if (sc.lum_type[lum] == 0u && sc.shape_type[sc.lum_shape[lum]] == 1u) {
+		// Sphere::pdfSolidAngle (sphere.cpp:239-255)
+		const float *SP = sc.shape_params + 24 * (size_t) sc.lum_shape[lum];
+		const V3 w = p - V3(SP[0], SP[1], SP[2]);
+		const float invDistW = 1 / length(w);
+		const float squareTerm = fabsf(SP[3] * invDistW);
+		if (squareTerm >= 1 - kEpsilon) {
+			const V3 lumToPoint = p - lp;
+			const float distSquared = dot(lumToPoint, lumToPoint), dp = dot(lumToPoint, ln);
+			pdf = (dp > 0) ? (SP[23] * distSquared * sqrtf(distSquared) / dp) : 0.0f;
+		} else {
+			const float cosThetaMax = sqrtf(smax(0.0f, 1 - squareTerm * squareTerm));
+			pdf = 1 / (2 * kPi * (1 - cosThetaMax));          // squareToConePdf (util.cpp:652-654)
+		}
+	} else if (sc.lum_type[lum] == 0u) {
 		const V3 lumToPoint = p - lp;
 		const float distSquared = dot(lumToPoint, lumToPoint);
 		const float invDP = smax(0.0f, sqrtf(distSquared) / dot(lumToPoint, ln));
@@ -1050,7 +1222,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 		}
 		Its its;
 		if (valid)
-			fill_its(sc, rayD, h.w, __uint_as_float(h.y), __uint_as_float(h.z), its);
+			fill_its(sc, rayO, rayD, __uint_as_float(h.x), h.w, __uint_as_float(h.y), __uint_as_float(h.z), its);
 		const int shapeLum = valid ? sc.shape_lum[its.shape] : -1;
 
 		do {

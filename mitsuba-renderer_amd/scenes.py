@@ -18,6 +18,16 @@ class MeshDesc:
         self.triangles = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
         self.normals = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
         self.bsdf, self.lum, self.face_normals, self.name = int(bsdf), int(lum), bool(face_normals), name
+        self.shape_type, self.sphere = abi.SHAPE_TRIMESH, None
+
+
+class SphereDesc(MeshDesc):
+    """<shape type="sphere"> with `center` and `radius` (src/shapes/sphere.cpp:44-47): one kd-tree primitive"""
+
+    def __init__(self, center, radius, bsdf=-1, lum=-1, inverted=False, name="sphere"):
+        MeshDesc.__init__(self, np.zeros((0, 3)), np.zeros((0, 3), dtype=np.uint32), bsdf, lum, True, None, name)
+        self.shape_type = abi.SHAPE_SPHERE
+        self.sphere = (tuple(float(F(v)) for v in center), float(F(radius)), bool(inverted))
 
 
 class SceneDescription:
@@ -114,6 +124,10 @@ class SceneDescription:
         self.meshes.append(MeshDesc(*a, **k))
         return self.meshes[-1]
 
+    def add_sphere(self, *a, **k):
+        self.meshes.append(SphereDesc(*a, **k))
+        return self.meshes[-1]
+
     @property
     def n_tris(self):
         return sum(m.triangles.shape[0] for m in self.meshes)
@@ -133,6 +147,11 @@ class SceneDescription:
             meshes[i].face_normals = 1 if m.face_normals else 0
             meshes[i].bsdf = m.bsdf
             meshes[i].lum = m.lum
+            meshes[i].shape_type = m.shape_type
+            if m.sphere is not None:
+                meshes[i].sphere_center = (C.c_float * 3)(*m.sphere[0])
+                meshes[i].sphere_radius = m.sphere[1]
+                meshes[i].sphere_inverted = 1 if m.sphere[2] else 0
         bt = np.asarray(self.bsdf_type, dtype=np.uint32)
         bp = np.ascontiguousarray(np.stack(self.bsdf_params) if self.bsdf_params else np.zeros((0, abi.BSDF_NPARAMS)), dtype=np.float32)
         lt = np.asarray(self.lum_type, dtype=np.uint32)
@@ -326,5 +345,26 @@ def next_rows(sphere_subdiv=2):
     return sd
 
 
+def spheres():
+    """analytic `sphere` shapes (glass, mirror, diffuse, one inverted) and a sphere-shaped
+    area luminaire (Sphere::sampleSolidAngle) next to a mesh luminaire, inside the Cornell box"""
+    sd = SceneDescription("spheres")
+    white = sd.lambertian(0.73)
+    red = sd.lambertian(0.63, 0.065, 0.05)
+    green = sd.lambertian(0.14, 0.45, 0.091)
+    for name, p0, e1, e2, nrm in _box_faces():
+        pos, tri = _quad(p0, e1, e2, nrm)
+        sd.add_mesh(pos, tri, bsdf={"left": red, "right": green}.get(name, white), face_normals=True, name=name)
+    _add_light(sd, intensity=4.0)
+    sd.add_sphere((-0.45, 0.35, -0.3), 0.35, bsdf=sd.dielectric())
+    sd.add_sphere((0.5, 0.3, 0.3), 0.3, bsdf=sd.mirror(0.9))
+    sd.add_sphere((0.0, 0.2, 0.55), 0.2, bsdf=sd.lambertian(0.3, 0.4, 0.8))
+    sd.add_sphere((0.45, 1.3, -0.4), 0.25, bsdf=sd.twosided(sd.phong(30.0, 0.3, 0.5)), inverted=True)
+    lum = sd.add_lum(abi.LUM_AREA, [9.0, 7.0, 4.0])
+    sd.add_sphere((-0.55, 1.45, 0.35), 0.12, bsdf=sd.lambertian(0.0), lum=lum)
+    sd.max_depth = 8
+    return sd
+
+
 def by_name(name, **kw):
-    return {"c1": cornell_c1, "c3": cornell_c3, "c5": cornell_c5, "next": next_rows}[name](**kw)
+    return {"c1": cornell_c1, "c3": cornell_c3, "c5": cornell_c5, "next": next_rows, "spheres": spheres}[name](**kw)

@@ -65,7 +65,7 @@ typedef struct orc_kdtree {
 	double stats[6];
 } orc_kdtree;
 
-int  orc_kd_build(const float *vtx_pos, const uint32_t *tri_idx, uint32_t n_tris,
+int  orc_kd_build(const float *vtx_pos, const uint32_t *tri_idx, uint32_t n_tris, const float *gen_aabb,
                   const mtsgpu_kd_params *params, orc_kdtree *out);
 void orc_kd_free(orc_kdtree *t);
 

@@ -30,6 +30,7 @@ typedef struct {
 
 typedef struct {
 	const float *vtx; const uint32_t *tri; uint32_t primCount;
+	const float *genAABB;   /* [primCount][6]: boxes of the non-triangle primitives (tri row = {NONE,NONE,NONE}) */
 	/* parameters (gkdtree.h:711-724) */
 	float traversalCost, queryCost, emptySpaceBonus;
 	uint32_t stopPrims, maxBadRefines, exactPrimThreshold, maxDepth; int minMaxBins, clip, retract;
@@ -62,6 +63,10 @@ static float aabb_surface_area(const aabb_t *b) {
 /* Triangle::getAABB (include/mitsuba/core/triangle.h:39-44) */
 static void prim_aabb(const ctx_t *c, uint32_t idx, aabb_t *out) {
 	const uint32_t *t = c->tri + 3 * (size_t) idx;
+	if (t[0] == MTSGPU_KNOTRIANGLE) {       /* shape->getAABB() (skdtree.h:203-213) */
+		for (int i = 0; i < 3; ++i) { out->min[i] = c->genAABB[6 * (size_t) idx + i]; out->max[i] = c->genAABB[6 * (size_t) idx + 3 + i]; }
+		return;
+	}
 	aabb_reset(out);
 	aabb_expand_pt(out, c->vtx + 3 * (size_t) t[0]);
 	aabb_expand_pt(out, c->vtx + 3 * (size_t) t[1]);
@@ -70,6 +75,12 @@ static void prim_aabb(const ctx_t *c, uint32_t idx, aabb_t *out) {
 
 static int prim_clipped_aabb(const ctx_t *c, uint32_t idx, const aabb_t *box, aabb_t *out) {
 	const uint32_t *t = c->tri + 3 * (size_t) idx;
+	if (t[0] == MTSGPU_KNOTRIANGLE) {       /* Shape::getClippedAABB (shape.cpp:59-63): getAABB().clip(box) */
+		prim_aabb(c, idx, out);
+		aabb_clip(out, box);
+		for (int i = 0; i < 3; ++i) if (out->max[i] < out->min[i]) return 0;     /* AABB::isValid */
+		return 1;
+	}
 	return orc_clipped_aabb(c->vtx + 3 * (size_t) t[0], c->vtx + 3 * (size_t) t[1], c->vtx + 3 * (size_t) t[2],
 	                        box->min, box->max, out->min, out->max);
 }
@@ -569,11 +580,11 @@ static float build_tree_minmax(ctx_t *c, uint32_t depth, uint32_t node, const aa
 /* log2i (include/mitsuba/core/util.h): floor(log2(v)) */
 static int log2i_(uint32_t v) { int r = 0; while (v >>= 1) r++; return r; }
 
-int orc_kd_build(const float *vtx_pos, const uint32_t *tri_idx, uint32_t n_tris,
+int orc_kd_build(const float *vtx_pos, const uint32_t *tri_idx, uint32_t n_tris, const float *gen_aabb,
                  const mtsgpu_kd_params *kp, orc_kdtree *out) {
 	ctx_t c; memset(&c, 0, sizeof(c));
 	memset(out, 0, sizeof(*out));
-	c.vtx = vtx_pos; c.tri = tri_idx; c.primCount = n_tris;
+	c.vtx = vtx_pos; c.tri = tri_idx; c.primCount = n_tris; c.genAABB = gen_aabb;
 	/* defaults: gkdtree.h:711-724 */
 	c.traversalCost = (kp && kp->traversal_cost > 0) ? kp->traversal_cost : 15;
 	c.queryCost = (kp && kp->query_cost > 0) ? kp->query_cost : 20;

@@ -56,6 +56,65 @@ typedef struct { uint32_t shapeIndex, primIndex, prim; float u, v; } icache_t;
 
 /* rayIntersectHavran<shadowRay> (include/mitsuba/render/sahkdtree3.h:170-300) with
  * ShapeKDTree::intersect (include/mitsuba/render/skdtree.h:244-336) inlined */
+/* solveQuadratic (src/libcore/util.cpp:450-488) */
+static int solve_quadratic(float a, float b, float c, float *x0, float *x1) {
+	if (a == 0) {
+		if (b != 0) { *x0 = *x1 = -c / b; return 1; }
+		return 0;
+	}
+	float discrim = b*b - 4.0f*a*c;
+	if (discrim < 0)
+		return 0;
+	float temp, sqrtDiscrim = sqrtf(discrim);
+	if (b < 0)
+		temp = -0.5f * (b - sqrtDiscrim);
+	else
+		temp = -0.5f * (b + sqrtDiscrim);
+	*x0 = temp / a;
+	*x1 = c / temp;
+	if (*x0 > *x1) { float tmp = *x0; *x0 = *x1; *x1 = tmp; }
+	return 1;
+}
+
+/* Sphere::rayIntersect(ray, mint, maxt, t, tmp) (src/shapes/sphere.cpp:94-116); P = shape parameter block */
+static int sphere_ray_intersect(const float *P, const float ro[3], const float rd[3], float mint, float maxt, float *t) {
+	float o[3];
+	v3_sub(o, ro, P);
+	float A = rd[0]*rd[0] + rd[1]*rd[1] + rd[2]*rd[2];
+	float B = 2 * (rd[0]*o[0] + rd[1]*o[1] + rd[2]*o[2]);
+	float C = o[0]*o[0] + o[1]*o[1] + o[2]*o[2] - P[3]*P[3];
+	float nearT, farT;
+	if (!solve_quadratic(A, B, C, &nearT, &farT))
+		return 0;
+	if (nearT > maxt || farT < mint)
+		return 0;
+	if (nearT < mint) {
+		if (farT > maxt)
+			return 0;
+		*t = farT;
+	} else {
+		*t = nearT;
+	}
+	return 1;
+}
+
+/* Sphere::rayIntersect(ray, mint, maxt) (sphere.cpp:118-134) */
+static int sphere_ray_intersect_shadow(const float *P, const float ro[3], const float rd[3], float mint, float maxt) {
+	float o[3];
+	v3_sub(o, ro, P);
+	float A = rd[0]*rd[0] + rd[1]*rd[1] + rd[2]*rd[2];
+	float B = 2 * (rd[0]*o[0] + rd[1]*o[1] + rd[2]*o[2]);
+	float C = o[0]*o[0] + o[1]*o[1] + o[2]*o[2] - P[3]*P[3];
+	float nearT, farT;
+	if (!solve_quadratic(A, B, C, &nearT, &farT))
+		return 0;
+	if (nearT > maxt || farT < mint)
+		return 0;
+	if (nearT < mint && farT > maxt)
+		return 0;
+	return 1;
+}
+
 static int havran(const mtsgpu_scene *sc, const ray_t *ray, float mint, float maxt, float *t,
                   icache_t *cache, int shadowRay, orc_trace_counts *cnt) {
 	kdstack_t stack[KD_MAXDEPTH + 2];
@@ -120,7 +179,19 @@ static int havran(const mtsgpu_scene *sc, const ray_t *ray, float mint, float ma
 			const uint32_t *ta = sc->triaccel + 12 * (size_t) primIdx;
 			float tempU, tempV, tempT;
 			int result;
-			if (!shadowRay) {
+			if (ta[0] == MTSGPU_KNOTRIANGLE) {
+				/* non-triangle shape (skdtree.h:287-296 / :328-332) */
+				const float *SP = sc->shape_params + MTSGPU_SHAPE_NPARAMS * (size_t) ta[10];
+				if (!shadowRay) {
+					result = sphere_ray_intersect(SP, ray->o, ray->d, mint, maxt, t);
+					if (result) {
+						cache->shapeIndex = ta[10]; cache->primIndex = MTSGPU_KNOTRIANGLE; cache->prim = primIdx;
+						cache->u = cache->v = 0.0f;
+					}
+				} else {
+					result = sc->shape_bsdf[ta[10]] >= 0 && sphere_ray_intersect_shadow(SP, ray->o, ray->d, mint, maxt);
+				}
+			} else if (!shadowRay) {
 				result = orc_triaccel_intersect(ta, ray->o, ray->d, mint, maxt, &tempU, &tempV, &tempT);
 				if (result) {
 					*t = tempT;
@@ -167,7 +238,43 @@ static int kd_clip(const mtsgpu_scene *sc, const ray_t *ray, int closest, float 
 }
 
 /* fillIntersectionRecord<true> (include/mitsuba/render/skdtree.h:352-432) */
+/* Sphere::fillIntersectionRecord (src/shapes/sphere.cpp:136-178); uv / dpdu / dpdv only matter through the frame */
+static void sphere_fill_its(const float *P, const ray_t *ray, its_t *its) {
+	const float *O2W = P + 5, *W2O = P + 14;
+	const float radius = P[3];
+	for (int i = 0; i < 3; ++i) its->p[i] = ray->o[i] + its->t * ray->d[i];
+	float pc[3], local[3];
+	v3_sub(pc, its->p, P);
+	for (int i = 0; i < 3; ++i) local[i] = W2O[3*i] * pc[0] + W2O[3*i+1] * pc[1] + W2O[3*i+2] * pc[2];   /* transform.h:163-170 */
+	const float theta = orc_acosf(fminf_(fmaxf_(local[2] / radius, -(float) 1), (float) 1));
+	/* its.dpdu = m_objectToWorld(Vector(-local.y, local.x, 0) * (2*M_PI)) */
+	float du[3] = { -local[1] * (2*ORC_PI), local[0] * (2*ORC_PI), 0 * (2*ORC_PI) }, dpdu[3], dpdv[3];
+	for (int i = 0; i < 3; ++i) dpdu[i] = O2W[3*i] * du[0] + O2W[3*i+1] * du[1] + O2W[3*i+2] * du[2];
+	v3_normalize(its->geoN, pc);
+	const float zrad = sqrtf(local[0]*local[0] + local[1]*local[1]);
+	if (zrad > 0) {
+		const float invZRad = 1.0f / zrad, cosPhi = local[0] * invZRad, sinPhi = local[1] * invZRad;
+		float dv[3] = { (local[2] * cosPhi) * ORC_PI, (local[2] * sinPhi) * ORC_PI, (-orc_sinf(theta) * radius) * ORC_PI };
+		for (int i = 0; i < 3; ++i) dpdv[i] = O2W[3*i] * dv[0] + O2W[3*i+1] * dv[1] + O2W[3*i+2] * dv[2];
+		v3_normalize(its->geoS, dpdu);
+		v3_normalize(its->geoT, dpdv);
+	} else {
+		orc_coordinate_system(its->geoN, its->geoS, its->geoT);
+	}
+	if (P[4] != 0.0f)
+		for (int i = 0; i < 3; ++i) its->geoN[i] *= -1;
+	for (int i = 0; i < 3; ++i) { its->shN[i] = its->geoN[i]; its->shS[i] = its->geoS[i]; its->shT[i] = its->geoT[i]; }
+	float md[3] = { -ray->d[0], -ray->d[1], -ray->d[2] };
+	its->wi[0] = v3_dot(md, its->shS); its->wi[1] = v3_dot(md, its->shT); its->wi[2] = v3_dot(md, its->shN);
+}
+
 static void fill_its(const mtsgpu_scene *sc, const ray_t *ray, const icache_t *cache, its_t *its) {
+	if (cache->primIndex == MTSGPU_KNOTRIANGLE) {
+		sphere_fill_its(sc->shape_params + MTSGPU_SHAPE_NPARAMS * (size_t) cache->shapeIndex, ray, its);
+		its->shape = cache->shapeIndex;
+		its->prim = cache->prim;
+		return;
+	}
 	const uint32_t *tri = sc->tri_idx + 3 * (size_t) cache->prim;
 	const float b[3] = { 1 - cache->u - cache->v, cache->u, cache->v };
 	const float *p0 = sc->vtx_pos + 3 * (size_t) tri[0];
@@ -310,7 +417,57 @@ static int bsphere_ray_intersect(const float center[3], float radius, const floa
 /* Luminaire::sample for the two plugins (src/luminaires/area.cpp:68-79, constant.cpp:73-87) */
 static void luminaire_sample(const mtsgpu_scene *sc, int l, const float p[3], lrec_t *lRec, const float sample[2]) {
 	const float *P = sc->lum_params + MTSGPU_LUM_NPARAMS * (size_t) l;
-	if (sc->lum_type[l] == MTSGPU_LUM_AREA) {
+	if (sc->lum_type[l] == MTSGPU_LUM_AREA && sc->shape_type && sc->shape_type[sc->lum_shape[l]] == MTSGPU_SHAPE_SPHERE) {
+		/* Sphere::sampleSolidAngle (src/shapes/sphere.cpp:196-237), then AreaLuminaire::sample (area.cpp:68-79) */
+		const float *SP = sc->shape_params + MTSGPU_SHAPE_NPARAMS * (size_t) sc->lum_shape[l];
+		const float radius = SP[3];
+		float w[3];
+		v3_sub(w, SP, p);
+		const float invDistW = 1 / v3_length(w);
+		const float squareTerm = fabsf(radius * invDistW);
+		if (squareTerm >= 1 - ORC_EPS) {
+			/* inside the sphere: uniform sampling */
+			float d[3];
+			orc_square_to_sphere(sample, d);
+			for (int i = 0; i < 3; ++i) { lRec->p[i] = SP[i] + d[i] * radius; lRec->n[i] = d[i]; }
+			float lumToPoint[3];
+			v3_sub(lumToPoint, p, lRec->p);
+			float distSquared = v3_dot(lumToPoint, lumToPoint), dp = v3_dot(lumToPoint, lRec->n);
+			if (dp > 0)
+				lRec->pdf = SP[23] * distSquared * sqrtf(distSquared) / dp;
+			else
+				lRec->pdf = 0;
+		} else {
+			const float cosThetaMax = sqrtf(fmaxf_((float) 0, 1 - squareTerm*squareTerm));
+			/* squareToCone (util.cpp:656-662) */
+			const float cosTheta = (1 - sample[0]) + sample[0] * cosThetaMax;
+			const float sinTheta = sqrtf(1 - cosTheta * cosTheta);
+			const float phi = sample[1] * (2 * ORC_PI);
+			const float cone[3] = { orc_cosf(phi) * sinTheta, orc_sinf(phi) * sinTheta, cosTheta };
+			/* Frame(w*invDistW).toWorld(cone) (frame.h:44-60) */
+			float fn[3], fs[3], ft[3], d[3];
+			v3_scale(fn, w, invDistW);
+			orc_coordinate_system(fn, fs, ft);
+			for (int i = 0; i < 3; ++i) d[i] = fs[i] * cone[0] + ft[i] * cone[1] + fn[i] * cone[2];
+			float t;
+			if (!sphere_ray_intersect(SP, p, d, 0, INFINITY, &t)) {
+				lRec->pdf = 0;       /* roundoff: no sample */
+			} else {
+				for (int i = 0; i < 3; ++i) lRec->p[i] = p[i] + t * d[i];
+				float pc[3];
+				v3_sub(pc, lRec->p, SP);
+				v3_normalize(lRec->n, pc);
+				lRec->pdf = 1 / ((2 * ORC_PI) * (1 - cosThetaMax));
+			}
+		}
+		v3_sub(lRec->d, p, lRec->p);
+		if (lRec->pdf > 0 && v3_dot(lRec->d, lRec->n) > 0) {
+			lRec->value[0] = P[0]; lRec->value[1] = P[1]; lRec->value[2] = P[2];
+			v3_normalize(lRec->d, lRec->d);
+		} else {
+			lRec->pdf = 0;
+		}
+	} else if (sc->lum_type[l] == MTSGPU_LUM_AREA) {
 		/* Shape::sampleSolidAngle (shape.cpp:65-75) -> TriMesh::sampleArea (trimesh.cpp:297-302) */
 		const uint32_t s = (uint32_t) sc->lum_shape[l];
 		const uint32_t t0 = sc->shape_tri_offset[s], nT = sc->shape_tri_offset[s+1] - t0;
@@ -431,7 +588,26 @@ static float scene_pdf_luminaire(const mtsgpu_scene *sc, const float p[3], const
 	const float luminance = 1.0f;   /* getSamplingWeight(), luminaire.cpp:33 */
 	const float fraction = luminance / sc->lum_sel_sum;
 	float pdf;
-	if (sc->lum_type[lRec->lum] == MTSGPU_LUM_AREA) {
+	if (sc->lum_type[lRec->lum] == MTSGPU_LUM_AREA && sc->shape_type && sc->shape_type[sc->lum_shape[lRec->lum]] == MTSGPU_SHAPE_SPHERE) {
+		/* Sphere::pdfSolidAngle (sphere.cpp:239-255) */
+		const float *SP = sc->shape_params + MTSGPU_SHAPE_NPARAMS * (size_t) sc->lum_shape[lRec->lum];
+		float w[3];
+		v3_sub(w, p, SP);
+		const float invDistW = 1 / v3_length(w);
+		const float squareTerm = fabsf(SP[3] * invDistW);
+		if (squareTerm >= 1 - ORC_EPS) {
+			float lumToPoint[3];
+			v3_sub(lumToPoint, p, lRec->p);
+			float distSquared = v3_dot(lumToPoint, lumToPoint), dp = v3_dot(lumToPoint, lRec->n);
+			if (dp > 0)
+				pdf = SP[23] * distSquared * sqrtf(distSquared) / dp;
+			else
+				pdf = 0;
+		} else {
+			const float cosThetaMax = sqrtf(fmaxf_((float) 0, 1 - squareTerm*squareTerm));
+			pdf = 1 / (2 * ORC_PI * (1 - cosThetaMax));       /* squareToConePdf (util.cpp:652-654) */
+		}
+	} else if (sc->lum_type[lRec->lum] == MTSGPU_LUM_AREA) {
 		float lumToPoint[3];
 		v3_sub(lumToPoint, p, lRec->p);
 		float distSquared = v3_dot(lumToPoint, lumToPoint);

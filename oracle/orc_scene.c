@@ -11,6 +11,7 @@ struct orc_flat_scene {
 	float *vtx_pos, *vtx_nrm;
 	uint32_t *tri_idx, *shape_tri_offset, *shape_flags, *triaccel;
 	int32_t *shape_bsdf, *shape_lum;
+	uint32_t *shape_type; float *shape_params;
 	uint32_t *bsdf_type; float *bsdf_params;
 	uint32_t *lum_type; float *lum_params; int32_t *lum_shape; float *lum_inv_area;
 	uint32_t *lum_cdf_offset; float *lum_tri_cdf, *lum_sel_cdf, *lum_sel_pdf;
@@ -91,7 +92,14 @@ static float discrete_pdf_build(const float *values, uint32_t n, float *cdf, flo
 int orc_flatten(const mtsgpu_scene_desc *d, const mtsgpu_kd_params *kdp, orc_flat_scene **out) {
 	orc_flat_scene *fs = (orc_flat_scene *) calloc(1, sizeof(orc_flat_scene));
 	uint32_t nShapes = d->n_meshes, nVerts = 0, nTris = 0;
-	for (uint32_t s = 0; s < nShapes; ++s) { nVerts += d->meshes[s].n_verts; nTris += d->meshes[s].n_tris; }
+	/* m_shapeMap (skdtree.cpp:43-60): a TriMesh contributes its triangles, any other shape ONE primitive */
+	for (uint32_t s = 0; s < nShapes; ++s) {
+		const int sphere = d->meshes[s].shape_type == MTSGPU_SHAPE_SPHERE;
+		nVerts += sphere ? 0 : d->meshes[s].n_verts; nTris += sphere ? 1 : d->meshes[s].n_tris;
+	}
+	float *genAABB = (float *) calloc(6 * ((size_t) nTris + 1), sizeof(float));
+	fs->shape_type = (uint32_t *) calloc(nShapes + 1, sizeof(uint32_t));
+	fs->shape_params = (float *) calloc(MTSGPU_SHAPE_NPARAMS * ((size_t) nShapes + 1), sizeof(float));
 	fs->vtx_pos = (float *) malloc(sizeof(float) * 3 * ((size_t) nVerts + 1));
 	fs->vtx_nrm = (float *) calloc(3 * ((size_t) nVerts + 1), sizeof(float));
 	fs->tri_idx = (uint32_t *) malloc(sizeof(uint32_t) * 3 * ((size_t) nTris + 1));
@@ -125,6 +133,24 @@ int orc_flatten(const mtsgpu_scene_desc *d, const mtsgpu_kd_params *kdp, orc_fla
 		fs->shape_tri_offset[s] = tbase;
 		fs->shape_bsdf[s] = m->bsdf;
 		fs->shape_lum[s] = m->lum;
+		if (m->lum >= 0 && (uint32_t) m->lum < nLums)
+			fs->lum_shape[m->lum] = (int32_t) s;
+		if (m->shape_type == MTSGPU_SHAPE_SPHERE) {
+			/* Sphere::Sphere with `center` + `radius` (src/shapes/sphere.cpp:44-60): objectToWorld is a translation */
+			float *P = fs->shape_params + MTSGPU_SHAPE_NPARAMS * (size_t) s;
+			fs->shape_type[s] = MTSGPU_SHAPE_SPHERE;
+			const float r = m->sphere_radius;
+			for (int i = 0; i < 3; ++i) P[i] = 0.0f * 0.0f + 0.0f * 0.0f + 0.0f * 0.0f + m->sphere_center[i];    /* m_objectToWorld(Point(0,0,0)) */
+			P[3] = r; P[4] = m->sphere_inverted ? 1.0f : 0.0f;
+			P[5] = P[9] = P[13] = 1.0f;  P[14] = P[18] = P[22] = 1.0f;
+			P[23] = 1 / (4 * ORC_PI * r * r);
+			/* Sphere::getAABB (sphere.cpp:82-88) */
+			const float absRadius = fabsf(r);
+			for (int i = 0; i < 3; ++i) { genAABB[6 * (size_t) tbase + i] = P[i] - absRadius; genAABB[6 * (size_t) tbase + 3 + i] = P[i] + absRadius; }
+			for (int k = 0; k < 3; ++k) fs->tri_idx[3 * (size_t) tbase + k] = MTSGPU_KNOTRIANGLE;
+			tbase += 1;
+			continue;
+		}
 		memcpy(fs->vtx_pos + 3 * (size_t) vbase, m->positions, sizeof(float) * 3 * (size_t) m->n_verts);
 		if (!m->face_normals) {
 			fs->shape_flags[s] |= MTSGPU_SHAPE_HAS_NORMALS;
@@ -136,18 +162,23 @@ int orc_flatten(const mtsgpu_scene_desc *d, const mtsgpu_kd_params *kdp, orc_fla
 		for (uint32_t t = 0; t < m->n_tris; ++t)
 			for (int k = 0; k < 3; ++k)
 				fs->tri_idx[3 * ((size_t) tbase + t) + k] = m->triangles[3 * (size_t) t + k] + vbase;
-		if (m->lum >= 0 && (uint32_t) m->lum < nLums)
-			fs->lum_shape[m->lum] = (int32_t) s;
 		vbase += m->n_verts; tbase += m->n_tris;
 	}
 	fs->shape_tri_offset[nShapes] = tbase;
 
 	/* kd-tree over all triangles + TriAccel table (skdtree.cpp:62-101) */
-	orc_kd_build(fs->vtx_pos, fs->tri_idx, nTris, kdp, &fs->kd);
+	orc_kd_build(fs->vtx_pos, fs->tri_idx, nTris, genAABB, kdp, &fs->kd);
+	free(genAABB);
 	for (uint32_t s = 0; s < nShapes; ++s) {
 		for (uint32_t t = fs->shape_tri_offset[s]; t < fs->shape_tri_offset[s+1]; ++t) {
 			const uint32_t *tri = fs->tri_idx + 3 * (size_t) t;
 			uint32_t *ta = fs->triaccel + 12 * (size_t) t;
+			if (fs->shape_type[s] != MTSGPU_SHAPE_TRIMESH) {
+				/* a 'fake' triangle which redirects to the Shape (skdtree.cpp:92-96) */
+				memset(ta, 0, 48);
+				ta[10] = s; ta[0] = MTSGPU_KNOTRIANGLE;
+				continue;
+			}
 			orc_triaccel_load(fs->vtx_pos + 3 * (size_t) tri[0], fs->vtx_pos + 3 * (size_t) tri[1],
 			                  fs->vtx_pos + 3 * (size_t) tri[2], ta);
 			ta[10] = s;
@@ -166,7 +197,7 @@ int orc_flatten(const mtsgpu_scene_desc *d, const mtsgpu_kd_params *kdp, orc_fla
 	uint32_t cdfTotal = 0;
 	for (uint32_t l = 0; l < nLums; ++l) {
 		fs->lum_cdf_offset[l] = cdfTotal;
-		if (fs->lum_type[l] == MTSGPU_LUM_AREA && fs->lum_shape[l] >= 0) {
+		if (fs->lum_type[l] == MTSGPU_LUM_AREA && fs->lum_shape[l] >= 0 && fs->shape_type[fs->lum_shape[l]] == MTSGPU_SHAPE_TRIMESH) {
 			uint32_t s = (uint32_t) fs->lum_shape[l];
 			cdfTotal += fs->shape_tri_offset[s+1] - fs->shape_tri_offset[s] + 1;
 		}
@@ -178,8 +209,12 @@ int orc_flatten(const mtsgpu_scene_desc *d, const mtsgpu_kd_params *kdp, orc_fla
 		float *P = fs->lum_params + MTSGPU_LUM_NPARAMS * (size_t) l;
 		if (fs->lum_type[l] == MTSGPU_LUM_AREA) {
 			if (fs->lum_shape[l] < 0) { orc_flat_scene_free(fs); return MTSGPU_EINVAL; }
-			/* TriMesh::configure (trimesh.cpp:279-283) */
 			uint32_t s = (uint32_t) fs->lum_shape[l];
+			if (fs->shape_type[s] == MTSGPU_SHAPE_SPHERE) {
+				fs->lum_inv_area[l] = fs->shape_params[MTSGPU_SHAPE_NPARAMS * (size_t) s + 23];    /* m_invSurfaceArea */
+				continue;
+			}
+			/* TriMesh::configure (trimesh.cpp:279-283) */
 			uint32_t t0 = fs->shape_tri_offset[s], n = fs->shape_tri_offset[s+1] - t0;
 			float *areas = (float *) malloc(sizeof(float) * ((size_t) n + 1));
 			for (uint32_t t = 0; t < n; ++t)
@@ -224,6 +259,7 @@ int orc_flatten(const mtsgpu_scene_desc *d, const mtsgpu_kd_params *kdp, orc_fla
 	sc->vtx_pos = fs->vtx_pos; sc->vtx_nrm = fs->vtx_nrm; sc->tri_idx = fs->tri_idx;
 	sc->shape_tri_offset = fs->shape_tri_offset; sc->shape_bsdf = fs->shape_bsdf;
 	sc->shape_lum = fs->shape_lum; sc->shape_flags = fs->shape_flags;
+	sc->shape_type = fs->shape_type; sc->shape_params = fs->shape_params;
 	sc->n_nodes = fs->kd.n_nodes; sc->n_indices = fs->kd.n_indices;
 	sc->kd_nodes = fs->kd.nodes; sc->kd_indices = fs->kd.indices; sc->triaccel = fs->triaccel;
 	for (int a = 0; a < 3; ++a) { sc->aabb_min[a] = fs->kd.aabb_min[a]; sc->aabb_max[a] = fs->kd.aabb_max[a]; }
@@ -249,6 +285,7 @@ void orc_flat_scene_free(orc_flat_scene *fs) {
 	orc_kd_free(&fs->kd);
 	free(fs->vtx_pos); free(fs->vtx_nrm); free(fs->tri_idx); free(fs->shape_tri_offset);
 	free(fs->shape_flags); free(fs->shape_bsdf); free(fs->shape_lum); free(fs->triaccel);
+	free(fs->shape_type); free(fs->shape_params);
 	free(fs->bsdf_type); free(fs->bsdf_params); free(fs->lum_type); free(fs->lum_params);
 	free(fs->lum_shape); free(fs->lum_inv_area); free(fs->lum_cdf_offset); free(fs->lum_tri_cdf);
 	free(fs->lum_sel_cdf); free(fs->lum_sel_pdf);

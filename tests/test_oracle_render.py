@@ -259,6 +259,45 @@ def test_high_quality_edges(mts, orc):
     assert np.allclose(acc, hq, rtol=2e-6, atol=1e-7)
 
 
+def test_sphere_shape(mts, orc):
+    """`sphere` shapes (src/shapes/sphere.cpp): one kd-tree primitive each; hits agree with the analytic
+    intersection in binary64; a sphere-shaped area luminaire lights the box; both hosts flatten identically"""
+    sd = mts.scenes.spheres()
+    fs = orc.FlatScene(sd)
+    arr = mts.abi.scene_arrays(fs.scene.contents)
+    assert list(arr["shape_type"][-5:]) == [1] * 5 and arr["tri_idx"][-1, 0] == 0xFFFFFFFF
+    assert (arr["triaccel"][-5:, 0] == 0xFFFFFFFF).all() and (arr["triaccel"][:-5, 0] <= 3).all()
+    pscene = mts.Scene(sd)                      # keep it alive: .sc points into it
+    prod = mts.abi.scene_arrays(pscene.sc)
+    for k in arr:
+        assert np.asarray(arr[k]).tobytes() == np.asarray(prod[k]).tobytes(), k
+    from conftest import chord_rays
+    rays = chord_rays(20000, (0, 1, 0), 2.2, seed=11)
+    hits = orc.trace_rays(fs.scene, rays)
+    nprim = len(arr["tri_idx"])
+    on_sphere = hits[:, 3] >= nprim - 5
+    on_sphere &= hits[:, 3] != 0xFFFFFFFF
+    assert on_sphere.sum() > 100
+    t = hits[:, 0].view(np.float32)
+    P = arr["shape_params"]
+    o, d = rays[:, 0:3].astype(np.float64), rays[:, 4:7].astype(np.float64)
+    for i in np.flatnonzero(on_sphere)[:2000]:
+        shape = int(arr["triaccel"][hits[i, 3], 10])
+        c, r = P[shape, 0:3].astype(np.float64), float(P[shape, 3])
+        p = o[i] + float(t[i]) * d[i]
+        assert abs(np.linalg.norm(p - c) - abs(r)) < 2e-5 * max(1.0, float(t[i]))
+    cam = orc.make_camera(sd, 40, 40)
+    prm = orc.render_params(sd.max_depth, sampler=mts.abi.SAMPLER_LD_KEYED, spp=16, seed=4)
+    film, st = orc.render(fs.scene, cam, prm)
+    img = orc.develop(film)
+    assert np.isfinite(film).all() and img.mean() > 0.05
+    # removing the sphere luminaire darkens the image: it is really sampled (Sphere::sampleSolidAngle)
+    sd2 = mts.scenes.spheres(); sd2.meshes.pop(); sd2.lum_type.pop(); sd2.lum_params.pop()
+    fs2 = orc.FlatScene(sd2)
+    film2, _ = orc.render(fs2.scene, cam, prm)
+    assert orc.develop(film2).mean() < 0.93 * img.mean()
+
+
 def test_phong_chi_square_and_twosided(orc):
     """phong is in the reference's own chi-square list (data/tests/test_bsdf.xml); twosided mirrors the lobe"""
     import ctypes as C
