@@ -47,7 +47,11 @@ enum {
 	MTSGPU_BSDF_PHONG = 5,      /* params: [0] exponent [1] kd [2] ks [3] specularSamplingWeight
 	                                       [4] diffuseSamplingWeight [5..7] diffuseRefl [8..10] specRefl
 	                                       (values after Phong::configure, src/bsdfs/phong.cpp:74-96)   */
-	MTSGPU_BSDF_NTYPES = 6,
+	MTSGPU_BSDF_ROUGHGLASS = 6, /* params: [0] distribution (0 beckmann, 1 phong, 2 ggx) [1] alpha (phong: the exponent
+	                                       2/alpha^2 - 2 the constructor derives, roughglass.cpp:130-136) [2] intIOR
+	                                       [3] extIOR [4..6] specularReflectance [7..9] specularTransmittance
+	                                       (src/bsdfs/roughglass.cpp)                                              */
+	MTSGPU_BSDF_NTYPES = 7,
 	/* OR-ed into bsdf_type: the BSDF is wrapped in a `twosided` adapter (src/bsdfs/twosided.cpp) */
 	MTSGPU_BSDF_TWOSIDED = 0x100
 };

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 ABI_VERSION = 2
-BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET, BSDF_MIRROR, BSDF_PHONG = 0, 1, 2, 3, 4, 5
+BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET, BSDF_MIRROR, BSDF_PHONG, BSDF_ROUGHGLASS = 0, 1, 2, 3, 4, 5, 6
 BSDF_TWOSIDED = 0x100
 BSDF_NPARAMS = 16
 LUM_AREA, LUM_CONSTANT, LUM_POINT, LUM_DIRECTIONAL, LUM_SPOT = 0, 1, 2, 3, 4

@@ -891,7 +891,7 @@ __device__ __forceinline__ float pdf_luminaire(const DScene &sc, V3 p, int lum, 
 }
 
 // --- BSDF building blocks (roughmetal.cpp:75-117 == microfacet.cpp:95-136) ---
-enum : uint32_t { T_DIFFUSE_REFL = 0x1, T_DELTA_REFL = 0x4, T_DELTA_TRANS = 0x8, T_GLOSSY_REFL = 0x10,
+enum : uint32_t { T_DIFFUSE_REFL = 0x1, T_DELTA_REFL = 0x4, T_DELTA_TRANS = 0x8, T_GLOSSY_REFL = 0x10, T_GLOSSY_TRANS = 0x20,
                   T_DELTA = 0xC, T_TRANSMISSION = 0x2A };
 
 __device__ __forceinline__ float frame_tan_theta(V3 v) {      // frame.h:98-103
@@ -1139,6 +1139,157 @@ template <> struct Bsdf<5> {
 			st = T_DIFFUSE_REFL;
 			qv = f(P, wi, wo) * (1.0f / pdf(P, wi, wo));
 		}
+		if (isZero(qv)) return V3(0, 0, 0);
+		pdfv = pdf(P, wi, wo);
+		return f(P, wi, wo);
+	}
+};
+
+// RoughGlass (src/bsdfs/roughglass.cpp) through BSDF::sample(bRec, pdf, s) (bsdf.cpp:37-48): the plugin's own
+// 3-argument sample() takes its pdf by value (roughglass.cpp:619) and therefore does not override the virtual.
+// path.cpp leaves bRec.sampler NULL (clamped Fresnel term of the surface normal), quantity = ERadiance.
+// P: [0] distribution (0 beckmann, 1 phong, 2 ggx) [1] alpha [2] intIOR [3] extIOR [4..6] specRefl [7..9] specTrans
+template <> struct Bsdf<6> {
+	static constexpr float kInvTwoPi = 0.15915494309189533577f;
+	static __device__ __forceinline__ float signum(float v) { return (v < 0) ? -1.0f : 1.0f; }
+	// evalD (roughglass.cpp:213-257)
+	static __device__ __forceinline__ float evalD(int distr, V3 m, float alpha) {
+		if (m.z <= 0) return 0.0f;
+		float result;
+		if (distr == 0) {
+			const float ex = frame_tan_theta(m) / alpha;
+			result = dexp(-(ex * ex)) / (kPi * alpha * alpha * dpow4(m.z));
+		} else if (distr == 1) {
+			result = (alpha + 2) * kInvTwoPi * dpow(m.z, alpha);
+		} else {
+			const float tanTheta = frame_tan_theta(m), cosTheta = m.z;
+			const float root = alpha / (cosTheta * cosTheta * (alpha * alpha + tanTheta * tanTheta));
+			result = kInvPi * (root * root);
+		}
+		if ((double) result < 1e-40) result = 0;
+		return result;
+	}
+	// sampleD (roughglass.cpp:266-293) + sphericalDirection (util.cpp:543-550)
+	static __device__ __forceinline__ V3 sampleD(int distr, float sx, float sy, float alpha) {
+		const float phiM = (2.0f * kPi) * sy;
+		float thetaM;
+		if (distr == 0) thetaM = datan(sqrtf(-alpha * alpha * dlog(1.0f - sx)));
+		else if (distr == 1) thetaM = dacos(dpow(sx, (float) 1 / (alpha + 2)));
+		else thetaM = datan(alpha * sqrtf(sx) / sqrtf(1.0f - sx));
+		float st, ct, sp, cp;
+		dsincos(thetaM, st, ct); dsincos(phiM, sp, cp);
+		return V3(st * cp, st * sp, ct);
+	}
+	// smithG1 (roughglass.cpp:303-343)
+	static __device__ __forceinline__ float smithG1(int distr, V3 v, V3 m, float alpha) {
+		const float tanTheta = fabsf(frame_tan_theta(v));
+		if (tanTheta == 0.0f) return 1.0f;
+		if (dot(v, m) * v.z <= 0) return 0.0f;
+		if (distr == 2) {
+			const float root = alpha * tanTheta;
+			return 2.0f / (1.0f + sqrtf(1.0f + root * root));
+		}
+		if (distr == 1) alpha = sqrtf(0.5f * alpha + 1) / tanTheta;     // falls through to the Beckmann case
+		const float a = 1.0f / (alpha * tanTheta);
+		const float aSqr = a * a;
+		if (a >= 1.6f) return 1.0f;
+		return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+	}
+	// the half-vector of f() and pdf() (roughglass.cpp:355-377 == :417-446)
+	static __device__ __forceinline__ V3 halfVector(const float *P, V3 wi, V3 wo, bool reflect, float etaI, float etaT) {
+		if (reflect)
+			return normalize(wo + wi) * signum(wo.z);
+		const V3 n = normalize(V3(wi.x * etaI + wo.x * etaT, wi.y * etaI + wo.y * etaT, wi.z * etaI + wo.z * etaT));
+		const float sgn = (P[3] > P[2]) ? 1.0f : -1.0f;
+		return V3(sgn * n.x, sgn * n.y, sgn * n.z);
+	}
+	static __device__ __forceinline__ V3 f(const float *P, V3 wi, V3 wo) {
+		const int distr = (int) P[0];
+		const bool reflect = wi.z * wo.z > 0;
+		float etaI = P[3], etaT = P[2];
+		if (wi.z < 0) { const float t = etaI; etaI = etaT; etaT = t; }
+		const V3 H = halfVector(P, wi, wo, reflect, etaI, etaT);
+		const float alpha = P[1];
+		const float D = evalD(distr, H, alpha);
+		if (D == 0) return V3(0, 0, 0);
+		const float F = fresnel(dot(wi, H), P[3], P[2]);
+		const float G = smithG1(distr, wi, H, alpha) * smithG1(distr, wo, H, alpha);
+		if (reflect) {
+			const float value = F * D * G / (4.0f * wi.z * wo.z);
+			return V3(P[4] * value, P[5] * value, P[6] * value);
+		}
+		const float sqrtDenom = etaI * dot(wi, H) + etaT * dot(wo, H);
+		float value = ((1 - F) * D * G * etaT * etaT * dot(wi, H) * dot(wo, H)) / (wi.z * wo.z * sqrtDenom * sqrtDenom);
+		value *= (etaI * etaI) / (etaT * etaT);                     // bRec.quantity == ERadiance
+		const float av = fabsf(value);
+		return V3(P[7] * av, P[8] * av, P[9] * av);
+	}
+	static __device__ __forceinline__ float pdf(const float *P, V3 wi, V3 wo) {
+		const int distr = (int) P[0];
+		const bool reflect = wi.z * wo.z > 0;
+		float etaI = P[3], etaT = P[2];
+		if (wi.z < 0) { const float t = etaI; etaI = etaT; etaT = t; }
+		const V3 H = halfVector(P, wi, wo, reflect, etaI, etaT);
+		float dwh_dwo;
+		if (reflect) {
+			dwh_dwo = 1.0f / (4.0f * dot(wo, H));
+		} else {
+			const float sqrtDenom = etaI * dot(wi, H) + etaT * dot(wo, H);
+			dwh_dwo = (etaT * etaT * dot(wo, H)) / (sqrtDenom * sqrtDenom);
+		}
+		float alpha = P[1];
+		alpha = alpha * (1.2f - 0.2f * sqrtf(fabsf(wi.z)));
+		float prob = evalD(distr, H, alpha);
+		const float F = smin(0.9f, smax(0.1f, fresnel(wi.z, P[3], P[2])));
+		prob *= reflect ? F : (1 - F);
+		return fabsf(prob * H.z * dwh_dwo);
+	}
+	// sample(bRec, sample) (roughglass.cpp:487-617), then pdf() and f() as BSDF::sample(bRec, pdf, s) does
+	static __device__ __forceinline__ V3 sample(const float *P, V3 wi, float sx, float sy, V3 &wo, float &pdfv, uint32_t &st) {
+		pdfv = 0; st = 0; wo = V3(0, 0, 0);
+		const int distr = (int) P[0];
+		bool choseReflection = true;
+		float sampleF = smin(0.9f, smax(0.1f, fresnel(wi.z, P[3], P[2])));
+		if (sx < sampleF) {
+			sx /= sampleF;
+		} else {
+			sx = (sx - sampleF) / (1 - sampleF);
+			choseReflection = false;
+		}
+		const float alpha = P[1];
+		const float sampleAlpha = alpha * (1.2f - 0.2f * sqrtf(fabsf(wi.z)));
+		const V3 m = sampleD(distr, sx, sy, sampleAlpha);
+		V3 result;
+		if (choseReflection) {
+			const float k = 2 * dot(wi, m);                          // reflect (roughglass.cpp:180-182)
+			wo = V3(k * m.x - wi.x, k * m.y - wi.y, k * m.z - wi.z);
+			st = T_GLOSSY_REFL;
+			if (wi.z * wo.z <= 0) return V3(0, 0, 0);
+			result = V3(P[4], P[5], P[6]);
+		} else {
+			float etaI = P[3], etaT = P[2];
+			if (wi.z < 0) { const float t = etaI; etaI = etaT; etaT = t; }
+			const float eta = etaI / etaT, c = dot(wi, m);           // refract (roughglass.cpp:185-201)
+			const float cosThetaTSqr = 1 + eta * eta * (c * c - 1);
+			if (cosThetaTSqr < 0) return V3(0, 0, 0);
+			const float k = eta * c - signum(wi.z) * sqrtf(cosThetaTSqr);
+			wo = V3(m.x * k - wi.x * eta, m.y * k - wi.y * eta, m.z * k - wi.z * eta);
+			st = T_GLOSSY_TRANS;
+			if (wi.z * wo.z >= 0) return V3(0, 0, 0);
+			const float scale = (etaI * etaI) / (etaT * etaT);
+			result = V3(P[7] * scale, P[8] * scale, P[9] * scale);
+		}
+		float numerator = evalD(distr, m, alpha) * smithG1(distr, wi, m, alpha) * smithG1(distr, wo, m, alpha) * dot(wi, m);
+		float denominator = evalD(distr, m, sampleAlpha) * m.z * wi.z * wo.z;
+		float F = fresnel(dot(wi, m), P[3], P[2]);
+		if (!choseReflection) {
+			sampleF = 1 - sampleF;
+			F = 1 - F;
+		}
+		numerator *= F;
+		denominator *= sampleF;
+		const float w = fabsf(numerator / denominator);
+		const V3 qv(result.x * w, result.y * w, result.z * w);
 		if (isZero(qv)) return V3(0, 0, 0);
 		pdfv = pdf(P, wi, wo);
 		return f(P, wi, wo);
@@ -1563,6 +1714,7 @@ void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, co
 		case 3: hipLaunchKernelGGL(k_shade<3>, g, b, 0, s, sc, ps, cfg, q, view); break;
 		case 4: hipLaunchKernelGGL(k_shade<4>, g, b, 0, s, sc, ps, cfg, q, view); break;
 		case 5: hipLaunchKernelGGL(k_shade<5>, g, b, 0, s, sc, ps, cfg, q, view); break;
+		case 6: hipLaunchKernelGGL(k_shade<6>, g, b, 0, s, sc, ps, cfg, q, view); break;
 		default: hipLaunchKernelGGL(k_shade<kNumBsdfTypes>, g, b, 0, s, sc, ps, cfg, q, view); break;
 	}
 }

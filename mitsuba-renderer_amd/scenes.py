@@ -81,6 +81,14 @@ class SceneDescription:
         dsw = F(1.0) - ssw
         return self.add_bsdf(abi.BSDF_PHONG, [exponent, kd, ks, ssw, dsw, rd, rd, rd, rs, rs, rs])
 
+    def roughglass(self, alpha=0.1, int_ior=1.5046, ext_ior=1.0, distribution="beckmann", refl=1.0, trans=1.0):
+        """src/bsdfs/roughglass.cpp: for `phong` the constructor maps alpha to the exponent 2/alpha^2 - 2 (:130-136)"""
+        d = {"beckmann": 0, "phong": 1, "ggx": 2}[distribution]
+        a = F(alpha)
+        if d == 1:
+            a = F(2) / (a * a) - F(2)
+        return self.add_bsdf(abi.BSDF_ROUGHGLASS, [d, a, int_ior, ext_ior, refl, refl, refl, trans, trans, trans])
+
     def twosided(self, bsdf):
         """wrap an existing BSDF block in the `twosided` adapter (src/bsdfs/twosided.cpp)"""
         self.bsdf_type[bsdf] |= abi.BSDF_TWOSIDED
@@ -360,6 +368,9 @@ def spheres():
     sd.add_sphere((0.5, 0.3, 0.3), 0.3, bsdf=sd.mirror(0.9))
     sd.add_sphere((0.0, 0.2, 0.55), 0.2, bsdf=sd.lambertian(0.3, 0.4, 0.8))
     sd.add_sphere((0.45, 1.3, -0.4), 0.25, bsdf=sd.twosided(sd.phong(30.0, 0.3, 0.5)), inverted=True)
+    sd.add_sphere((-0.75, 0.15, 0.6), 0.15, bsdf=sd.roughglass(0.15, 1.5, 1.0, "beckmann"))
+    sd.add_sphere((-0.25, 0.12, 0.8), 0.12, bsdf=sd.roughglass(0.4, 1.5, 1.0, "ggx"))
+    sd.add_sphere((0.75, 0.12, 0.8), 0.12, bsdf=sd.roughglass(0.3, 1.33, 1.0, "phong", trans=0.9))
     lum = sd.add_lum(abi.LUM_AREA, [9.0, 7.0, 4.0])
     sd.add_sphere((-0.55, 1.45, 0.35), 0.12, bsdf=sd.lambertian(0.0), lum=lum)
     sd.max_depth = 8

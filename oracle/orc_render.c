@@ -629,7 +629,7 @@ static void area_le(const mtsgpu_scene *sc, int l, const float n[3], const float
 /* ========================================================================== */
 /* BSDFs (local shading frame)                                                */
 /* ========================================================================== */
-enum { T_DIFFUSE_REFL = 0x1, T_DELTA_REFL = 0x4, T_DELTA_TRANS = 0x8, T_GLOSSY_REFL = 0x10,
+enum { T_DIFFUSE_REFL = 0x1, T_DELTA_REFL = 0x4, T_DELTA_TRANS = 0x8, T_GLOSSY_REFL = 0x10, T_GLOSSY_TRANS = 0x20,
        T_DELTA = 0x4 | 0x8, T_TRANSMISSION = 0x2 | 0x8 | 0x20 };
 
 static inline int spec_is_zero(const float s[3]) { return !(s[0] != 0.0f) && !(s[1] != 0.0f) && !(s[2] != 0.0f); }
@@ -676,6 +676,188 @@ static float smith_beckmann_g1(float alphaB, const float v[3], const float m[3])
 static void mf_reflect(const float wi[3], const float n[3], float wo[3]) {
 	float s = 2.0f * v3_dot(n, wi);
 	wo[0] = n[0]*s - wi[0]; wo[1] = n[1]*s - wi[1]; wo[2] = n[2]*s - wi[2];
+}
+
+/* ---- RoughGlass (src/bsdfs/roughglass.cpp) ----
+ * P: [0] distribution [1] alpha [2] intIOR [3] extIOR [4..6] specularReflectance [7..9] specularTransmittance.
+ * path.cpp leaves bRec.sampler NULL, component -1, typeMask all, quantity ERadiance.  The 3-argument
+ * sample() of the plugin takes its pdf BY VALUE (roughglass.cpp:619), so it does not override the virtual and
+ * BSDF::sample(bRec, pdf&, sample) (bsdf.cpp:37-48) runs: sample(bRec, s), then pdf(bRec) and f(bRec). */
+#define ORC_INV_TWOPI 0.15915494309189533577f
+static inline float rg_signum(float value) { return (value < 0) ? -1.0f : 1.0f; }
+
+/* evalD (roughglass.cpp:213-257) */
+static float rg_eval_d(int distr, const float m[3], float alpha) {
+	if (m[2] <= 0)
+		return 0.0f;
+	float result;
+	if (distr == 0) {
+		const float ex = frame_tan_theta(m) / alpha;
+		result = orc_expf(-(ex*ex)) / (ORC_PI * alpha*alpha * orc_pow4f(m[2]));
+	} else if (distr == 1) {
+		result = (alpha + 2) * ORC_INV_TWOPI * orc_powf(m[2], alpha);
+	} else {
+		const float tanTheta = frame_tan_theta(m), cosTheta = m[2];
+		const float root = alpha / (cosTheta*cosTheta * (alpha*alpha + tanTheta*tanTheta));
+		result = ORC_INV_PI * (root * root);
+	}
+	if (result < 1e-40)
+		result = 0;
+	return result;
+}
+
+/* sampleD (roughglass.cpp:266-293) + sphericalDirection (util.cpp:543-550) */
+static void rg_sample_d(int distr, const float sample[2], float alpha, float m[3]) {
+	float phiM = (2.0f * ORC_PI) * sample[1], thetaM = 0.0f;
+	if (distr == 0)
+		thetaM = orc_atanf(sqrtf(-alpha*alpha * orc_logf(1.0f - sample[0])));
+	else if (distr == 1)
+		thetaM = orc_acosf(orc_powf(sample[0], (float) 1 / (alpha + 2)));
+	else
+		thetaM = orc_atanf(alpha * sqrtf(sample[0]) / sqrtf(1.0f - sample[0]));
+	float sinTheta = orc_sinf(thetaM);
+	m[0] = sinTheta * orc_cosf(phiM);
+	m[1] = sinTheta * orc_sinf(phiM);
+	m[2] = orc_cosf(thetaM);
+}
+
+/* smithG1 (roughglass.cpp:303-343) */
+static float rg_smith_g1(int distr, const float v[3], const float m[3], float alpha) {
+	const float tanTheta = fabsf(frame_tan_theta(v));
+	if (tanTheta == 0.0f)
+		return 1.0f;
+	if (v3_dot(v, m) * v[2] <= 0)
+		return 0.0f;
+	if (distr == 2) {
+		const float root = alpha * tanTheta;
+		return 2.0f / (1.0f + sqrtf(1.0f + root*root));
+	}
+	if (distr == 1)
+		alpha = sqrtf(0.5f * alpha + 1) / tanTheta;      /* falls through to the Beckmann case */
+	const float a = 1.0f / (alpha * tanTheta);
+	const float aSqr = a * a;
+	if (a >= 1.6f)
+		return 1.0f;
+	return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+}
+
+/* the half-vector of f() and pdf() (roughglass.cpp:355-377 == :417-446) */
+static void rg_half_vector(const float *P, const float wi[3], const float wo[3], int reflect, float etaI, float etaT, float H[3]) {
+	if (reflect) {
+		float h[3], n[3];
+		v3_add(h, wo, wi); v3_normalize(n, h);
+		v3_scale(H, n, rg_signum(wo[2]));
+	} else {
+		float h[3], n[3];
+		for (int i = 0; i < 3; ++i) h[i] = wi[i]*etaI + wo[i]*etaT;
+		v3_normalize(n, h);
+		const float sgn = (P[3] > P[2] ? (float) 1 : (float) -1);
+		for (int i = 0; i < 3; ++i) H[i] = sgn * n[i];
+	}
+}
+
+/* f (roughglass.cpp:345-411) */
+static void roughglass_f(const float *P, const float wi[3], const float wo[3], float out[3]) {
+	const int distr = (int) P[0];
+	const int reflect = wi[2] * wo[2] > 0;
+	float etaI = P[3], etaT = P[2];
+	if (wi[2] < 0) { float t = etaI; etaI = etaT; etaT = t; }
+	float H[3];
+	rg_half_vector(P, wi, wo, reflect, etaI, etaT, H);
+	const float alpha = P[1];
+	out[0] = out[1] = out[2] = 0.0f;
+	const float D = rg_eval_d(distr, H, alpha);
+	if (D == 0)
+		return;
+	const float F = orc_fresnel(v3_dot(wi, H), P[3], P[2]);
+	const float G = rg_smith_g1(distr, wi, H, alpha) * rg_smith_g1(distr, wo, H, alpha);
+	if (reflect) {
+		float value = F * D * G / (4.0f * wi[2] * wo[2]);
+		for (int i = 0; i < 3; ++i) out[i] = P[4+i] * value;
+	} else {
+		float sqrtDenom = etaI * v3_dot(wi, H) + etaT * v3_dot(wo, H);
+		float value = ((1 - F) * D * G * etaT * etaT * v3_dot(wi, H)*v3_dot(wo, H)) /
+			(wi[2] * wo[2] * sqrtDenom * sqrtDenom);
+		value *= (etaI*etaI) / (etaT*etaT);                    /* bRec.quantity == ERadiance */
+		for (int i = 0; i < 3; ++i) out[i] = P[7+i] * fabsf(value);
+	}
+}
+
+/* pdf (roughglass.cpp:413-485), no sampler: the clamped Fresnel term of the surface normal */
+static float roughglass_pdf(const float *P, const float wi[3], const float wo[3]) {
+	const int distr = (int) P[0];
+	const int reflect = wi[2] * wo[2] > 0;
+	float etaI = P[3], etaT = P[2];
+	if (wi[2] < 0) { float t = etaI; etaI = etaT; etaT = t; }
+	float H[3], dwh_dwo;
+	rg_half_vector(P, wi, wo, reflect, etaI, etaT, H);
+	if (reflect) {
+		dwh_dwo = 1.0f / (4.0f * v3_dot(wo, H));
+	} else {
+		float sqrtDenom = etaI * v3_dot(wi, H) + etaT * v3_dot(wo, H);
+		dwh_dwo = (etaT*etaT * v3_dot(wo, H)) / (sqrtDenom*sqrtDenom);
+	}
+	float alpha = P[1];
+	alpha = alpha * (1.2f - 0.2f * sqrtf(fabsf(wi[2])));
+	float prob = rg_eval_d(distr, H, alpha);
+	const float F = fminf_((float) 0.9f, fmaxf_((float) 0.1f, orc_fresnel(wi[2], P[3], P[2])));
+	prob *= reflect ? F : (1-F);
+	return fabsf(prob * H[2] * dwh_dwo);
+}
+
+/* sample(bRec, sample) (roughglass.cpp:487-617), no sampler */
+static void roughglass_sample(const float *P, const float wi[3], const float _sample[2], float wo[3], uint32_t *stype, float out[3]) {
+	const int distr = (int) P[0];
+	float sample[2] = { _sample[0], _sample[1] };
+	int choseReflection = 1;
+	out[0] = out[1] = out[2] = 0.0f;
+	float sampleF = fminf_((float) 0.9f, fmaxf_((float) 0.1f, orc_fresnel(wi[2], P[3], P[2])));
+	if (sample[0] < sampleF) {
+		sample[0] /= sampleF;
+	} else {
+		sample[0] = (sample[0] - sampleF) / (1 - sampleF);
+		choseReflection = 0;
+	}
+	const float alpha = P[1];
+	const float sampleAlpha = alpha * (1.2f - 0.2f * sqrtf(fabsf(wi[2])));
+	float m[3];
+	rg_sample_d(distr, sample, sampleAlpha, m);
+	float result[3];
+	if (choseReflection) {
+		/* reflect(wi, m) = 2 * dot(wi, m) * Vector(m) - wi (roughglass.cpp:180-182) */
+		const float k = 2 * v3_dot(wi, m);
+		for (int i = 0; i < 3; ++i) wo[i] = k * m[i] - wi[i];
+		*stype = T_GLOSSY_REFL;
+		if (wi[2] * wo[2] <= 0)
+			return;
+		for (int i = 0; i < 3; ++i) result[i] = P[4+i];
+	} else {
+		float etaI = P[3], etaT = P[2];
+		if (wi[2] < 0) { float t = etaI; etaI = etaT; etaT = t; }
+		/* refract (roughglass.cpp:185-201) */
+		const float eta = etaI / etaT, c = v3_dot(wi, m);
+		const float cosThetaTSqr = 1 + eta * eta * (c*c-1);
+		if (cosThetaTSqr < 0)
+			return;
+		const float k = eta*c - rg_signum(wi[2]) * sqrtf(cosThetaTSqr);
+		for (int i = 0; i < 3; ++i) wo[i] = m[i] * k - wi[i] * eta;
+		*stype = T_GLOSSY_TRANS;
+		if (wi[2] * wo[2] >= 0)
+			return;
+		const float scale = (etaI*etaI) / (etaT*etaT);
+		for (int i = 0; i < 3; ++i) result[i] = P[7+i] * scale;
+	}
+	float numerator = rg_eval_d(distr, m, alpha) * rg_smith_g1(distr, wi, m, alpha) * rg_smith_g1(distr, wo, m, alpha) * v3_dot(wi, m);
+	float denominator = rg_eval_d(distr, m, sampleAlpha) * m[2] * wi[2] * wo[2];
+	float F = orc_fresnel(v3_dot(wi, m), P[3], P[2]);
+	if (!choseReflection) {
+		sampleF = 1-sampleF;
+		F = 1-F;
+	}
+	numerator *= F;
+	denominator *= sampleF;
+	const float w = fabsf(numerator / denominator);
+	for (int i = 0; i < 3; ++i) out[i] = result[i] * w;
 }
 
 /* ---- Lambertian (src/bsdfs/lambertian.cpp:95-126) ---- */
@@ -857,6 +1039,7 @@ static void bsdf_f_base(uint32_t type, const float *P, const float wi[3], const 
 		case MTSGPU_BSDF_ROUGHMETAL: roughmetal_f(P, wi, wo, out); break;
 		case MTSGPU_BSDF_MICROFACET: microfacet_f(P, wi, wo, out); break;
 		case MTSGPU_BSDF_PHONG: phong_f(P, wi, wo, out); break;
+		case MTSGPU_BSDF_ROUGHGLASS: roughglass_f(P, wi, wo, out); break;
 		default: out[0] = out[1] = out[2] = 0.0f; break;   /* dielectric.cpp:101-103, mirror.cpp:60-62 */
 	}
 }
@@ -867,6 +1050,7 @@ static float bsdf_pdf_base(uint32_t type, const float *P, const float wi[3], con
 		case MTSGPU_BSDF_ROUGHMETAL: return roughmetal_pdf(P, wi, wo);
 		case MTSGPU_BSDF_MICROFACET: return microfacet_pdf(P, wi, wo);
 		case MTSGPU_BSDF_PHONG: return phong_pdf(P, wi, wo);
+		case MTSGPU_BSDF_ROUGHGLASS: return roughglass_pdf(P, wi, wo);
 		default: return 0.0f;                              /* dielectric.cpp:105-107, mirror.cpp:64-66 */
 	}
 }
@@ -986,6 +1170,16 @@ static void bsdf_sample_base(uint32_t type, const float *P, const float wi[3], c
 			return;
 		*pdf = phong_pdf(P, wi, wo);
 		phong_f(P, wi, wo, out);
+		return;
+	}
+	case MTSGPU_BSDF_ROUGHGLASS: {
+		/* BSDF::sample(bRec, pdf, sample) fallback (bsdf.cpp:37-48) over roughglass.cpp:487-617 */
+		float q[3];
+		roughglass_sample(P, wi, s, wo, stype, q);
+		if (spec_is_zero(q))
+			return;
+		*pdf = roughglass_pdf(P, wi, wo);
+		roughglass_f(P, wi, wo, out);
 		return;
 	}
 	default: return;

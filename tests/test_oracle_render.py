@@ -63,12 +63,13 @@ def test_shadow_rays_ignore_non_occluders(mts, orc):
     assert orc.trace_rays(fs.scene, ray)[0, 3] != 0xFFFFFFFF     # closest-hit still sees it
 
 
-def _chi2_bsdf(orc, btype, params, wi, n=200000, nt=10, nph=20, seed=3):
+def _chi2_bsdf(orc, btype, params, wi, n=200000, nt=10, nph=20, seed=3, full_sphere=False, skip_theta_bins=()):
     from scipy import stats
     L = orc.lib()
     rng = np.random.RandomState(seed)
     P = np.zeros(16, dtype=np.float32); P[:len(params)] = params
     wi = np.asarray(wi, dtype=np.float32); wi /= np.linalg.norm(wi)
+    lo = -1.0 if full_sphere else 0.0              # cos(theta) range of the histogram
     hist = np.zeros((nt, nph))
     wo = np.zeros(3, dtype=np.float32); out = np.zeros(3, dtype=np.float32)
     pdf = C.c_float(); st = C.c_uint32()
@@ -79,7 +80,7 @@ def _chi2_bsdf(orc, btype, params, wi, n=200000, nt=10, nph=20, seed=3):
         if pdf.value <= 0:
             continue
         valid += 1
-        ct = min(max(wo[2], 0.0), 1.0)
+        ct = (min(max(wo[2], lo), 1.0) - lo) / (1.0 - lo)
         ph = np.arctan2(wo[1], wo[0]) % (2 * np.pi)
         hist[min(int(ct * nt), nt - 1), min(int(ph / (2 * np.pi) * nph), nph - 1)] += 1
     # expected counts: integrate pdf over each (cos theta, phi) cell (midpoint rule on a fine grid)
@@ -90,14 +91,16 @@ def _chi2_bsdf(orc, btype, params, wi, n=200000, nt=10, nph=20, seed=3):
         for j in range(nph):
             acc = 0.0
             for a in range(sub):
-                ct = (i + (a + 0.5) / sub) / nt
+                ct = lo + (1.0 - lo) * (i + (a + 0.5) / sub) / nt
                 stn = np.sqrt(max(0.0, 1 - ct * ct))
                 for b in range(4):
                     ph = (j + (b + 0.5) / 4) / nph * 2 * np.pi
                     w2[:] = (stn * np.cos(ph), stn * np.sin(ph), ct)
                     acc += L.orc_bsdf_pdf(btype, _p(P), _p(wi), _p(w2))
-            expected[i, j] = acc / (sub * 4) * (1.0 / nt) * (2 * np.pi / nph) * n
+            expected[i, j] = acc / (sub * 4) * ((1.0 - lo) / nt) * (2 * np.pi / nph) * n
     # pool cells with small expectation (test_chisquare.cpp pools below 5)
+    for b in skip_theta_bins:
+        expected[b, :] = 0; hist[b, :] = 0
     e, o = expected.ravel(), hist.ravel()
     big = e >= 5
     e2 = np.append(e[big], e[~big].sum()); o2 = np.append(o[big], o[~big].sum())
@@ -259,14 +262,142 @@ def test_high_quality_edges(mts, orc):
     assert np.allclose(acc, hq, rtol=2e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("distr,alpha", [(0, 0.3), (2, 0.4), (1, 2 / (0.3 * 0.3) - 2)])
+def test_roughglass_chi_square(orc, distr, alpha):
+    """the three roughglass configurations of the reference's own chi-square list (data/tests/test_bsdf.xml:92-117):
+    sample() must be distributed according to pdf() over the whole sphere.
+    pdf() (roughglass.cpp:413-485) does not reject half-vectors that lie on the same side of wi and wo, so it
+    assigns density to a few directions at the rim of the transmitted lobe that sample() never produces.  That is
+    the reference's behaviour and is kept (see the independent restatement below); the chi-square statistic leaves
+    out those bands of cos(theta_o): bins 1-2 of 16 from outside, bin 8 from inside."""
+    P = [distr, alpha, 1.5, 1.0, 1, 1, 1, 1, 1, 1]
+    p, frac = _chi2_bsdf(orc, 6, P, (0.3, 0.1, 0.9), n=40000, nt=16, full_sphere=True, skip_theta_bins=(1, 2))
+    assert frac > 0.8 and p > 0.003, (distr, p, frac)
+    if distr == 0:
+        # from inside a third of the microfacet normals fail by total internal reflection
+        p, frac = _chi2_bsdf(orc, 6, P, (0.5, -0.2, -0.7), n=40000, nt=16, full_sphere=True, skip_theta_bins=(8,))
+        assert frac > 0.55 and p > 0.003, (distr, p, frac)
+
+
+def _rg_fresnel(c, ext, inte):
+    etaI, etaT = (ext, inte) if c >= 0 else (inte, ext)
+    sinT = etaI / etaT * np.sqrt(max(0.0, 1 - c * c))
+    if sinT > 1:
+        return 1.0
+    cosT = np.sqrt(1 - sinT * sinT); c = abs(c)
+    Rs = (etaI * c - etaT * cosT) / (etaI * c + etaT * cosT); Rp = (etaT * c - etaI * cosT) / (etaT * c + etaI * cosT)
+    return (Rs * Rs + Rp * Rp) / 2
+
+
+def _rg_tan(v):
+    t = 1 - v[2] ** 2
+    return 0.0 if t <= 0 else np.sqrt(t) / v[2]
+
+
+def _rg_eval_d(d, m, a):
+    if m[2] <= 0:
+        return 0.0
+    if d == 0:
+        return np.exp(-(_rg_tan(m) / a) ** 2) / (np.pi * a * a * m[2] ** 4)
+    if d == 1:
+        return (a + 2) / (2 * np.pi) * m[2] ** a
+    r = a / (m[2] ** 2 * (a * a + _rg_tan(m) ** 2))
+    return r * r / np.pi
+
+
+@pytest.mark.parametrize("distr,alpha", [(0, 0.3), (2, 0.4), (1, 2 / (0.3 * 0.3) - 2)])
+def test_roughglass_against_binary64_restatement(orc, distr, alpha):
+    """sample() and pdf() of the oracle against a second, independent restatement of roughglass.cpp:266-293,
+    :413-617 in binary64 (numpy): same directions, same densities, from outside and from inside"""
+    import ctypes as C
+    L = orc.lib()
+    ext, inte = 1.0, 1.5
+    P = np.zeros(16, dtype=np.float32); P[:10] = [distr, alpha, inte, ext, 1, 1, 1, 1, 1, 1]
+    rng = np.random.RandomState(9)
+    wo = np.zeros(3, dtype=np.float32); out = np.zeros(3, dtype=np.float32)
+    pdf = C.c_float(); st = C.c_uint32()
+    for wi in ((0.3, 0.1, 0.9), (0.5, -0.2, -0.7)):
+        wi = np.array(wi, dtype=np.float32); wi /= np.linalg.norm(wi)
+        w = wi.astype(np.float64)
+        nv = 0
+        for s in rng.rand(1500, 2).astype(np.float32):
+            L.orc_bsdf_sample(6, _p(P), _p(wi), _p(s), _p(wo), C.byref(pdf), C.byref(st), _p(out))
+            # --- the restatement ---
+            u = s.astype(np.float64)
+            sF = min(0.9, max(0.1, _rg_fresnel(w[2], ext, inte)))
+            refl = u[0] < sF
+            u[0] = u[0] / sF if refl else (u[0] - sF) / (1 - sF)
+            sa = alpha * (1.2 - 0.2 * np.sqrt(abs(w[2])))
+            ph = 2 * np.pi * u[1]
+            th = (np.arctan(np.sqrt(-sa * sa * np.log(1 - u[0]))) if distr == 0 else
+                  np.arccos(u[0] ** (1 / (sa + 2))) if distr == 1 else np.arctan(sa * np.sqrt(u[0]) / np.sqrt(1 - u[0])))
+            m = np.array([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)])
+            etaI, etaT = (ext, inte) if w[2] >= 0 else (inte, ext)
+            if refl:
+                r = 2 * np.dot(w, m) * m - w
+                if w[2] * r[2] <= 0:
+                    r = None
+            else:
+                eta = etaI / etaT; c = np.dot(w, m); k = 1 + eta * eta * (c * c - 1)
+                r = None
+                if k >= 0:
+                    r = m * (eta * c - (-1 if w[2] < 0 else 1) * np.sqrt(k)) - w * eta
+                    if w[2] * r[2] >= 0:
+                        r = None
+            if r is None:
+                assert pdf.value == 0
+                continue
+            if pdf.value == 0:
+                continue                      # weight or density underflowed in binary32
+            nv += 1
+            assert np.abs(r - wo).max() < 2e-4 and st.value == (0x10 if refl else 0x20)
+            # --- pdf(wi, wo) ---
+            if refl:
+                H = (r + w) / np.linalg.norm(r + w) * (1 if r[2] >= 0 else -1)
+                dwh = 1 / (4 * np.dot(r, H))
+            else:
+                H = (1 if ext > inte else -1) * (w * etaI + r * etaT) / np.linalg.norm(w * etaI + r * etaT)
+                sd = etaI * np.dot(w, H) + etaT * np.dot(r, H)
+                dwh = etaT * etaT * np.dot(r, H) / (sd * sd)
+            expect = abs(_rg_eval_d(distr, H, sa) * (sF if refl else 1 - sF) * H[2] * dwh)
+            assert abs(pdf.value - expect) <= 2e-3 * expect + 1e-7, (pdf.value, expect)
+        assert nv > 600
+
+
+def test_roughglass_energy_and_reciprocity(orc):
+    """f * cos / pdf stays bounded (Walter's sampling weights <= ~4) and reflection is reciprocal"""
+    import ctypes as C
+    L = orc.lib()
+    P = np.zeros(16, dtype=np.float32); P[:10] = [0, 0.3, 1.5, 1.0, 1, 1, 1, 1, 1, 1]
+    rng = np.random.RandomState(5)
+    wi = np.array([0.4, 0.2, 0.8], dtype=np.float32); wi /= np.linalg.norm(wi)
+    wo = np.zeros(3, dtype=np.float32); out = np.zeros(3, dtype=np.float32)
+    pdf = C.c_float(); st = C.c_uint32()
+    tot, nrefl, ntrans = 0.0, 0, 0
+    for s in rng.rand(4000, 2).astype(np.float32):
+        L.orc_bsdf_sample(6, _p(P), _p(wi), _p(s), _p(wo), C.byref(pdf), C.byref(st), _p(out))
+        if pdf.value <= 0:
+            continue
+        w = out[0] * abs(wo[2]) / pdf.value
+        assert 0 <= w < 8
+        tot += w
+        nrefl += st.value == 0x10; ntrans += st.value == 0x20
+        if st.value == 0x10:
+            f2 = np.zeros(3, dtype=np.float32)
+            L.orc_bsdf_f(6, _p(P), _p(wo), _p(wi), _p(f2))
+            assert abs(f2[0] - out[0]) <= 2e-5 * max(1.0, abs(out[0]))
+    assert nrefl > 100 and ntrans > 2000
+    assert 0.3 < tot / 4000 < 1.0       # transmitted radiance is scaled by (etaI/etaT)^2 = 1/2.25 on the way in
+
+
 def test_sphere_shape(mts, orc):
     """`sphere` shapes (src/shapes/sphere.cpp): one kd-tree primitive each; hits agree with the analytic
     intersection in binary64; a sphere-shaped area luminaire lights the box; both hosts flatten identically"""
     sd = mts.scenes.spheres()
     fs = orc.FlatScene(sd)
     arr = mts.abi.scene_arrays(fs.scene.contents)
-    assert list(arr["shape_type"][-5:]) == [1] * 5 and arr["tri_idx"][-1, 0] == 0xFFFFFFFF
-    assert (arr["triaccel"][-5:, 0] == 0xFFFFFFFF).all() and (arr["triaccel"][:-5, 0] <= 3).all()
+    assert list(arr["shape_type"][-8:]) == [1] * 8 and arr["tri_idx"][-1, 0] == 0xFFFFFFFF
+    assert (arr["triaccel"][-8:, 0] == 0xFFFFFFFF).all() and (arr["triaccel"][:-8, 0] <= 3).all()
     pscene = mts.Scene(sd)                      # keep it alive: .sc points into it
     prod = mts.abi.scene_arrays(pscene.sc)
     for k in arr:
@@ -275,7 +406,7 @@ def test_sphere_shape(mts, orc):
     rays = chord_rays(20000, (0, 1, 0), 2.2, seed=11)
     hits = orc.trace_rays(fs.scene, rays)
     nprim = len(arr["tri_idx"])
-    on_sphere = hits[:, 3] >= nprim - 5
+    on_sphere = hits[:, 3] >= nprim - 8
     on_sphere &= hits[:, 3] != 0xFFFFFFFF
     assert on_sphere.sum() > 100
     t = hits[:, 0].view(np.float32)
