@@ -65,11 +65,14 @@ enum {
 	MTSGPU_LUM_POINT = 2,    /* params: [0..2] intensity [3..5] position                (src/luminaires/point.cpp) */
 	MTSGPU_LUM_DIRECTIONAL = 3, /* [0..2] intensity [3..5] direction (unit) [6] disk radius = scene bsphere radius
 	                               (src/luminaires/directional.cpp:65-91)                                        */
-	MTSGPU_LUM_SPOT = 4      /* [0..2] intensity [3..5] position [6] cos(beamWidth) [7] cos(cutoffAngle)
+	MTSGPU_LUM_SPOT = 4,     /* [0..2] intensity [3..5] position [6] cos(beamWidth) [7] cos(cutoffAngle)
 	                            [8] cutoffAngle (rad) [9] 1/(cutoffAngle-beamWidth) [10..18] world->luminaire
 	                            3x3 (row major) [19] beamWidth (rad)           (src/luminaires/spot.cpp:33-118) */
+	MTSGPU_LUM_ENVMAP = 5    /* [0] intensityScale [3..5] bsphere centre [6] radius (envmap.cpp:112-126)
+	                            [7..15] world->luminaire 3x3 [16..24] luminaire->world 3x3 (row major); the image and
+	                            its sampling density are the env_* arrays of the scene   (src/luminaires/envmap.cpp) */
 };
-#define MTSGPU_LUM_NPARAMS 24
+#define MTSGPU_LUM_NPARAMS 32
 
 /* Sampler kinds.  *_KEYED are the per-(pixel,sample)-keyed forms of the two
  * reference samplers (src/samplers/{independent,ldsampler}.cpp): identical
@@ -144,6 +147,15 @@ typedef struct mtsgpu_scene {
 	const float    *lum_sel_pdf; /* [n_lums]                                                  */
 	float lum_sel_sum;           /* DiscretePDF::getOriginalSum()                             */
 	int32_t background_lum;      /* index of the background luminaire or -1                   */
+
+	/* --- the environment map of the MTSGPU_LUM_ENVMAP luminaire (at most one per scene) ---
+	 * level 0 of MIPMap::fromBitmap (src/librender/mipmap.cpp:30-92,161-181: powers of two, ERepeat) and the
+	 * DiscretePDF over level min(3, levels-1) that EnvMapLuminaire::configure builds (envmap.cpp:95-110) */
+	uint32_t env_width, env_height;
+	const float *env_pixels;     /* [env_height][env_width][3] linear RGB                     */
+	uint32_t env_pdf_width, env_pdf_height;
+	const float *env_pdf;        /* [w*h]   DiscretePDF::m_pdf after build()                  */
+	const float *env_cdf;        /* [w*h+1] DiscretePDF::m_cdf                                */
 } mtsgpu_scene;
 
 /* PerspectiveCameraImpl state (src/cameras/perspective.cpp:43-112) */
@@ -251,9 +263,14 @@ typedef struct mtsgpu_scene_desc {
 	const float    *bsdf_params;
 	uint32_t n_lums;
 	const uint32_t *lum_type;    /* area luminaires must be referenced by exactly one mesh */
-	const float    *lum_params;  /* constant/directional: bsphere-derived entries are computed; spot: [6],[7],[9] are computed */
+	const float    *lum_params;  /* constant/directional/envmap: bsphere-derived entries are computed; spot: [6],[7],[9] are computed */
 	float camera_pos[3];         /* for ConstantLuminaire::preprocess (constant.cpp:49-63) */
 	int32_t has_camera;
+	/* bitmap of the envmap luminaire, any size: [env_height][env_width][3] linear RGB (what Bitmap::getFloatData
+	 * holds after the EXR is read, mipmap.cpp:161-181); its lum_params carry [0] intensityScale and
+	 * [16..24] luminaire->world rotation, everything else is derived */
+	uint32_t env_width, env_height;
+	const float *env_bitmap;
 } mtsgpu_scene_desc;
 
 /* kd-tree build parameters (gkdtree.h:711-724 defaults when 0 / negative) */

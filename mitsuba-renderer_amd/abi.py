@@ -9,8 +9,8 @@ ABI_VERSION = 2
 BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET, BSDF_MIRROR, BSDF_PHONG, BSDF_ROUGHGLASS = 0, 1, 2, 3, 4, 5, 6
 BSDF_TWOSIDED = 0x100
 BSDF_NPARAMS = 16
-LUM_AREA, LUM_CONSTANT, LUM_POINT, LUM_DIRECTIONAL, LUM_SPOT = 0, 1, 2, 3, 4
-LUM_NPARAMS = 24
+LUM_AREA, LUM_CONSTANT, LUM_POINT, LUM_DIRECTIONAL, LUM_SPOT, LUM_ENVMAP = 0, 1, 2, 3, 4, 5
+LUM_NPARAMS = 32
 SAMPLER_INDEPENDENT_KEYED, SAMPLER_LD_KEYED = 0, 1
 SHAPE_HAS_NORMALS = 1
 SHAPE_TRIMESH, SHAPE_SPHERE = 0, 1
@@ -37,6 +37,8 @@ class Scene(C.Structure):
         ("lum_inv_area", f32p), ("lum_cdf_offset", u32p), ("lum_tri_cdf", f32p),
         ("lum_sel_cdf", f32p), ("lum_sel_pdf", f32p),
         ("lum_sel_sum", C.c_float), ("background_lum", C.c_int32),
+        ("env_width", C.c_uint32), ("env_height", C.c_uint32), ("env_pixels", f32p),
+        ("env_pdf_width", C.c_uint32), ("env_pdf_height", C.c_uint32), ("env_pdf", f32p), ("env_cdf", f32p),
     ]
 
 
@@ -77,6 +79,7 @@ class SceneDesc(C.Structure):
         ("n_bsdfs", C.c_uint32), ("bsdf_type", u32p), ("bsdf_params", f32p),
         ("n_lums", C.c_uint32), ("lum_type", u32p), ("lum_params", f32p),
         ("camera_pos", C.c_float * 3), ("has_camera", C.c_int32),
+        ("env_width", C.c_uint32), ("env_height", C.c_uint32), ("env_bitmap", f32p),
     ]
 
 
@@ -138,4 +141,9 @@ def scene_arrays(sc):
     }
     ncdf = int(out["lum_cdf_offset"][-1]) if nl else 0
     out["lum_tri_cdf"] = np_from(sc.lum_tri_cdf, (ncdf,), np.float32)
+    out["env_size"] = (int(sc.env_width), int(sc.env_height), int(sc.env_pdf_width), int(sc.env_pdf_height))
+    out["env_pixels"] = np_from(sc.env_pixels, (sc.env_height, sc.env_width, 3), np.float32)
+    npdf = sc.env_pdf_width * sc.env_pdf_height
+    out["env_pdf"] = np_from(sc.env_pdf, (npdf,), np.float32)
+    out["env_cdf"] = np_from(sc.env_cdf, (npdf + 1 if npdf else 0,), np.float32)
     return out

@@ -399,7 +399,18 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 			if (shapeType((uint32_t) s) != MTSGPU_SHAPE_TRIMESH) {
 				if (sc->lum_cdf_offset[l + 1] != sc->lum_cdf_offset[l]) return fail(c, MTSGPU_EINVAL, "luminaire %u: a non-mesh emitter has no triangle CDF", l);
 			} else if (sc->lum_cdf_offset[l + 1] - sc->lum_cdf_offset[l] != n + 1) return fail(c, MTSGPU_EINVAL, "luminaire %u: CDF size mismatch", l);
-		} else if (sc->lum_type[l] > MTSGPU_LUM_SPOT) {
+		} else if (sc->lum_type[l] == MTSGPU_LUM_ENVMAP) {
+			// everything env_triangle / env_pdf index with (envmap.cpp:123-193)
+			if ((int32_t) l != sc->background_lum) return fail(c, MTSGPU_EINVAL, "luminaire %u: the envmap must be the background luminaire", l);
+			const uint64_t np = (uint64_t) sc->env_pdf_width * sc->env_pdf_height;
+			if (!sc->env_pixels || !sc->env_pdf || !sc->env_cdf || sc->env_width == 0 || sc->env_height == 0 || np == 0
+			    || sc->env_width > 16384 || sc->env_height > 16384 || np > (1u << 26))
+				return fail(c, MTSGPU_EINVAL, "luminaire %u: missing or oversized environment map", l);
+			for (uint64_t i = 0; i < np; ++i)
+				if (!(sc->env_cdf[i] <= sc->env_cdf[i + 1]) || !(sc->env_pdf[i] >= 0.0f)) return fail(c, MTSGPU_EINVAL, "luminaire %u: the environment map's CDF is not monotone", l);
+			const float *LP = sc->lum_params + (size_t) MTSGPU_LUM_NPARAMS * l;
+			for (int i = 0; i < 25; ++i) if (!std::isfinite(LP[i])) return fail(c, MTSGPU_EINVAL, "luminaire %u: non-finite parameter", l);
+		} else if (sc->lum_type[l] > MTSGPU_LUM_ENVMAP) {
 			return fail(c, MTSGPU_EINVAL, "luminaire %u: unknown type", l);
 		}
 	}
@@ -522,6 +533,14 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	rc |= upload(c, &d.lum_tri_cdf, sc->lum_tri_cdf, sc->lum_cdf_offset[sc->n_lums]);
 	rc |= upload(c, &d.lum_sel_cdf, sc->lum_sel_cdf, (size_t) sc->n_lums + 1);
 	rc |= upload(c, &d.lum_sel_pdf, sc->lum_sel_pdf, sc->n_lums);
+	if (sc->background_lum >= 0 && sc->lum_type[sc->background_lum] == MTSGPU_LUM_ENVMAP) {
+		const size_t np = (size_t) sc->env_pdf_width * sc->env_pdf_height;
+		rc |= upload(c, &d.env_pixels, sc->env_pixels, 3 * (size_t) sc->env_width * sc->env_height);
+		rc |= upload(c, &d.env_pdf, sc->env_pdf, np);
+		rc |= upload(c, &d.env_cdf, sc->env_cdf, np + 1);
+		d.env_width = sc->env_width; d.env_height = sc->env_height;
+		d.env_pdf_width = sc->env_pdf_width; d.env_pdf_height = sc->env_pdf_height;
+	}
 	if (rc) { freeAll(c->sceneAllocs); return rc; }
 	d.lum_sel_sum = sc->lum_sel_sum; d.background_lum = sc->background_lum;
 	d.n_lums = sc->n_lums; d.n_nodes = sc->n_nodes; d.n_tris = sc->n_tris; d.n_shapes = sc->n_shapes;

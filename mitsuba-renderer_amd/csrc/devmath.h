@@ -190,6 +190,27 @@ HD float dacos(float x) {
 	return (float) (2.0 * atan_d(sqrt((1.0 - xd) / (1.0 + xd))));
 }
 
+// std::atan2 (envmap.cpp:149,185): quadrant logic around the binary64 arctangent of y / x
+HD float datan2(float y, float x) {
+	const double PI = 3.14159265358979311600e+00, PIO2 = 1.57079632679489655800e+00;
+	if (x != x || y != y) return __builtin_nanf("");
+	const double yd = (double) y, xd = (double) x;
+	const bool ysign = (__builtin_bit_cast(uint32_t, y) >> 31) != 0u, xsign = (__builtin_bit_cast(uint32_t, x) >> 31) != 0u;
+	double r;
+	if (xd == 0.0) {
+		if (yd == 0.0) r = xsign ? PI : 0.0;
+		else return (float) (yd > 0.0 ? PIO2 : -PIO2);
+		return (float) (ysign ? -r : r);
+	}
+	if ((xd == (double) MG_INF || xd == -(double) MG_INF) && (yd == (double) MG_INF || yd == -(double) MG_INF)) {
+		r = xd > 0.0 ? 0.25 * PI : 0.75 * PI;
+		return (float) (yd > 0.0 ? r : -r);
+	}
+	r = atan_d(yd / xd);
+	if (xd < 0.0) r += ysign ? -PI : PI;
+	return (float) r;
+}
+
 HD float dpow4(float x) { double d = (double) x * (double) x; return (float) (d * d); }
 
 // binary64 exp / log (same reductions and polynomials as dexp / dlog) for pow

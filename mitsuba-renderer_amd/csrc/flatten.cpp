@@ -68,6 +68,8 @@ float buildCdf(const std::vector<float> &values, float *cdf, float *pdf) {
 
 } // namespace
 
+void buildEnvMap(const mtsgpu_scene_desc &d, float *P, FlatScene &fs);     // defined below (needs the matrix inverse)
+
 void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatScene &fs) {
 	const uint32_t nShapes = d.n_meshes, nLums = d.n_lums;
 	size_t nVerts = 0, nTris = 0;
@@ -219,6 +221,21 @@ void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatSc
 			}
 			P[3] = center.x; P[4] = center.y; P[5] = center.z; P[6] = br;
 			background = (int32_t) l;
+		} else if (fs.lumType[l] == MTSGPU_LUM_ENVMAP) {
+			// EnvMapLuminaire::preprocess (src/luminaires/envmap.cpp:112-126): the scene's bounding sphere, enlarged
+			float br = radius;
+			br *= 1.01f;
+			if (d.has_camera) {
+				const float old = br;
+				br = std::max(br, length(ld3(d.camera_pos) - center));
+				if (old != br)
+					br *= 1.01f;
+			}
+			P[3] = center.x; P[4] = center.y; P[5] = center.z; P[6] = br;
+			if (background >= 0)
+				throw std::runtime_error("flatten: more than one background luminaire");
+			buildEnvMap(d, P, fs);
+			background = (int32_t) l;
 		} else if (fs.lumType[l] == MTSGPU_LUM_POINT) {
 			// nothing to derive (point.cpp:28-33)
 		} else if (fs.lumType[l] == MTSGPU_LUM_DIRECTIONAL) {
@@ -239,7 +256,10 @@ void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatSc
 	}
 
 	mtsgpu_scene &sc = fs.sc;
+	const uint32_t envW = sc.env_width, envH = sc.env_height, envPW = sc.env_pdf_width, envPH = sc.env_pdf_height;   // set by buildEnvMap
 	std::memset(&sc, 0, sizeof(sc));
+	sc.env_width = envW; sc.env_height = envH; sc.env_pdf_width = envPW; sc.env_pdf_height = envPH;
+	sc.env_pixels = fs.envPixels.data(); sc.env_pdf = fs.envPdf.data(); sc.env_cdf = fs.envCdf.data();
 	sc.abi_version = MTSGPU_ABI_VERSION;
 	sc.n_shapes = nShapes; sc.n_tris = tbase; sc.n_verts = vbase;
 	sc.vtx_pos = fs.vtxPos.data(); sc.vtx_nrm = fs.vtxNrm.data(); sc.tri_idx = fs.triIdx.data();
@@ -364,6 +384,143 @@ Xf scale(float x, float y, float z) {                                           
 }
 
 } // namespace
+
+// ---------------------------------------------------------------------------
+// Environment map: MIPMap::fromBitmap (src/librender/mipmap.cpp:161-181) -> MIPMap::MIPMap with the
+// defaults EEWA / ERepeat (:30-108), and the sampling density of EnvMapLuminaire::configure
+// (src/luminaires/envmap.cpp:95-110)
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Rgb { float c[3]; };
+struct Image {
+	int w = 0, h = 0;
+	std::vector<Rgb> px;
+	Image(int w_, int h_) : w(w_), h(h_), px((size_t) w_ * h_, Rgb{ { 0, 0, 0 } }) {}
+	Rgb &at(int x, int y) { return px[(size_t) x + (size_t) w * y]; }
+	// MIPMap::getTexel with ERepeat (mipmap.cpp:203-224); modulo (util.cpp:424-427)
+	const Rgb &texel(int x, int y) const {
+		if (x <= 0 || y < 0 || x >= w || y >= h) { x = wrap(x, w); y = wrap(y, h); }
+		return px[(size_t) x + (size_t) w * y];
+	}
+	static int wrap(int a, int b) { const int r = a - (a / b) * b; return r < 0 ? r + b : r; }
+};
+
+bool isPow2(uint32_t v) { return v && !(v & (v - 1)); }
+uint32_t roundToPow2(uint32_t i) { i--; i |= i >> 1; i |= i >> 2; i |= i >> 4; i |= i >> 8; i |= i >> 16; return i + 1; }
+int log2iU32(uint32_t value) { int r = 0; while ((value >> r) != 0) r++; return r - 1; }        // util.cpp:410-415
+
+// lanczosSinc (util.cpp:664-674) with tau = 2; host libm like the reference
+float lanczosSinc(float t) {
+	const float tau = 2;
+	t = std::fabs(t);
+	if (t < kEpsilon) return 1.0f;
+	if (t > 1.0f) return 0.0f;
+	t *= kPi;
+	const float sincTerm = std::sin(t * tau) / (t * tau);
+	const float windowTerm = std::sin(t) / t;
+	return sincTerm * windowTerm;
+}
+
+struct ResampleWeight { int firstTexel; float weight[4]; };
+
+// MIPMap::resampleWeights (mipmap.cpp:183-201)
+std::vector<ResampleWeight> resampleWeights(int oldRes, int newRes) {
+	std::vector<ResampleWeight> w((size_t) newRes);
+	const float filterWidth = 2.0f;
+	for (int i = 0; i < newRes; ++i) {
+		const float center = (i + .5f) * oldRes / newRes;
+		w[i].firstTexel = (int) std::floor(center - filterWidth + 0.5f);
+		float weightSum = 0;
+		for (int j = 0; j < 4; ++j) {
+			const float pos = w[i].firstTexel + j + .5f;
+			const float weight = lanczosSinc((pos - center) / filterWidth);
+			weightSum += weight;
+			w[i].weight[j] = weight;
+		}
+		const float invWeights = 1.0f / weightSum;
+		for (int j = 0; j < 4; ++j) w[i].weight[j] *= invWeights;
+	}
+	return w;
+}
+
+} // namespace
+
+void buildEnvMap(const mtsgpu_scene_desc &d, float *P, FlatScene &fs) {
+	const int width = (int) d.env_width, height = (int) d.env_height;
+	if (!d.env_bitmap || width <= 0 || height <= 0 || width > 16384 || height > 16384)
+		throw std::runtime_error("flatten: the envmap luminaire needs a bitmap of at most 16384 x 16384 pixels");
+	Image src(width, height);
+	for (size_t i = 0; i < (size_t) width * height; ++i)
+		for (int c = 0; c < 3; ++c)
+			src.px[i].c[c] = std::max(0.0f, d.env_bitmap[3 * i + c]);          // fromLinearRGB + clampNegative
+	Image level0 = src;
+	if (!isPow2((uint32_t) width) || !isPow2((uint32_t) height)) {
+		// up-sampling to powers of two, x then y (mipmap.cpp:35-78)
+		const int W = (int) roundToPow2((uint32_t) width), H = (int) roundToPow2((uint32_t) height);
+		Image tmp(W, height);
+		const std::vector<ResampleWeight> wx = resampleWeights(width, W);
+		for (int y = 0; y < height; ++y)
+			for (int x = 0; x < W; ++x)
+				for (int j = 0; j < 4; ++j) {
+					int pos = wx[x].firstTexel + j;
+					if (pos < 0 || pos >= height)                                // sic: compared with the height (mipmap.cpp:48)
+						pos = Image::wrap(pos, width);
+					if (pos >= 0 && pos < width)
+						for (int c = 0; c < 3; ++c) tmp.at(x, y).c[c] += src.at(pos, y).c[c] * wx[x].weight[j];
+				}
+		level0 = Image(W, H);
+		const std::vector<ResampleWeight> wy = resampleWeights(height, H);
+		for (int x = 0; x < W; ++x)
+			for (int y = 0; y < H; ++y)
+				for (int j = 0; j < 4; ++j) {
+					int pos = wy[y].firstTexel + j;
+					if (pos < 0 || pos >= height)
+						pos = Image::wrap(pos, height);
+					if (pos >= 0 && pos < height)
+						for (int c = 0; c < 3; ++c) level0.at(x, y).c[c] += tmp.at(x, pos).c[c] * wy[y].weight[j];
+				}
+		for (Rgb &p : level0.px)
+			for (int c = 0; c < 3; ++c) p.c[c] = std::max(0.0f, p.c[c]);
+	}
+	// the number of levels follows the ORIGINAL size (mipmap.cpp:81); the density uses level min(3, levels - 1)
+	const int levels = 1 + log2iU32((uint32_t) std::max(width, height));
+	const int pdfLevel = std::min(3, levels - 1);
+	Image cur = level0;
+	for (int i = 1; i <= pdfLevel; ++i) {
+		Image next(std::max(1, cur.w / 2), std::max(1, cur.h / 2));
+		for (int y = 0; y < next.h; ++y)
+			for (int x = 0; x < next.w; ++x)
+				for (int c = 0; c < 3; ++c)
+					next.at(x, y).c[c] = (cur.texel(2 * x, 2 * y).c[c] + cur.texel(2 * x + 1, 2 * y).c[c]
+					                      + cur.texel(2 * x, 2 * y + 1).c[c] + cur.texel(2 * x + 1, 2 * y + 1).c[c]) * 0.25f;
+		cur = next;
+	}
+	std::vector<float> values((size_t) cur.w * cur.h);
+	size_t index = 0;
+	for (int y = 0; y < cur.h; ++y) {
+		const float sinFactor = std::sin(kPi * (y + .5f) / cur.h);
+		for (int x = 0; x < cur.w; ++x) {
+			const Rgb &s = cur.at(x, y);
+			values[index++] = (s.c[0] * 0.212671f + s.c[1] * 0.715160f + s.c[2] * 0.072169f) * sinFactor;   // getLuminance
+		}
+	}
+	fs.envPdf.assign(values.size(), 0.0f);
+	fs.envCdf.assign(values.size() + 1, 0.0f);
+	buildCdf(values, fs.envCdf.data(), fs.envPdf.data());
+	fs.envPixels.resize(3 * level0.px.size());
+	for (size_t i = 0; i < level0.px.size(); ++i)
+		for (int c = 0; c < 3; ++c) fs.envPixels[3 * i + c] = level0.px[i].c[c];
+	fs.sc.env_width = (uint32_t) level0.w; fs.sc.env_height = (uint32_t) level0.h;
+	fs.sc.env_pdf_width = (uint32_t) cur.w; fs.sc.env_pdf_height = (uint32_t) cur.h;
+	// m_worldToLuminaire = m_luminaireToWorld.inverse() (luminaire.cpp:30-37)
+	M4 m{}, inv{};
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m.m[i][j] = P[16 + 3 * i + j];
+	m.m[3][3] = 1.0f;
+	if (!invert(m, inv))
+		throw std::runtime_error("flatten: the envmap's toWorld rotation is singular");
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) P[7 + 3 * i + j] = inv.m[i][j];
+}
 
 void makeCamera(const float origin[3], const float target[3], const float up[3], float fovDeg, int width, int height,
                 mtsgpu_camera &out) {

@@ -24,6 +24,7 @@ bool clippedTriangleBox(const float *p0, const float *p1, const float *p2, const
 struct FlatScene {
 	mtsgpu_scene sc;
 	KdTree kd;
+	std::vector<float> envPixels, envPdf, envCdf;
 	std::vector<float> vtxPos, vtxNrm, shapeParams, bsdfParams, lumParams, lumInvArea, lumTriCdf, lumSelCdf, lumSelPdf;
 	std::vector<uint32_t> triIdx, shapeTriOffset, shapeFlags, shapeType, triaccel, bsdfType, lumType, lumCdfOffset;
 	std::vector<int32_t> shapeBsdf, shapeLum, lumShape;

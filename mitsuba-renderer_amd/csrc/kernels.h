@@ -11,6 +11,7 @@ constexpr int kTraceBlock = 256;
 constexpr unsigned kTraceGridBlocks = 256 * 8;   // largest persistent traversal grid: 256 CUs x resident workgroups
 constexpr unsigned trace_blocks_per_cu(int mode) { return mode == 0 ? 7u : 8u; }   // closest-hit state needs 72 VGPRs, shadow rays 64
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
+constexpr int kLumStride = 32;        // MTSGPU_LUM_NPARAMS
 constexpr int kCounterStride = 32;    // one 128-byte line per queue counter (atomics on one line serialise)
 constexpr int kBinShards = 16;        // the closest-hit kernel appends to bins[b] through 16 independent segments
 constexpr int kNumCounters = kNumBins * kBinShards + 2;   // bins x shards, next, shadow
@@ -30,6 +31,9 @@ struct DScene {
 	const int32_t  *shape_bsdf, *shape_lum;
 	const uint32_t *shape_type;   // MTSGPU_SHAPE_*
 	const float    *shape_params; // [n_shapes][24]
+	// environment map (level 0 of the MIPMap, RGB) and its sampling density (envmap.cpp:95-110)
+	const float    *env_pixels, *env_pdf, *env_cdf;
+	uint32_t        env_width, env_height, env_pdf_width, env_pdf_height;
 	const uint32_t *shape_flags, *shape_tri_offset;
 	const uint32_t *bsdf_type;
 	const float    *bsdf_params;

@@ -721,13 +721,61 @@ __device__ __forceinline__ bool bsphere_ray_intersect(V3 center, float radius, V
 	return true;
 }
 
+// ---- EnvMapLuminaire (src/luminaires/envmap.cpp) ----
+// MIPMap::triangle(0, x, y) with ERepeat (mipmap.cpp:226-243, getTexel :203-224)
+__device__ __forceinline__ V3 env_triangle(const DScene &sc, float x, float y) {
+	const int W = (int) sc.env_width, H = (int) sc.env_height;
+	x = x * W - 0.5f;
+	y = y * H - 0.5f;
+	const int xPos = (int) floorf(x), yPos = (int) floorf(y);
+	const float dx = x - xPos, dy = y - yPos;
+	V3 acc(0, 0, 0);
+	#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		int tx = xPos + (k >> 1), ty = yPos + (k & 1);
+		if (tx <= 0 || ty < 0 || tx >= W || ty >= H) {
+			int r = tx - (tx / W) * W; tx = (r < 0) ? r + W : r;               // modulo (util.cpp:424-427)
+			r = ty - (ty / H) * H; ty = (r < 0) ? r + H : r;
+		}
+		const float *t = sc.env_pixels + 3 * ((size_t) tx + (size_t) W * ty);
+		const float a = (k < 2) ? (1.0f - dx) : dx, b = (k & 1) ? dy : (1.0f - dy);
+		const V3 term(t[0] * a * b, t[1] * a * b, t[2] * a * b);
+		acc = (k == 0) ? term : V3(acc.x + term.x, acc.y + term.y, acc.z + term.z);
+	}
+	return acc;
+}
+// Le(direction) (envmap.cpp:147-153); LP = luminaire parameter block
+__device__ __forceinline__ V3 env_le(const DScene &sc, const float *LP, V3 dir) {
+	const float *M = LP + 7;
+	const V3 d(M[0] * dir.x + M[1] * dir.y + M[2] * dir.z, M[3] * dir.x + M[4] * dir.y + M[5] * dir.z, M[6] * dir.x + M[7] * dir.y + M[8] * dir.z);
+	const float u = .5f * (1 + datan2(d.x, -d.z) / kPi);
+	const float v = dacos(smax(-1.0f, smin(1.0f, d.y))) / kPi;
+	const V3 t = env_triangle(sc, u, v);
+	return V3(t.x * LP[0], t.y * LP[0], t.z * LP[0]);
+}
+// pdf(p, lRec, delta) (envmap.cpp:176-193); ld = lRec.d
+__device__ __forceinline__ float env_pdf(const DScene &sc, const float *LP, V3 ld) {
+	const float *M = LP + 7;
+	const V3 nd = -ld;
+	const V3 d(M[0] * nd.x + M[1] * nd.y + M[2] * nd.z, M[3] * nd.x + M[4] * nd.y + M[5] * nd.z, M[6] * nd.x + M[7] * nd.y + M[8] * nd.z);
+	const int rx = (int) sc.env_pdf_width, ry = (int) sc.env_pdf_height;
+	const float x = .5f * (1 + datan2(d.x, -d.z) / kPi) * rx;
+	const float y = dacos(smax(-1.0f, smin(1.0f, d.y))) / kPi * ry;
+	int xPos = (int) floorf(x); xPos = xPos < 0 ? 0 : (xPos > rx - 1 ? rx - 1 : xPos);
+	int yPos = (int) floorf(y); yPos = yPos < 0 ? 0 : (yPos > ry - 1 ? ry - 1 : yPos);
+	const float pdf = sc.env_pdf[xPos + yPos * rx];
+	const float sinTheta = sqrtf(smax(kEpsilon, 1 - d.y * d.y));
+	const float psx = 2 * kPi / rx, psy = kPi / ry;
+	return pdf / (psx * psy * sinTheta);
+}
+
 // Scene::sampleLuminaire without the visibility test (scene.cpp:396-415):
 // returns true when a shadow ray has to be traced; value is already divided by pdf.
 __device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s0, float s1, LRec &lRec) {
 	float sx = s0, sy = s1;
 	const int l = dpdf_sample_reuse(sc.lum_sel_cdf, sc.n_lums, sx);
 	const float lumPdf = sc.lum_sel_pdf[l];
-	const float *LP = sc.lum_params + 24 * (size_t) l;
+	const float *LP = sc.lum_params + kLumStride * (size_t) l;
 	if (sc.lum_type[l] == 0u && sc.shape_type[sc.lum_shape[l]] == 1u) {
 		// AreaLuminaire::sample (area.cpp:68-79) -> Sphere::sampleSolidAngle (src/shapes/sphere.cpp:196-237)
 		const float *SP = sc.shape_params + 24 * (size_t) sc.lum_shape[l];
@@ -826,6 +874,34 @@ __device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s
 			else if (!(cosTheta >= LP[6])) result = result * ((LP[8] - dacos(cosTheta)) * LP[9]);
 		}
 		lRec.value = result * (invDist * invDist);
+	} else if (sc.lum_type[l] == 5u) {
+		// EnvMapLuminaire::sampleDirection + sample (envmap.cpp:123-145, :159-172)
+		const int rx = (int) sc.env_pdf_width, ry = (int) sc.env_pdf_height;
+		const int idx = dpdf_sample_reuse(sc.env_cdf, (uint32_t) (rx * ry), sx);
+		float pdf = sc.env_pdf[idx];
+		const int row = idx / rx, col = idx - rx * row;
+		const float x = col + sx, y = row + sy;
+		const V3 tv = env_triangle(sc, x * (1.0f / rx), y * (1.0f / ry));
+		const float psx = 2 * kPi / rx, psy = kPi / ry;
+		const float theta = psy * y, phi = psx * x - kPi;
+		float sinTheta, cosTheta, sinPhi, cosPhi;
+		dsincos(theta, sinTheta, cosTheta); dsincos(phi, sinPhi, cosPhi);
+		pdf = pdf / (psx * psy * sinTheta);
+		const float *L2W = LP + 16;
+		const V3 v(-sinTheta * sinPhi, -cosTheta, sinTheta * cosPhi);
+		const V3 d(L2W[0] * v.x + L2W[1] * v.y + L2W[2] * v.z, L2W[3] * v.x + L2W[4] * v.y + L2W[5] * v.z, L2W[6] * v.x + L2W[7] * v.y + L2W[8] * v.z);
+		lRec.pdf = pdf;
+		lRec.value = V3(tv.x * LP[0], tv.y * LP[0], tv.z * LP[0]);
+		const V3 center(LP[3], LP[4], LP[5]);
+		const float radius = LP[6];
+		float nearHit, farHit;
+		if (length(p - center) <= radius && bsphere_ray_intersect(center, radius, p, -d, nearHit, farHit)) {
+			lRec.p = V3(p.x - d.x * nearHit, p.y - d.y * nearHit, p.z - d.z * nearHit);
+			lRec.n = normalize(center - lRec.p);
+			lRec.d = d;
+		} else {
+			lRec.pdf = 0.0f;
+		}
 	} else if (sc.lum_type[l] == 3u) {
 		// DirectionalLuminaire::sample (directional.cpp:84-91)
 		const V3 dir(LP[3], LP[4], LP[5]);
@@ -862,7 +938,7 @@ __device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s
 }
 
 // Scene::pdfLuminaire (scene.cpp:381-394); Shape::pdfSolidAngle (shape.cpp:77-83); constant.cpp:89-91
-__device__ __forceinline__ float pdf_luminaire(const DScene &sc, V3 p, int lum, V3 lp, V3 ln) {
+__device__ __forceinline__ float pdf_luminaire(const DScene &sc, V3 p, int lum, V3 lp, V3 ln, V3 ld) {
 	const float fraction = 1.0f / sc.lum_sel_sum;
 	float pdf;
 	if (sc.lum_type[lum] == 0u && sc.shape_type[sc.lum_shape[lum]] == 1u) {
@@ -884,6 +960,8 @@ __device__ __forceinline__ float pdf_luminaire(const DScene &sc, V3 p, int lum, 
 		const float distSquared = dot(lumToPoint, lumToPoint);
 		const float invDP = smax(0.0f, sqrtf(distSquared) / dot(lumToPoint, ln));
 		pdf = sc.lum_inv_area[lum] * distSquared * invDP;
+	} else if (sc.lum_type[lum] == 5u) {
+		pdf = env_pdf(sc, sc.lum_params + kLumStride * (size_t) lum, ld);
 	} else {
 		pdf = 1.0f / (4 * kPi);
 	}
@@ -1393,16 +1471,16 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 				if (valid) {
 					if (shapeLum >= 0) {
 						// LuminaireSamplingRecord(its, -ray.d); value = its.Le(-ray.d) (area.cpp:62-66)
-						const float *LP = sc.lum_params + 24 * (size_t) shapeLum;
+						const float *LP = sc.lum_params + kLumStride * (size_t) shapeLum;
 						lp = its.p; ln = its.geoN; llum = shapeLum;
 						lvalue = (dot(-rayD, its.geoN) <= 0) ? V3(0, 0, 0) : V3(LP[0], LP[1], LP[2]);
 						hitLuminaire = true;
 					}
 				} else {
 					if (sc.background_lum >= 0) {
-						const float *LP = sc.lum_params + 24 * (size_t) sc.background_lum;
+						const float *LP = sc.lum_params + kLumStride * (size_t) sc.background_lum;
 						llum = sc.background_lum;
-						lvalue = V3(LP[0], LP[1], LP[2]);
+						lvalue = (sc.lum_type[llum] == 5u) ? env_le(sc, LP, normalize(rayD)) : V3(LP[0], LP[1], LP[2]);
 						hitLuminaire = true;
 					} else {
 						depth++;
@@ -1410,7 +1488,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 					}
 				}
 				if (hitLuminaire) {
-					const float lumPdf = (!(sampledType & T_DELTA)) ? pdf_luminaire(sc, rayO, llum, lp, ln) : 0.0f;
+					const float lumPdf = (!(sampledType & T_DELTA)) ? pdf_luminaire(sc, rayO, llum, lp, ln, -rayD) : 0.0f;
 					const float weight = mi_weight(bsdfPdf, lumPdf);
 					Li.x += thr.x * lvalue.x * bsdfVal.x * weight;
 					Li.y += thr.y * lvalue.y * bsdfVal.y * weight;
@@ -1434,8 +1512,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 			// ---- head of the iteration (path.cpp:62-98) ----
 			if (!valid) {
 				if ((flags & F_EMITTED) && sc.background_lum >= 0) {
-					const float *LP = sc.lum_params + 24 * (size_t) sc.background_lum;
-					Li.x += thr.x * LP[0]; Li.y += thr.y * LP[1]; Li.z += thr.z * LP[2];
+					const float *LP = sc.lum_params + kLumStride * (size_t) sc.background_lum;
+					const V3 le = (sc.lum_type[sc.background_lum] == 5u) ? env_le(sc, LP, normalize(rayD)) : V3(LP[0], LP[1], LP[2]);
+					Li.x += thr.x * le.x; Li.y += thr.y * le.y; Li.z += thr.z * le.z;
 				}
 				break;
 			}
@@ -1446,7 +1525,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 			const bool twoSided = (sc.bsdf_type[bsdfIdx] & 0x100u) != 0;
 			if (shapeLum >= 0 && (flags & F_EMITTED)) {
 				// Li += pathThroughput * its.Le(-ray.d) (path.cpp:80-81, area.cpp:62-66)
-				const float *LP = sc.lum_params + 24 * (size_t) shapeLum;
+				const float *LP = sc.lum_params + kLumStride * (size_t) shapeLum;
 				const V3 le = (dot(-rayD, its.geoN) <= 0) ? V3(0.0f, 0.0f, 0.0f) : V3(LP[0], LP[1], LP[2]);
 				Li.x += thr.x * le.x; Li.y += thr.y * le.y; Li.z += thr.z * le.z;
 			}

@@ -43,6 +43,7 @@ class SceneDescription:
         self.camera = dict(origin=(0.0, 1.0, 3.4), target=(0.0, 1.0, 0.0), up=(0.0, 1.0, 0.0), fov=39.3)
         self.max_depth = -1
         self.rr_depth = 10
+        self.env_bitmap = None      # [H][W][3] float32 of the envmap luminaire
 
     # --- property blocks --------------------------------------------------
     def add_bsdf(self, btype, params):
@@ -121,6 +122,15 @@ class SceneDescription:
         P[10:13] = right; P[13:16] = new_up; P[16:19] = d    # world -> luminaire rotation (rows)
         return l
 
+    def envmap(self, bitmap, intensity_scale=1.0, to_world=None):
+        """<luminaire type="envmap"> (src/luminaires/envmap.cpp): lat-long bitmap [H][W][3], optional rotation"""
+        l = self.add_lum(abi.LUM_ENVMAP, [intensity_scale, 0, 0])
+        R = np.eye(3, dtype=np.float32) if to_world is None else np.asarray(to_world, dtype=np.float32).reshape(3, 3)
+        self.lum_params[l][16:25] = R.ravel()
+        self.env_bitmap = np.ascontiguousarray(bitmap, dtype=np.float32)
+        assert self.env_bitmap.ndim == 3 and self.env_bitmap.shape[2] == 3
+        return l
+
     def add_lum(self, ltype, intensity):
         p = np.zeros(abi.LUM_NPARAMS, dtype=np.float32)
         p[:3] = np.asarray(intensity, dtype=np.float32)
@@ -175,6 +185,10 @@ class SceneDescription:
         d.lum_params = abi.ptr(lp, abi.f32p)
         d.camera_pos = (C.c_float * 3)(*[float(v) for v in self.camera["origin"]])
         d.has_camera = 1
+        if self.env_bitmap is not None:
+            d.env_width, d.env_height = self.env_bitmap.shape[1], self.env_bitmap.shape[0]
+            d.env_bitmap = abi.ptr(self.env_bitmap, abi.f32p)
+            keep.append(self.env_bitmap)
         keep += [meshes, bt, bp, lt, lp]
         return d, keep
 
@@ -377,5 +391,38 @@ def spheres():
     return sd
 
 
+def env_bitmap(width=96, height=40, seed=5):
+    """a synthetic HDR lat-long image: sky gradient, a small hot sun, ground colour, hash noise (not a power of two,
+    so MIPMap's Lanczos up-sampling runs)"""
+    y, x = np.mgrid[0:height, 0:width].astype(np.float32)
+    v = (y + F(0.5)) / F(height)
+    img = np.zeros((height, width, 3), dtype=np.float32)
+    sky = (F(1) - v)[..., None] * np.array([0.5, 0.7, 1.2], dtype=np.float32) + F(0.15)
+    ground = np.array([0.25, 0.2, 0.12], dtype=np.float32)
+    img[:] = np.where((v < F(0.55))[..., None], sky, ground)
+    sx, sy = int(width * 0.3), int(height * 0.22)
+    img[sy:sy + 2, sx:sx + 3] = np.array([60.0, 55.0, 40.0], dtype=np.float32)
+    h = (x.astype(np.uint32) * np.uint32(73856093) ^ y.astype(np.uint32) * np.uint32(19349663) ^ np.uint32(seed * 83492791)) & np.uint32(0xFFFF)
+    img *= (F(0.9) + F(0.2) * h.astype(np.float32) / F(65535.0))[..., None]
+    return img
+
+
+def envlit():
+    """an `envmap` luminaire (rotated) lights glossy / diffuse / glass objects on a ground plane"""
+    sd = SceneDescription("envlit")
+    grey = sd.lambertian(0.5)
+    pos, tri = _quad((-3.0, 0.0, -3.0), (6.0, 0, 0), (0, 0, 6.0), (0, 1, 0))
+    sd.add_mesh(pos, tri, bsdf=grey, face_normals=True, name="ground")
+    pos, tri = icosphere(2, 0.4, (-0.7, 0.4, 0.0))
+    sd.add_mesh(pos, tri, bsdf=sd.roughmetal(0.15), face_normals=False, name="metal")
+    sd.add_sphere((0.3, 0.45, -0.2), 0.45, bsdf=sd.dielectric())
+    sd.add_sphere((1.1, 0.3, 0.5), 0.3, bsdf=sd.phong(40.0, 0.5, 0.3))
+    c, s_ = F(np.cos(0.7)), F(np.sin(0.7))
+    sd.envmap(env_bitmap(), 0.4, to_world=[[c, 0, s_], [0, 1, 0], [-s_, 0, c]])
+    sd.camera = dict(origin=(0.2, 1.3, 3.6), target=(0.1, 0.4, 0.0), up=(0.0, 1.0, 0.0), fov=40.0)
+    sd.max_depth = 6
+    return sd
+
+
 def by_name(name, **kw):
-    return {"c1": cornell_c1, "c3": cornell_c3, "c5": cornell_c5, "next": next_rows, "spheres": spheres}[name](**kw)
+    return {"c1": cornell_c1, "c3": cornell_c3, "c5": cornell_c5, "next": next_rows, "spheres": spheres, "envlit": envlit}[name](**kw)

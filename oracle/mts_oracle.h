@@ -77,7 +77,7 @@ void  orc_fresnel_conductor(float cosTheta, const float eta[3], const float k[3]
 /* deterministic elementary functions shared (as a specification) with the kernels */
 float orc_sinf(float x); float orc_cosf(float x); float orc_expf(float x);
 float orc_logf(float x); float orc_atanf(float x); float orc_pow4f(float x);
-float orc_powf(float x, float y); float orc_acosf(float x);
+float orc_powf(float x, float y); float orc_acosf(float x); float orc_atan2f(float y, float x);
 void  orc_square_to_disk_concentric(const float s[2], float out[2]);
 
 /* ---------------- triangle code ------------------------------------------- */
@@ -134,6 +134,11 @@ void orc_tabulate_filter(int kind, float half_size, float stddev, orc_tabfilter 
  * ImageBlock::putSample, then added to the film (Film::putImageBlock, mfilm.cpp:118-143).
  * Summation order is fixed: inside a block by (pixel row-major, sample index),
  * blocks by (tx%2 + 2*(ty%2)) colour. */
+/* test hooks for the luminaires: Luminaire::sample without the visibility test (out = p, n, d, value, pdf) and
+ * Scene::pdfLuminaire */
+void orc_luminaire_sample(const mtsgpu_scene *sc, int l, const float p[3], const float sample[2], float out[13]);
+float orc_luminaire_pdf(const mtsgpu_scene *sc, int l, const float p[3], const float lp[3], const float ln[3], const float ld[3]);
+
 void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *p,
                       const orc_tabfilter *filter, int block_size, int part, int n_parts, int hq_edges,
                       float *film, mtsgpu_stats *stats);

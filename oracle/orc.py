@@ -66,6 +66,7 @@ def lib():
     L.orc_ld_generate_keyed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, f32p, f32p]
     L.orc_radical_inverse.argtypes = [C.c_int, C.c_uint64]; L.orc_radical_inverse.restype = C.c_float
     L.orc_radical_inverse_incremental.argtypes = [C.c_int, C.c_float]; L.orc_radical_inverse_incremental.restype = C.c_float
+    L.orc_atan2f.argtypes = [C.c_float, C.c_float]; L.orc_atan2f.restype = C.c_float
     for n in ("orc_sinf", "orc_cosf", "orc_expf", "orc_logf", "orc_atanf", "orc_pow4f"):
         getattr(L, n).argtypes = [C.c_float]; getattr(L, n).restype = C.c_float
     L.orc_square_to_sphere.argtypes = [f32p, f32p]
@@ -95,6 +96,8 @@ def lib():
     L.orc_tabulate_filter.argtypes = [C.c_int, C.c_float, C.c_float, C.POINTER(TabFilter)]
     L.orc_render_tiles.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(RenderParams), C.POINTER(TabFilter),
                                    C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(abi.Stats)]
+    L.orc_luminaire_sample.argtypes = [C.POINTER(abi.Scene), C.c_int, f32p, f32p, f32p]
+    L.orc_luminaire_pdf.argtypes = [C.POINTER(abi.Scene), C.c_int, f32p, f32p, f32p, f32p]; L.orc_luminaire_pdf.restype = C.c_float
     L.orc_bsdf_f.argtypes = [C.c_uint32, f32p, f32p, f32p, f32p]
     L.orc_bsdf_pdf.argtypes = [C.c_uint32, f32p, f32p, f32p]; L.orc_bsdf_pdf.restype = C.c_float
     L.orc_bsdf_sample.argtypes = [C.c_uint32, f32p, f32p, f32p, f32p, f32p, u32p, f32p]

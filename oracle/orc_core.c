@@ -425,6 +425,26 @@ float orc_atanf(float x) {
 	return (float) dm_atan_d((double) x);
 }
 
+/* std::atan2 (envmap.cpp:149,185): quadrant logic around the binary64 arctangent of y/x */
+float orc_atan2f(float y, float x) {
+	const double PI = 3.14159265358979311600e+00, PIO2 = 1.57079632679489655800e+00;
+	if (x != x || y != y) return NAN;
+	const double yd = (double) y, xd = (double) x;
+	double r;
+	if (xd == 0.0) {
+		if (yd == 0.0) r = signbit(x) ? PI : 0.0;
+		else return (float) (yd > 0.0 ? PIO2 : -PIO2);
+		return (float) (signbit(y) ? -r : r);
+	}
+	if (isinf(xd) && isinf(yd)) {
+		r = xd > 0.0 ? 0.25 * PI : 0.75 * PI;
+		return (float) (yd > 0.0 ? r : -r);
+	}
+	r = dm_atan_d(yd / xd);
+	if (xd < 0.0) r += signbit(y) ? -PI : PI;
+	return (float) r;
+}
+
 /* std::pow(x, 4.0f) */
 float orc_pow4f(float x) {
 	double d = (double) x * (double) x;

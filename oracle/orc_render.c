@@ -414,6 +414,66 @@ static int bsphere_ray_intersect(const float center[3], float radius, const floa
 	return 1;
 }
 
+/* ---- EnvMapLuminaire (src/luminaires/envmap.cpp) ---- */
+/* MIPMap::triangle(0, x, y) with EEWA/ERepeat (mipmap.cpp:226-243, getTexel :203-224) */
+static void env_triangle(const mtsgpu_scene *sc, float x, float y, float out[3]) {
+	const int W = (int) sc->env_width, H = (int) sc->env_height;
+	x = x * W - 0.5f;
+	y = y * H - 0.5f;
+	const int xPos = (int) floorf(x), yPos = (int) floorf(y);
+	const float dx = x - xPos, dy = y - yPos;
+	const int ox[4] = { 0, 0, 1, 1 }, oy[4] = { 0, 1, 0, 1 };
+	float acc[3] = { 0, 0, 0 };
+	for (int k = 0; k < 4; ++k) {
+		int tx = xPos + ox[k], ty = yPos + oy[k];
+		if (tx <= 0 || ty < 0 || tx >= W || ty >= H) {
+			int r = tx - (int) (tx / W) * W; tx = (r < 0) ? r + W : r;         /* modulo (util.cpp:424-427) */
+			r = ty - (int) (ty / H) * H; ty = (r < 0) ? r + H : r;
+		}
+		const float *t = sc->env_pixels + 3 * ((size_t) tx + (size_t) W * ty);
+		/* getTexel(..) * a * b: the Spectrum is scaled by the two factors one after the other */
+		const float a = (k < 2) ? (1.0f - dx) : dx, b = (k & 1) ? dy : (1.0f - dy);
+		if (k == 0) for (int c = 0; c < 3; ++c) acc[c] = t[c] * a * b;
+		else for (int c = 0; c < 3; ++c) acc[c] = acc[c] + t[c] * a * b;
+	}
+	out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
+}
+
+/* Le(direction) (envmap.cpp:147-153) */
+static void env_le(const mtsgpu_scene *sc, const float *P, const float direction[3], float out[3]) {
+	const float *M = P + 7;
+	const float d[3] = { M[0]*direction[0] + M[1]*direction[1] + M[2]*direction[2],
+	                     M[3]*direction[0] + M[4]*direction[1] + M[5]*direction[2],
+	                     M[6]*direction[0] + M[7]*direction[1] + M[8]*direction[2] };
+	const float u = .5f * (1 + orc_atan2f(d[0], -d[2]) / ORC_PI);
+	const float v = orc_acosf(fmaxf_((float) -1.0f, fminf_((float) 1.0f, d[1]))) / ORC_PI;
+	env_triangle(sc, u, v, out);
+	for (int c = 0; c < 3; ++c) out[c] *= P[0];
+}
+
+/* Le(ray) = Le(normalize(ray.d)) (envmap.cpp:155-157) */
+static void env_le_ray(const mtsgpu_scene *sc, const float *P, const float rd[3], float out[3]) {
+	float n[3];
+	v3_normalize(n, rd);
+	env_le(sc, P, n, out);
+}
+
+/* pdf(p, lRec, delta) (envmap.cpp:176-193) */
+static float env_pdf(const mtsgpu_scene *sc, const float *P, const float lrec_d[3]) {
+	const float *M = P + 7;
+	const float nd[3] = { -lrec_d[0], -lrec_d[1], -lrec_d[2] };
+	const float d[3] = { M[0]*nd[0] + M[1]*nd[1] + M[2]*nd[2], M[3]*nd[0] + M[4]*nd[1] + M[5]*nd[2], M[6]*nd[0] + M[7]*nd[1] + M[8]*nd[2] };
+	const int rx = (int) sc->env_pdf_width, ry = (int) sc->env_pdf_height;
+	const float x = .5f * (1 + orc_atan2f(d[0], -d[2]) / ORC_PI) * rx;
+	const float y = orc_acosf(fmaxf_((float) -1.0f, fminf_((float) 1.0f, d[1]))) / ORC_PI * ry;
+	int xPos = (int) floorf(x); if (xPos < 0) xPos = 0; if (xPos > rx - 1) xPos = rx - 1;
+	int yPos = (int) floorf(y); if (yPos < 0) yPos = 0; if (yPos > ry - 1) yPos = ry - 1;
+	const float pdf = sc->env_pdf[xPos + yPos * rx];
+	const float sinTheta = sqrtf(fmaxf_((float) ORC_EPS, 1 - d[1]*d[1]));
+	const float psx = 2 * ORC_PI / rx, psy = ORC_PI / ry;             /* m_pdfPixelSize (envmap.cpp:108) */
+	return pdf / (psx * psy * sinTheta);
+}
+
 /* Luminaire::sample for the two plugins (src/luminaires/area.cpp:68-79, constant.cpp:73-87) */
 static void luminaire_sample(const mtsgpu_scene *sc, int l, const float p[3], lrec_t *lRec, const float sample[2]) {
 	const float *P = sc->lum_params + MTSGPU_LUM_NPARAMS * (size_t) l;
@@ -536,6 +596,40 @@ static void luminaire_sample(const mtsgpu_scene *sc, int l, const float p[3], lr
 		}
 		float i2 = invDist*invDist;
 		lRec->value[0] = result[0] * i2; lRec->value[1] = result[1] * i2; lRec->value[2] = result[2] * i2;
+	} else if (sc->lum_type[l] == MTSGPU_LUM_ENVMAP) {
+		/* EnvMapLuminaire::sampleDirection + sample (envmap.cpp:123-145, :159-172) */
+		const int rx = (int) sc->env_pdf_width, ry = (int) sc->env_pdf_height;
+		float sx = sample[0], pdf;
+		const int idx = dpdf_sample_reuse(sc->env_cdf, (uint32_t) (rx * ry), &sx);
+		pdf = sc->env_pdf[idx];
+		const int row = idx / rx, col = idx - rx * row;
+		const float x = col + sx, y = row + sample[1];
+		float value[3];
+		env_triangle(sc, x * (1.0f / rx), y * (1.0f / ry), value);
+		for (int c = 0; c < 3; ++c) value[c] *= P[0];
+		const float psx = 2 * ORC_PI / rx, psy = ORC_PI / ry;
+		const float theta = psy * y, phi = psx * x - ORC_PI;
+		const float sinTheta = orc_sinf(theta), cosTheta = orc_cosf(theta);
+		const float sinPhi = orc_sinf(phi), cosPhi = orc_cosf(phi);
+		pdf = pdf / (psx * psy * sinTheta);
+		const float *L2W = P + 16;
+		const float v[3] = { -sinTheta * sinPhi, -cosTheta, sinTheta*cosPhi };
+		float d[3];
+		for (int i = 0; i < 3; ++i) d[i] = L2W[3*i] * v[0] + L2W[3*i+1] * v[1] + L2W[3*i+2] * v[2];
+		lRec->pdf = pdf;
+		lRec->value[0] = value[0]; lRec->value[1] = value[1]; lRec->value[2] = value[2];
+		const float *center = P + 3; const float radius = P[6];
+		float dv[3], md[3] = { -d[0], -d[1], -d[2] }, nearHit, farHit;
+		v3_sub(dv, p, center);
+		if (v3_length(dv) <= radius && bsphere_ray_intersect(center, radius, p, md, &nearHit, &farHit)) {
+			for (int i = 0; i < 3; ++i) lRec->p[i] = p[i] - d[i] * nearHit;
+			float cn[3];
+			v3_sub(cn, center, lRec->p);
+			v3_normalize(lRec->n, cn);
+			lRec->d[0] = d[0]; lRec->d[1] = d[1]; lRec->d[2] = d[2];
+		} else {
+			lRec->pdf = 0.0f;
+		}
 	} else if (sc->lum_type[l] == MTSGPU_LUM_DIRECTIONAL) {
 		/* DirectionalLuminaire::sample (directional.cpp:84-91) */
 		const float k = 2 * P[6];
@@ -613,10 +707,27 @@ static float scene_pdf_luminaire(const mtsgpu_scene *sc, const float p[3], const
 		float distSquared = v3_dot(lumToPoint, lumToPoint);
 		float invDP = fmaxf_((float) 0, sqrtf(distSquared) / v3_dot(lumToPoint, lRec->n));
 		pdf = sc->lum_inv_area[lRec->lum] * distSquared * invDP;
+	} else if (sc->lum_type[lRec->lum] == MTSGPU_LUM_ENVMAP) {
+		pdf = env_pdf(sc, sc->lum_params + MTSGPU_LUM_NPARAMS * (size_t) lRec->lum, lRec->d);
 	} else {
 		pdf = 1.0f / (4*ORC_PI);
 	}
 	return pdf * fraction;
+}
+
+/* test hooks: Luminaire::sample (no visibility test) and Scene::pdfLuminaire for one luminaire.
+ * out[13] = p, n, d, value, pdf */
+void orc_luminaire_sample(const mtsgpu_scene *sc, int l, const float p[3], const float sample[2], float out[13]) {
+	lrec_t r; memset(&r, 0, sizeof(r));
+	luminaire_sample(sc, l, p, &r, sample);
+	for (int i = 0; i < 3; ++i) { out[i] = r.p[i]; out[3+i] = r.n[i]; out[6+i] = r.d[i]; out[9+i] = r.value[i]; }
+	out[12] = r.pdf;
+}
+float orc_luminaire_pdf(const mtsgpu_scene *sc, int l, const float p[3], const float lp[3], const float ln[3], const float ld[3]) {
+	lrec_t r; memset(&r, 0, sizeof(r));
+	for (int i = 0; i < 3; ++i) { r.p[i] = lp[i]; r.n[i] = ln[i]; r.d[i] = ld[i]; }
+	r.lum = l;
+	return scene_pdf_luminaire(sc, p, &r);
 }
 
 /* AreaLuminaire::Le (area.cpp:62-66) */
@@ -1311,7 +1422,9 @@ static void path_li(const mtsgpu_scene *sc, const orc_render_params *prm, const 
 			/* scene->LeBackground(ray) (scene.h:403-405): ConstantLuminaire::Le = intensity */
 			if (emitted && sc->background_lum >= 0) {
 				const float *P = sc->lum_params + MTSGPU_LUM_NPARAMS * (size_t) sc->background_lum;
-				for (int i = 0; i < 3; ++i) Li[i] += pathThroughput[i] * P[i];
+				float le[3] = { P[0], P[1], P[2] };
+				if (sc->lum_type[sc->background_lum] == MTSGPU_LUM_ENVMAP) env_le_ray(sc, P, ray.d, le);
+				for (int i = 0; i < 3; ++i) Li[i] += pathThroughput[i] * le[i];
 			}
 			break;
 		}
@@ -1398,6 +1511,7 @@ static void path_li(const mtsgpu_scene *sc, const orc_render_params *prm, const 
 				const float *P = sc->lum_params + MTSGPU_LUM_NPARAMS * (size_t) sc->background_lum;
 				lRec.lum = sc->background_lum;
 				lRec.value[0] = P[0]; lRec.value[1] = P[1]; lRec.value[2] = P[2];
+				if (sc->lum_type[sc->background_lum] == MTSGPU_LUM_ENVMAP) env_le_ray(sc, P, ray.d, lRec.value);
 				lRec.d[0] = -ray.d[0]; lRec.d[1] = -ray.d[1]; lRec.d[2] = -ray.d[2];
 				hitLuminaire = 1;
 			} else {

@@ -15,6 +15,7 @@ struct orc_flat_scene {
 	uint32_t *bsdf_type; float *bsdf_params;
 	uint32_t *lum_type; float *lum_params; int32_t *lum_shape; float *lum_inv_area;
 	uint32_t *lum_cdf_offset; float *lum_tri_cdf, *lum_sel_cdf, *lum_sel_pdf;
+	float *env_pixels, *env_pdf, *env_cdf;
 };
 
 /* unitAngle (include/mitsuba/core/util.h:343-348) */
@@ -88,6 +89,8 @@ static float discrete_pdf_build(const float *values, uint32_t n, float *cdf, flo
 	cdf[n] = 1.0f;
 	return originalSum;
 }
+
+static int build_envmap(orc_flat_scene *fs, const mtsgpu_scene_desc *d, float *P);
 
 int orc_flatten(const mtsgpu_scene_desc *d, const mtsgpu_kd_params *kdp, orc_flat_scene **out) {
 	orc_flat_scene *fs = (orc_flat_scene *) calloc(1, sizeof(orc_flat_scene));
@@ -235,6 +238,20 @@ int orc_flatten(const mtsgpu_scene_desc *d, const mtsgpu_kd_params *kdp, orc_fla
 			}
 			P[3] = bc[0]; P[4] = bc[1]; P[5] = bc[2]; P[6] = br;
 			background = (int32_t) l;
+		} else if (fs->lum_type[l] == MTSGPU_LUM_ENVMAP) {
+			/* EnvMapLuminaire::preprocess (src/luminaires/envmap.cpp:112-126): same bounding sphere logic */
+			float bc[3] = { center[0], center[1], center[2] }, br = radius;
+			br *= 1.01f;
+			if (d->has_camera) {
+				float oldr = br, dv[3];
+				v3_sub(dv, d->camera_pos, bc);
+				br = fmaxf_(br, v3_length(dv));
+				if (oldr != br)
+					br *= 1.01f;
+			}
+			P[3] = bc[0]; P[4] = bc[1]; P[5] = bc[2]; P[6] = br;
+			if (background >= 0 || build_envmap(fs, d, P) != 0) { orc_flat_scene_free(fs); return MTSGPU_EINVAL; }
+			background = (int32_t) l;
 		} else if (fs->lum_type[l] == MTSGPU_LUM_DIRECTIONAL) {
 			/* DirectionalLuminaire::preprocess (directional.cpp:65-72): m_diskRadius = scene bsphere radius */
 			P[6] = radius;
@@ -269,6 +286,7 @@ int orc_flatten(const mtsgpu_scene_desc *d, const mtsgpu_kd_params *kdp, orc_fla
 	sc->lum_cdf_offset = fs->lum_cdf_offset; sc->lum_tri_cdf = fs->lum_tri_cdf;
 	sc->lum_sel_cdf = fs->lum_sel_cdf; sc->lum_sel_pdf = fs->lum_sel_pdf;
 	sc->background_lum = background;
+	sc->env_pixels = fs->env_pixels; sc->env_pdf = fs->env_pdf; sc->env_cdf = fs->env_cdf;     /* sizes set by build_envmap */
 	*out = fs;
 	return 0;
 }
@@ -286,6 +304,7 @@ void orc_flat_scene_free(orc_flat_scene *fs) {
 	free(fs->vtx_pos); free(fs->vtx_nrm); free(fs->tri_idx); free(fs->shape_tri_offset);
 	free(fs->shape_flags); free(fs->shape_bsdf); free(fs->shape_lum); free(fs->triaccel);
 	free(fs->shape_type); free(fs->shape_params);
+	free(fs->env_pixels); free(fs->env_pdf); free(fs->env_cdf);
 	free(fs->bsdf_type); free(fs->bsdf_params); free(fs->lum_type); free(fs->lum_params);
 	free(fs->lum_shape); free(fs->lum_inv_area); free(fs->lum_cdf_offset); free(fs->lum_tri_cdf);
 	free(fs->lum_sel_cdf); free(fs->lum_sel_pdf);
@@ -375,6 +394,149 @@ static void xf_scale(xform_t *x, float vx, float vy, float vz) {
 	float m[4][4] = { {vx,0,0,0}, {0,vy,0,0}, {0,0,vz,0}, {0,0,0,1} };
 	float i[4][4] = { {1.0f/vx,0,0,0}, {0,1.0f/vy,0,0}, {0,0,1.0f/vz,0}, {0,0,0,1} };
 	memcpy(x->m, m, sizeof(m)); memcpy(x->inv, i, sizeof(i));
+}
+
+/* ========================================================================== */
+/* Environment map: MIPMap::fromBitmap + EnvMapLuminaire::configure            */
+/* ========================================================================== */
+static int is_pow2_(uint32_t v) { return v && !(v & (v - 1)); }
+static uint32_t round_to_pow2_(uint32_t i) { i--; i |= i >> 1; i |= i >> 2; i |= i >> 4; i |= i >> 8; i |= i >> 16; return i + 1; }
+static int log2i_u32(uint32_t value) { int r = 0; while ((value >> r) != 0) r++; return r - 1; }      /* util.cpp:410-415 */
+static int modulo_(int a, int b) { int result = a - (int) (a / b) * b; return (result < 0) ? result + b : result; }   /* util.cpp:424-427 */
+
+/* lanczosSinc (util.cpp:664-674), tau = 2; host libm like the reference */
+static float lanczos_sinc(float t, float tau) {
+	t = fabsf(t);
+	if (t < ORC_EPS)
+		return 1.0f;
+	else if (t > 1.0f)
+		return 0.0f;
+	t *= ORC_PI;
+	float sincTerm = sinf(t*tau)/(t*tau);
+	float windowTerm = sinf(t)/t;
+	return sincTerm * windowTerm;
+}
+
+typedef struct { int firstTexel; float weight[4]; } resample_weight_t;
+
+/* MIPMap::resampleWeights (mipmap.cpp:183-201) */
+static resample_weight_t *resample_weights(int oldRes, int newRes) {
+	float filterWidth = 2.0f;
+	resample_weight_t *weights = (resample_weight_t *) malloc(sizeof(resample_weight_t) * (size_t) newRes);
+	for (int i = 0; i < newRes; i++) {
+		float center = (i + .5f) * oldRes / newRes;
+		weights[i].firstTexel = (int) floorf(center - filterWidth + (float) 0.5f);
+		float weightSum = 0;
+		for (int j = 0; j < 4; j++) {
+			float pos = weights[i].firstTexel + j + .5f;
+			float weight = lanczos_sinc((pos - center) / filterWidth, 2);
+			weightSum += weight;
+			weights[i].weight[j] = weight;
+		}
+		float invWeights = 1.0f / weightSum;
+		for (int j = 0; j < 4; j++)
+			weights[i].weight[j] *= invWeights;
+	}
+	return weights;
+}
+
+/* MIPMap::getTexel with ERepeat (mipmap.cpp:203-224) */
+static const float *mip_texel(const float *img, int w, int h, int x, int y) {
+	if (x <= 0 || y < 0 || x >= w || y >= h) {
+		x = modulo_(x, w);
+		y = modulo_(y, h);
+	}
+	return img + 3 * ((size_t) x + (size_t) w * y);
+}
+
+/* MIPMap::fromBitmap (mipmap.cpp:161-181) -> MIPMap::MIPMap (EEWA, ERepeat; :30-92), pyramid up to the level
+ * EnvMapLuminaire::configure needs (envmap.cpp:95-110); fills env_pixels / env_pdf / env_cdf and the sizes */
+static int build_envmap(orc_flat_scene *fs, const mtsgpu_scene_desc *d, float *P) {
+	const int width = (int) d->env_width, height = (int) d->env_height;
+	if (!d->env_bitmap || width <= 0 || height <= 0 || width > 16384 || height > 16384)
+		return -1;
+	float *pixels = (float *) malloc(sizeof(float) * 3 * (size_t) width * height);
+	for (size_t i = 0; i < 3 * (size_t) width * height; ++i)
+		pixels[i] = fmaxf_((float) 0.0f, d->env_bitmap[i]);             /* fromLinearRGB + clampNegative */
+	int m_width = width, m_height = height;
+	float *texture = pixels;
+	if (!is_pow2_((uint32_t) width) || !is_pow2_((uint32_t) height)) {
+		m_width = (int) round_to_pow2_((uint32_t) width);
+		m_height = (int) round_to_pow2_((uint32_t) height);
+		float *texture1 = (float *) calloc(3 * (size_t) m_width * height, sizeof(float));
+		resample_weight_t *weights = resample_weights(width, m_width);
+		for (int y = 0; y < height; y++)
+			for (int x = 0; x < m_width; x++) {
+				float *dst = texture1 + 3 * ((size_t) x + (size_t) m_width * y);
+				dst[0] = dst[1] = dst[2] = 0.0f;
+				for (int j = 0; j < 4; j++) {
+					int pos = weights[x].firstTexel + j;
+					if (pos < 0 || pos >= height)                        /* sic: tested against the height (mipmap.cpp:48) */
+						pos = modulo_(pos, width);
+					if (pos >= 0 && pos < width)
+						for (int c = 0; c < 3; ++c) dst[c] += pixels[3 * ((size_t) pos + (size_t) y * width) + c] * weights[x].weight[j];
+				}
+			}
+		free(weights);
+		free(pixels);
+		texture = (float *) calloc(3 * (size_t) m_width * m_height, sizeof(float));
+		weights = resample_weights(height, m_height);
+		for (int x = 0; x < m_width; x++)
+			for (int y = 0; y < m_height; y++)
+				for (int j = 0; j < 4; j++) {
+					int pos = weights[y].firstTexel + j;
+					if (pos < 0 || pos >= height)
+						pos = modulo_(pos, height);
+					if (pos >= 0 && pos < height)
+						for (int c = 0; c < 3; ++c)
+							texture[3 * ((size_t) x + (size_t) m_width * y) + c] += texture1[3 * ((size_t) x + (size_t) pos * m_width) + c] * weights[y].weight[j];
+				}
+		for (size_t i = 0; i < 3 * (size_t) m_width * m_height; ++i)
+			texture[i] = fmaxf_((float) 0.0f, texture[i]);
+		free(weights);
+		free(texture1);
+	}
+	const int levels = 1 + log2i_u32((uint32_t) (width > height ? width : height));    /* the ORIGINAL size (mipmap.cpp:81) */
+	const int mipMapLevel = (3 < levels - 1) ? 3 : levels - 1;
+	/* pyramid levels 1..mipMapLevel (mipmap.cpp:93-108) */
+	float *cur = texture; int cw = m_width, ch = m_height;
+	for (int i = 1; i <= mipMapLevel; ++i) {
+		const int nw = (cw / 2 > 1) ? cw / 2 : 1, nh = (ch / 2 > 1) ? ch / 2 : 1;
+		float *next = (float *) malloc(sizeof(float) * 3 * (size_t) nw * nh);
+		for (int y = 0; y < nh; y++)
+			for (int x = 0; x < nw; x++)
+				for (int c = 0; c < 3; ++c)
+					next[3 * ((size_t) x + (size_t) y * nw) + c] =
+						(mip_texel(cur, cw, ch, 2*x, 2*y)[c] + mip_texel(cur, cw, ch, 2*x+1, 2*y)[c] +
+						 mip_texel(cur, cw, ch, 2*x, 2*y+1)[c] + mip_texel(cur, cw, ch, 2*x+1, 2*y+1)[c]) * 0.25f;
+		if (cur != texture) free(cur);
+		cur = next; cw = nw; ch = nh;
+	}
+	/* EnvMapLuminaire::configure (envmap.cpp:95-110) */
+	const int rx = cw, ry = ch;
+	float *values = (float *) malloc(sizeof(float) * (size_t) rx * ry);
+	int index = 0;
+	for (int y = 0; y < ry; ++y) {
+		float sinFactor = sinf(ORC_PI * (y + .5f) / ry);
+		for (int x = 0; x < rx; ++x) {
+			const float *s = cur + 3 * ((size_t) x + (size_t) y * rx);
+			values[index++] = (s[0] * 0.212671f + s[1] * 0.715160f + s[2] * 0.072169f) * sinFactor;    /* getLuminance, spectrum.h:387-389 */
+		}
+	}
+	fs->env_pdf = (float *) malloc(sizeof(float) * (size_t) rx * ry);
+	fs->env_cdf = (float *) malloc(sizeof(float) * ((size_t) rx * ry + 1));
+	discrete_pdf_build(values, (uint32_t) (rx * ry), fs->env_cdf, fs->env_pdf);
+	free(values);
+	if (cur != texture) free(cur);
+	fs->env_pixels = texture;
+	fs->sc.env_width = (uint32_t) m_width; fs->sc.env_height = (uint32_t) m_height;
+	fs->sc.env_pdf_width = (uint32_t) rx; fs->sc.env_pdf_height = (uint32_t) ry;
+	/* m_worldToLuminaire = m_luminaireToWorld.inverse() (luminaire.cpp:26-33): Matrix4x4 inverse of the rotation */
+	float m[4][4] = { { P[16], P[17], P[18], 0 }, { P[19], P[20], P[21], 0 }, { P[22], P[23], P[24], 0 }, { 0, 0, 0, 1 } }, inv[4][4];
+	if (!mat_invert(m, inv))
+		return -1;
+	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) P[7 + 3*i + j] = inv[i][j];
+	return 0;
 }
 
 int orc_make_camera(const float origin[3], const float target[3], const float up[3],

@@ -12,6 +12,7 @@ SCENES = {
     "c5_small": lambda s: s.cornell_c5(sphere_subdiv=2),
     "next_rows": lambda s: s.next_rows(sphere_subdiv=2),
     "spheres": lambda s: s.spheres(),
+    "envlit": lambda s: s.envlit(),
 }
 
 
@@ -62,7 +63,8 @@ def test_ld_tables_bit_exact(gpu_lib, mts, orc):
 @pytest.mark.parametrize("name,sampler", [("c1", "independent"), ("c1", "ldsampler"), ("c3_small", "ldsampler"),
                                           ("c5_small", "independent"), ("c5_small", "ldsampler"),
                                           ("next_rows", "independent"), ("next_rows", "ldsampler"),
-                                          ("spheres", "independent"), ("spheres", "ldsampler")])
+                                          ("spheres", "independent"), ("spheres", "ldsampler"),
+                                          ("envlit", "independent"), ("envlit", "ldsampler")])
 def test_li_samples_bit_exact(gpu_lib, mts, orc, name, sampler):
     """MIPathTracer::Li per camera sample: radiance, alpha, raster position and path depth"""
     sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, name, W=32, H=32, sampler=sampler, spp=16)
@@ -77,7 +79,7 @@ def test_li_samples_bit_exact(gpu_lib, mts, orc, name, sampler):
 
 @pytest.mark.parametrize("name,sampler,spp", [("c1", "independent", 16), ("c1", "ldsampler", 32), ("c3_small", "ldsampler", 16),
                                               ("c5_small", "ldsampler", 16), ("next_rows", "ldsampler", 16),
-                                              ("spheres", "ldsampler", 16)])
+                                              ("spheres", "ldsampler", 16), ("envlit", "ldsampler", 16)])
 def test_film_matches_oracle(gpu_lib, mts, orc, name, sampler, spp):
     """whole renderBlock + putSample pipeline; tolerance stated by north_star: pixel RMSE < 1e-5
     (the target is bit-identical, which is what is asserted first and reported)"""

@@ -390,6 +390,70 @@ def test_roughglass_energy_and_reciprocity(orc):
     assert 0.3 < tot / 4000 < 1.0       # transmitted radiance is scaled by (etaI/etaT)^2 = 1/2.25 on the way in
 
 
+def test_atan2_is_faithful(orc):
+    L = orc.lib()
+    rng = np.random.RandomState(2)
+    ys = np.concatenate([rng.randn(4000), [0.0, -0.0, 1.0, -1.0, 0.0, -0.0, 3e-30, -2e30]]).astype(np.float32)
+    xs = np.concatenate([rng.randn(4000), [1.0, 1.0, 0.0, 0.0, -1.0, -1.0, -1e-30, 1e30]]).astype(np.float32)
+    for y, x in zip(ys, xs):
+        got = L.orc_atan2f(float(y), float(x))
+        exp = np.arctan2(np.float64(y), np.float64(x))
+        assert abs(got - exp) <= 1.2e-7 * max(1.0, abs(exp)), (y, x, got, exp)
+    assert L.orc_atan2f(0.0, -1.0) == np.float32(np.pi) and L.orc_atan2f(-0.0, -1.0) == -np.float32(np.pi)
+
+
+def test_envmap_luminaire(mts, orc):
+    """`envmap` (src/luminaires/envmap.cpp): MIPMap level 0 + the sampling density; sample() and pdf() agree with each
+    other, the sampled directions follow the density (chi-square over the density's own cells), and the film of an
+    env-lit scene is finite and lit"""
+    import ctypes as C
+    from scipy import stats
+    sd = mts.scenes.envlit()
+    fs = orc.FlatScene(sd)
+    arr = fs.arrays()
+    W, H, pw, ph = arr["env_size"]
+    assert (W, H) == (128, 64) and (pw, ph) == (16, 8)                 # 96x40 up-sampled; level 3 of the pyramid
+    assert abs(arr["env_pdf"].sum() - 1) < 1e-5 and arr["env_cdf"][0] == 0 and arr["env_cdf"][-1] == 1
+    assert (arr["env_pixels"] >= 0).all() and arr["env_pixels"].max() > 20     # the sun survives the Lanczos filter
+    # the product's host code builds the same arrays bit for bit
+    pscene = mts.Scene(sd)
+    prod = mts.abi.scene_arrays(pscene.sc)
+    for k in ("env_pixels", "env_pdf", "env_cdf", "lum_params"):
+        assert np.asarray(arr[k]).tobytes() == np.asarray(prod[k]).tobytes(), k
+    L = orc.lib()
+    p = np.array([0.1, 0.5, 0.2], dtype=np.float32)
+    out = np.zeros(13, dtype=np.float32)
+    rng = np.random.RandomState(8)
+    n = 20000
+    counts = np.zeros(pw * ph)
+    M = arr["lum_params"][0][7:16].reshape(3, 3).astype(np.float64)
+    for s in rng.rand(n, 2).astype(np.float32):
+        L.orc_luminaire_sample(fs.scene, 0, _p(p), _p(s), _p(out))
+        assert out[12] > 0
+        d = out[6:9].astype(np.float64)
+        assert abs(np.linalg.norm(d) - 1) < 1e-5
+        # Scene::pdfLuminaire of the sampled direction == the density sample() reported (same table cell)
+        pdf = L.orc_luminaire_pdf(fs.scene, 0, _p(p), _p(out[0:3].copy()), _p(out[3:6].copy()), _p(out[6:9].copy()))
+        dl = M @ (-d)
+        u = 0.5 * (1 + np.arctan2(dl[0], -dl[2]) / np.pi) * pw; v = np.arccos(np.clip(dl[1], -1, 1)) / np.pi * ph
+        if min(u % 1, 1 - u % 1, v % 1, 1 - v % 1) > 1e-3:             # away from the cell borders
+            if abs(dl[1]) < 0.999:                                     # 1 - d.y^2 cancels next to the poles (envmap.cpp:190)
+                assert abs(pdf - out[12]) <= 2e-3 * out[12], (pdf, out[12])
+            counts[min(int(u), pw - 1) + pw * min(int(v), ph - 1)] += 1
+        # the sampled point lies on the bounding sphere, the normal points inwards
+        c, r = arr["lum_params"][0][3:6], arr["lum_params"][0][6]
+        assert abs(np.linalg.norm(out[0:3] - c) - r) < 1e-3 * r
+    e = arr["env_pdf"].astype(np.float64) * counts.sum()
+    big = e >= 5
+    chi2 = ((counts[big] - e[big]) ** 2 / e[big]).sum()
+    assert 1 - stats.chi2.cdf(chi2, big.sum() - 1) > 0.003
+    cam = orc.make_camera(sd, 48, 36)
+    prm = orc.render_params(sd.max_depth, sampler=mts.abi.SAMPLER_LD_KEYED, spp=16, seed=4)
+    film, st = orc.render(fs.scene, cam, prm)
+    img = orc.develop(film)
+    assert np.isfinite(film).all() and img.mean() > 0.1 and img[:10].mean() > img[-10:].mean() * 0.5
+
+
 def test_sphere_shape(mts, orc):
     """`sphere` shapes (src/shapes/sphere.cpp): one kd-tree primitive each; hits agree with the analytic
     intersection in binary64; a sphere-shaped area luminaire lights the box; both hosts flatten identically"""
