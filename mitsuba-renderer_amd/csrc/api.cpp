@@ -173,6 +173,7 @@ hipEvent_t *nextEventPair(mtsgpu_ctx *c, std::vector<std::pair<hipEvent_t, hipEv
 int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile const int *cancel) {
 	uint32_t nQ = nPaths;
 	uint32_t *cur = c->queueA, *nxt = c->queueB;
+	bool first = true;       // camera rays and their shadow rays are coherent: plain 64-ray batches win there
 	hipStream_t s = c->stream;
 	while (nQ > 0) {
 		if (cancel && *cancel)
@@ -182,7 +183,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		// closest hit + material sort
 		hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
 		if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
-		launch_trace(s, 0, c->countTraversal, true, c->dsc, c->paths, c->q, cur, nQ);
+		launch_trace(s, 0, c->countTraversal, true, c->dsc, c->paths, c->q, cur, nQ, first);
 		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
 		HIPCHK(c, hipGetLastError());
 		c->stats.rays_closest += nQ; c->stats.trace_launches++;
@@ -213,7 +214,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		if (nShadow) {
 			hipEvent_t *ev2 = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
 			if (ev2) HIPCHK(c, hipEventRecord(ev2[0], s));
-			launch_trace(s, 1, c->countTraversal, false, c->dsc, c->paths, c->q, c->q.shadow, nShadow);
+			launch_trace(s, 1, c->countTraversal, false, c->dsc, c->paths, c->q, c->q.shadow, nShadow, first);
 			if (ev2) HIPCHK(c, hipEventRecord(ev2[1], s));
 			HIPCHK(c, hipGetLastError());
 			c->stats.rays_shadow += nShadow; c->stats.trace_launches++;
@@ -232,6 +233,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		}
 		std::swap(cur, nxt);
 		nQ = nNext;
+		first = false;
 	}
 	return 0;
 }
@@ -781,7 +783,7 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 8 * sizeof(unsigned long long), c->stream));
 	hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
 	if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
-	launch_trace(c->stream, shadow ? 2 : 0, c->countTraversal, false, c->dsc, c->paths, c->q, c->queueA, n);
+	launch_trace(c->stream, shadow ? 2 : 0, c->countTraversal, false, c->dsc, c->paths, c->q, c->queueA, n, false);
 	if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
 	HIPCHK(c, hipGetLastError());
 	HIPCHK(c, hipMemcpy2DAsync(hits, 16, c->paths.base + 2, kPathSlots * sizeof(float4), 16, n, hipMemcpyDeviceToHost, c->stream));

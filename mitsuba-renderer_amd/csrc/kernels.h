@@ -122,7 +122,7 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 // mode 1: shadow rays over ps.sh_* (adds ps.nee to ps.Li when unoccluded)
 // mode 2: any-hit over ps.ray_* (writes ps.hit.w = occluded) -- test/benchmark API
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
-                  const DQueues &q, const uint32_t *queue, uint32_t n);
+                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent);
 // prefix[s] = number of entries of the bin in segments < s (prefix[kBinShards] = total)
 struct BinView { uint32_t prefix[kBinShards + 1]; };
 void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,

@@ -1757,27 +1757,29 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 }
 
 template <int MODE, bool COUNT, bool BIN>
-static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n) {
+static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent) {
 	// persistent grid: enough workgroups to fill every CU, never more than there are rays
 	const unsigned blocks = std::min<unsigned>(blocks_for(n, kTraceBlock), 256u * trace_blocks_per_cu(MODE));
 	DQueues qq = q;
 	// the early loop exits trade the latency of a few straggling rays for throughput; with only a few
 	// batches per wave the stragglers are the critical path, so small launches run the plain loops
-	if (n < 8u * kTraceGridBlocks * kTraceBlock)
+	if (n < 8u * kTraceGridBlocks * kTraceBlock || coherent)
 		qq.desc_min = qq.leaf_min = 1;
+	if (coherent && !getenv("MTSGPU_REFILL"))
+		qq.refill_min = 64;       // neighbouring camera samples finish together: refilling would only mix batches
 	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, sc, ps, qq, queue, n);
 }
 
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
-                  const DQueues &q, const uint32_t *queue, uint32_t n) {
+                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent) {
 	if (!n) return;
 	if (mode == 0) {
-		if (bin) { if (count) launch_trace_t<0, true, true>(s, sc, ps, q, queue, n); else launch_trace_t<0, false, true>(s, sc, ps, q, queue, n); }
-		else     { if (count) launch_trace_t<0, true, false>(s, sc, ps, q, queue, n); else launch_trace_t<0, false, false>(s, sc, ps, q, queue, n); }
+		if (bin) { if (count) launch_trace_t<0, true, true>(s, sc, ps, q, queue, n, coherent); else launch_trace_t<0, false, true>(s, sc, ps, q, queue, n, coherent); }
+		else     { if (count) launch_trace_t<0, true, false>(s, sc, ps, q, queue, n, coherent); else launch_trace_t<0, false, false>(s, sc, ps, q, queue, n, coherent); }
 	} else if (mode == 1) {
-		if (count) launch_trace_t<1, true, false>(s, sc, ps, q, queue, n); else launch_trace_t<1, false, false>(s, sc, ps, q, queue, n);
+		if (count) launch_trace_t<1, true, false>(s, sc, ps, q, queue, n, coherent); else launch_trace_t<1, false, false>(s, sc, ps, q, queue, n, coherent);
 	} else {
-		if (count) launch_trace_t<2, true, false>(s, sc, ps, q, queue, n); else launch_trace_t<2, false, false>(s, sc, ps, q, queue, n);
+		if (count) launch_trace_t<2, true, false>(s, sc, ps, q, queue, n, coherent); else launch_trace_t<2, false, false>(s, sc, ps, q, queue, n, coherent);
 	}
 }
 
