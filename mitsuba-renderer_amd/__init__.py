@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "libmtsgpu.so")
 
 EXPORTS = [
     "mtsgpu_create", "mtsgpu_destroy", "mtsgpu_last_error", "mtsgpu_abi_version", "mtsgpu_abi_sizeof", "mtsgpu_set_stream",
-    "mtsgpu_upload_scene", "mtsgpu_set_camera", "mtsgpu_set_integrator", "mtsgpu_set_sampler",
+    "mtsgpu_upload_scene", "mtsgpu_set_camera", "mtsgpu_set_integrator", "mtsgpu_set_direct_integrator", "mtsgpu_set_sampler",
     "mtsgpu_set_tiles", "mtsgpu_set_rfilter", "mtsgpu_set_film_edges", "mtsgpu_tabulate_filter", "mtsgpu_set_film_buffer", "mtsgpu_set_options", "mtsgpu_render", "mtsgpu_sync",
     "mtsgpu_read_film", "mtsgpu_clear_film", "mtsgpu_get_stats", "mtsgpu_trace_rays", "mtsgpu_ld_tables",
     "mtsgpu_li_samples", "mtsgpu_flatten", "mtsgpu_flat_scene_get", "mtsgpu_flat_scene_free",
@@ -65,6 +65,7 @@ def lib():
     L.mtsgpu_set_camera.argtypes = [vp, C.POINTER(abi.Camera)]
     L.mtsgpu_set_integrator.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.mtsgpu_set_sampler.argtypes = [vp, C.c_int, C.c_uint32, C.c_int, C.c_uint64]
+    L.mtsgpu_set_direct_integrator.argtypes = [vp, C.c_int, C.c_int]
     L.mtsgpu_set_tiles.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.mtsgpu_set_film_buffer.argtypes = [vp, vp]
     L.mtsgpu_set_rfilter.argtypes = [vp, C.c_float, C.c_float, f32p]
@@ -175,8 +176,11 @@ class MIPathTracer:
             raise MtsGpuError("%s: %s (code %d)" % (what, lib().mtsgpu_last_error(self._ctx).decode(), rc))
 
     def configure(self):
-        self._chk(lib().mtsgpu_set_integrator(self._ctx, self.maxDepth, self.rrDepth, int(self.strictNormals)), "set_integrator")
+        self._configure_integrator()
         return self
+
+    def _configure_integrator(self):
+        self._chk(lib().mtsgpu_set_integrator(self._ctx, self.maxDepth, self.rrDepth, int(self.strictNormals)), "set_integrator")
 
     def preprocess(self, scene, camera, sampler="independent", sampleCount=4, depth=3, seed=0x5EED):
         """Scene::preprocess -> Integrator::preprocess: upload the flattened scene, camera and sampler."""
@@ -277,6 +281,17 @@ class MIPathTracer:
             self.close()
         except Exception:
             pass
+
+
+class MIDirectIntegrator(MIPathTracer):
+    """The `direct` integrator (src/integrators/direct/direct.cpp): luminaireSamples, bsdfSamples in {0, 1}"""
+
+    def __init__(self, luminaireSamples=1, bsdfSamples=1, device=0):
+        MIPathTracer.__init__(self, device=device)
+        self.luminaireSamples, self.bsdfSamples = int(luminaireSamples), int(bsdfSamples)
+
+    def _configure_integrator(self):
+        self._chk(lib().mtsgpu_set_direct_integrator(self._ctx, self.luminaireSamples, self.bsdfSamples), "set_direct_integrator")
 
 
 def develop(film):

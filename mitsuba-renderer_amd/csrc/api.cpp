@@ -42,6 +42,7 @@ struct mtsgpu_ctx {
 	float *film = nullptr; bool ownFilm = false; size_t filmPixels = 0;
 	float filtSizeX = 0.5f, filtSizeY = 0.5f; int filtBorder = 0;
 	bool hqEdges = false;
+	int integrator = 0, nLumSamples = 1, nBsdfSamples = 1;
 	float *filtValues = nullptr;           // device [16][16]
 	TileMeta *tileMeta = nullptr; size_t tileMetaCap = 0;
 	float *blocks = nullptr; size_t blocksCap = 0;
@@ -152,6 +153,11 @@ DConfig makeConfig(const mtsgpu_ctx *c, bool slotPerPath) {
 	cfg.width = c->cam.width; cfg.height = c->cam.height;
 	cfg.pix_w = c->cam.width; cfg.pix_off = 0;
 	cfg.max_depth = c->maxDepth; cfg.rr_depth = c->rrDepth; cfg.strict_normals = c->strictNormals;
+	cfg.integrator = c->integrator; cfg.n_lum = c->nLumSamples; cfg.n_bsdf = c->nBsdfSamples;
+	// MIDirectIntegrator::configure (direct.cpp:51-56)
+	cfg.weight_bsdf = 1 / (float) c->nBsdfSamples; cfg.weight_lum = 1 / (float) c->nLumSamples;
+	cfg.frac_bsdf = c->nBsdfSamples / (float) (c->nLumSamples + c->nBsdfSamples);
+	cfg.frac_lum = c->nLumSamples / (float) (c->nLumSamples + c->nBsdfSamples);
 	cfg.sampler_kind = c->samplerKind;
 	cfg.spp = effectiveSpp(c); cfg.ld_depth = c->ldDepth; cfg.seed = c->seed;
 	cfg.slot_per_path = slotPerPath ? 1 : 0;
@@ -564,6 +570,17 @@ int mtsgpu_set_integrator(mtsgpu_ctx *c, int max_depth, int rr_depth, int strict
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
 	if (rr_depth <= 0) return fail(c, MTSGPU_EINVAL, "rrDepth == 0 breaks the computation of alpha values! (integrator.cpp:291)");
 	c->maxDepth = max_depth; c->rrDepth = rr_depth; c->strictNormals = strict_normals ? 1 : 0;
+	c->integrator = 0;
+	return 0;
+}
+
+int mtsgpu_set_direct_integrator(mtsgpu_ctx *c, int luminaire_samples, int bsdf_samples) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	if (luminaire_samples < 0 || bsdf_samples < 0 || luminaire_samples + bsdf_samples <= 0)
+		return fail(c, MTSGPU_EINVAL, "luminaireSamples + bsdfSamples must be > 0 (direct.cpp:41)");
+	if (luminaire_samples > 1 || bsdf_samples > 1)
+		return fail(c, MTSGPU_EINVAL, "more than one sample per strategy draws from Sampler::next2DArray, which this path does not implement");
+	c->integrator = 1; c->nLumSamples = luminaire_samples; c->nBsdfSamples = bsdf_samples;
 	return 0;
 }
 

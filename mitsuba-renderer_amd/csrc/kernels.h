@@ -86,6 +86,9 @@ struct DConfig {
 	int32_t width, height;
 	int32_t pix_w, pix_off;            // rendered rectangle: pixel ids index a pix_w-wide grid whose origin is (pix_off, pix_off)
 	int32_t max_depth, rr_depth, strict_normals;
+	// integrator plugin: 0 = path (MIPathTracer), 1 = direct (MIDirectIntegrator, direct.cpp:51-56)
+	int32_t integrator, n_lum, n_bsdf;
+	float frac_lum, frac_bsdf, weight_lum, weight_bsdf;
 	int32_t sampler_kind;
 	uint32_t spp; int32_t ld_depth;
 	uint64_t seed;

@@ -1449,6 +1449,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 			misc_zw = make_uint2(r.z, r.w);
 			smp.d1 = (flags >> F_D1_SHIFT) & 0xFFu; smp.d2 = (flags >> F_D2_SHIFT) & 0xFFu;
 		}
+		const bool direct = cfg.integrator == 1;
 		Its its;
 		if (valid)
 			fill_its(sc, rayO, rayD, __uint_as_float(h.x), h.w, __uint_as_float(h.y), __uint_as_float(h.z), its);
@@ -1483,19 +1484,21 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 						lvalue = (sc.lum_type[llum] == 5u) ? env_le(sc, LP, normalize(rayD)) : V3(LP[0], LP[1], LP[2]);
 						hitLuminaire = true;
 					} else {
-						depth++;
+						if (!direct) depth++;
 						break;
 					}
 				}
 				if (hitLuminaire) {
 					const float lumPdf = (!(sampledType & T_DELTA)) ? pdf_luminaire(sc, rayO, llum, lp, ln, -rayD) : 0.0f;
-					const float weight = mi_weight(bsdfPdf, lumPdf);
+					// direct.cpp:189-191 weighs the two strategies by their sample counts
+					const float weight = direct ? mi_weight(bsdfPdf * cfg.frac_bsdf, lumPdf * cfg.frac_lum) * cfg.weight_bsdf
+					                            : mi_weight(bsdfPdf, lumPdf);
 					Li.x += thr.x * lvalue.x * bsdfVal.x * weight;
 					Li.y += thr.y * lvalue.y * bsdfVal.y * weight;
 					Li.z += thr.z * lvalue.z * bsdfVal.z * weight;
 				}
-				if (!valid)
-					break;
+				if (!valid || direct)
+					break;                                  // MIDirectIntegrator stops after its BSDF sample (direct.cpp:193)
 				flags &= ~F_EMITTED;                       // rRec.type = ERadianceNoEmission
 				if (depth >= cfg.rr_depth && !(sampledType & T_TRANSMISSION)) {
 					const float approxAlbedo = smin(0.9f, smax(smax(bsdfVal.x, bsdfVal.y), bsdfVal.z));
@@ -1529,26 +1532,31 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 				const V3 le = (dot(-rayD, its.geoN) <= 0) ? V3(0.0f, 0.0f, 0.0f) : V3(LP[0], LP[1], LP[2]);
 				Li.x += thr.x * le.x; Li.y += thr.y * le.y; Li.z += thr.z * le.z;
 			}
-			if (cfg.max_depth > 0 && depth >= cfg.max_depth)
-				break;
-			const float wiDotGeoN = -dot(its.geoN, rayD), wiDotShN = its.wi.z;
-			if (wiDotGeoN * wiDotShN < 0 && cfg.strict_normals)
-				break;
+			if (!direct) {      // MonteCarloIntegrator properties; the direct integrator has neither (direct.cpp:33-41)
+				if (cfg.max_depth > 0 && depth >= cfg.max_depth)
+					break;
+				const float wiDotGeoN = -dot(its.geoN, rayD), wiDotShN = its.wi.z;
+				if (wiDotGeoN * wiDotShN < 0 && cfg.strict_normals)
+					break;
+			}
+			const bool strict = cfg.strict_normals && !direct;
 
 			// ---- luminaire sampling (path.cpp:100-126) ----
 			{
 				float s0, s1;
 				sampler_next2d(cfg, smp, s0, s1);
 				LRec lRec;
-				if (sample_luminaire(sc, its.p, s0, s1, lRec)) {
+				if ((!direct || cfg.n_lum > 0) && sample_luminaire(sc, its.p, s0, s1, lRec)) {
 					const V3 wo = -lRec.d;
 					const V3 woL(dot(wo, its.shS), dot(wo, its.shT), dot(wo, its.shN));
 					V3 bsdfVal = Bsdf2<BT>::f(twoSided, BP, its.wi, woL) * fabsf(woL.z);
 					const float woDotGeoN = dot(its.geoN, wo);
-					if (!isZero(bsdfVal) && (!cfg.strict_normals || woDotGeoN * woL.z > 0)) {
+					if (!isZero(bsdfVal) && (!strict || woDotGeoN * woL.z > 0)) {
 						// isIntersectable() || isBackgroundLuminaire() (path.cpp:118-120): 0 for delta luminaires
-						const float bsdfPdf = (sc.lum_type[lRec.lum] <= 1u) ? Bsdf2<BT>::pdf(twoSided, BP, its.wi, woL) : 0.0f;
-						const float weight = mi_weight(lRec.pdf, bsdfPdf);
+						const uint32_t lt = sc.lum_type[lRec.lum];      // area, constant and envmap luminaires can be hit by BSDF samples
+						const float bsdfPdf = (lt <= 1u || lt == 5u) ? Bsdf2<BT>::pdf(twoSided, BP, its.wi, woL) : 0.0f;
+						const float weight = direct ? mi_weight(lRec.pdf * cfg.frac_lum, bsdfPdf * cfg.frac_bsdf) * cfg.weight_lum
+						                            : mi_weight(lRec.pdf, bsdfPdf);          // direct.cpp:143-145
 						// added to Li by k_trace<shadow> iff the segment is unoccluded
 						ps.nee(id) = make_float4(thr.x * lRec.value.x * bsdfVal.x * weight,
 						                         thr.y * lRec.value.y * bsdfVal.y * weight,
@@ -1564,6 +1572,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 			// ---- BSDF sampling (path.cpp:128-146) ----
 			float s0, s1;
 			sampler_next2d(cfg, smp, s0, s1);
+			if (direct && cfg.n_bsdf <= 0)
+				break;                                      // the sample is drawn even when it is not used (direct.cpp:156-161)
 			V3 woL; float bsdfPdf; uint32_t sampledType;
 			V3 bsdfVal = Bsdf2<BT>::sample(twoSided, BP, its.wi, s0, s1, woL, bsdfPdf, sampledType);
 			if (!isZero(bsdfVal))
@@ -1575,7 +1585,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 			            its.shS.y * woL.x + its.shT.y * woL.y + its.shN.y * woL.z,
 			            its.shS.z * woL.x + its.shT.z * woL.y + its.shN.z * woL.z);
 			const float woDotGeoN = dot(its.geoN, wo);
-			if (woDotGeoN * woL.z <= 0 && cfg.strict_normals)
+			if (woDotGeoN * woL.z <= 0 && strict)
 				break;
 			// ray = Ray(its.p, wo, time): mint = Epsilon, maxt = inf
 			ps.ray_o(id) = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);

@@ -111,6 +111,8 @@ typedef struct orc_render_params {
 	int sampler_kind;                          /* MTSGPU_SAMPLER_*        */
 	uint32_t spp; int ld_depth; uint64_t seed;
 	int n_threads;                             /* OpenMP threads (0 = all) */
+	int integrator;                            /* 0 = path (MIPathTracer), 1 = direct (MIDirectIntegrator) */
+	int luminaire_samples, bsdf_samples;       /* direct.cpp:36-41; 0 or 1 each (no next2DArray)       */
 } orc_render_params;
 
 /* SampleIntegrator::renderBlock over a pixel rectangle [x0,x1) x [y0,y1) with the

@@ -18,7 +18,8 @@ abi = _pkgload.load().abi
 class RenderParams(C.Structure):
     _fields_ = [("max_depth", C.c_int), ("rr_depth", C.c_int), ("strict_normals", C.c_int),
                 ("sampler_kind", C.c_int), ("spp", C.c_uint32), ("ld_depth", C.c_int),
-                ("seed", C.c_uint64), ("n_threads", C.c_int)]
+                ("seed", C.c_uint64), ("n_threads", C.c_int),
+                ("integrator", C.c_int), ("luminaire_samples", C.c_int), ("bsdf_samples", C.c_int)]
 
 
 class TabFilter(C.Structure):
@@ -151,8 +152,9 @@ def make_camera(desc, width, height):
 
 
 def render_params(max_depth, rr_depth=10, strict_normals=0, sampler=abi.SAMPLER_INDEPENDENT_KEYED,
-                  spp=4, ld_depth=3, seed=0x5EED, n_threads=0):
-    return RenderParams(max_depth, rr_depth, strict_normals, sampler, spp, ld_depth, seed, n_threads)
+                  spp=4, ld_depth=3, seed=0x5EED, n_threads=0, integrator="path", luminaire_samples=1, bsdf_samples=1):
+    return RenderParams(max_depth, rr_depth, strict_normals, sampler, spp, ld_depth, seed, n_threads,
+                        {"path": 0, "direct": 1}[integrator], luminaire_samples, bsdf_samples)
 
 
 def render(scene_ptr, cam, params, rect=None):

@@ -1464,7 +1464,7 @@ static void path_li(const mtsgpu_scene *sc, const orc_render_params *prm, const 
 			if (!spec_is_zero(bsdfVal) && (!strictNormals || woDotGeoN * woL[2] > 0)) {
 				/* Luminaire::isIntersectable() || isBackgroundLuminaire() (path.cpp:118-120): false for delta lights */
 				const uint32_t lt = sc->lum_type[lRec.lum];
-				float bsdfPdf = (lt == MTSGPU_LUM_AREA || lt == MTSGPU_LUM_CONSTANT) ? orc_bsdf_pdf(btype, BP, its.wi, woL) : 0;
+				float bsdfPdf = (lt == MTSGPU_LUM_AREA || lt == MTSGPU_LUM_CONSTANT || lt == MTSGPU_LUM_ENVMAP) ? orc_bsdf_pdf(btype, BP, its.wi, woL) : 0;
 				const float weight = mi_weight(lRec.pdf, bsdfPdf);
 				for (int i = 0; i < 3; ++i)
 					Li[i] += pathThroughput[i] * lRec.value[i] * bsdfVal[i] * weight;
@@ -1548,6 +1548,122 @@ static void path_li(const mtsgpu_scene *sc, const orc_render_params *prm, const 
 	}
 	res->Li[0] = Li[0]; res->Li[1] = Li[1]; res->Li[2] = Li[2];
 	res->depth = depth;
+}
+
+/* MIDirectIntegrator::Li (src/integrators/direct/direct.cpp:64-198) for a camera ray (rRec.depth == 1) with
+ * luminaireSamples, bsdfSamples in {0, 1}: larger counts draw from Sampler::next2DArray, which is not restated. */
+static void direct_li(const mtsgpu_scene *sc, const orc_render_params *prm, const ray_t *r, sampler_t *smp,
+                      li_result *res, mtsgpu_stats *st) {
+	its_t its, bsdfIts;
+	ray_t ray = *r;
+	float Li[3] = { 0.0f, 0.0f, 0.0f };
+	/* configure() (direct.cpp:51-56) */
+	const int numLuminaireSamples = prm->luminaire_samples, numBSDFSamples = prm->bsdf_samples;
+	const float weightBSDF = 1 / (float) numBSDFSamples, weightLum = 1 / (float) numLuminaireSamples;
+	const float fracBSDF = numBSDFSamples / (float) (numLuminaireSamples + numBSDFSamples);
+	const float fracLum = numLuminaireSamples / (float) (numLuminaireSamples + numBSDFSamples);
+	res->depth = 1;
+
+	int valid = scene_ray_intersect(sc, &ray, &its, st);
+	res->alpha = valid ? 1.0f : 0.0f;
+	if (!valid) {
+		if (sc->background_lum >= 0) {
+			const float *P = sc->lum_params + MTSGPU_LUM_NPARAMS * (size_t) sc->background_lum;
+			float le[3] = { P[0], P[1], P[2] };
+			if (sc->lum_type[sc->background_lum] == MTSGPU_LUM_ENVMAP) env_le_ray(sc, P, ray.d, le);
+			for (int i = 0; i < 3; ++i) Li[i] = le[i];
+		}
+		goto done;
+	}
+	{
+		const int shapeLum = sc->shape_lum[its.shape];
+		float md[3] = { -ray.d[0], -ray.d[1], -ray.d[2] };
+		if (shapeLum >= 0) {
+			float le[3];
+			area_le(sc, shapeLum, its.geoN, md, le);
+			for (int i = 0; i < 3; ++i) Li[i] += le[i];
+		}
+		const int bsdfIdx = sc->shape_bsdf[its.shape];
+		if (bsdfIdx < 0)
+			goto done;
+		const uint32_t btype = sc->bsdf_type[bsdfIdx];
+		const float *BP = sc->bsdf_params + MTSGPU_BSDF_NPARAMS * (size_t) bsdfIdx;
+
+		/* ---- luminaire sampling (direct.cpp:122-150): the sample is drawn even when no luminaire sample is taken ---- */
+		lrec_t lRec; memset(&lRec, 0, sizeof(lRec));
+		float sample[2];
+		sampler_next2d(smp, sample);
+		for (int k = 0; k < numLuminaireSamples; ++k) {
+			if (scene_sample_luminaire(sc, its.p, &lRec, sample, st)) {
+				const float wo[3] = { -lRec.d[0], -lRec.d[1], -lRec.d[2] };
+				float woL[3] = { v3_dot(wo, its.shS), v3_dot(wo, its.shT), v3_dot(wo, its.shN) };
+				float bsdfVal[3];
+				orc_bsdf_f(btype, BP, its.wi, woL, bsdfVal);
+				float ac = fabsf(woL[2]);
+				bsdfVal[0] *= ac; bsdfVal[1] *= ac; bsdfVal[2] *= ac;
+				if (!spec_is_zero(bsdfVal)) {
+					const uint32_t lt = sc->lum_type[lRec.lum];
+					float bsdfPdf = (lt == MTSGPU_LUM_AREA || lt == MTSGPU_LUM_CONSTANT || lt == MTSGPU_LUM_ENVMAP) ? orc_bsdf_pdf(btype, BP, its.wi, woL) : 0;
+					const float weight = mi_weight(lRec.pdf * fracLum, bsdfPdf * fracBSDF) * weightLum;
+					for (int i = 0; i < 3; ++i)
+						Li[i] += lRec.value[i] * bsdfVal[i] * weight;
+				}
+			}
+		}
+
+		/* ---- BSDF sampling (direct.cpp:152-195) ---- */
+		sampler_next2d(smp, sample);
+		for (int k = 0; k < numBSDFSamples; ++k) {
+			float woL[3], bsdfPdf, bsdfVal[3];
+			uint32_t sampledType;
+			orc_bsdf_sample(btype, BP, its.wi, sample, woL, &bsdfPdf, &sampledType, bsdfVal);
+			if (!spec_is_zero(bsdfVal)) {
+				float ac = fabsf(woL[2]);
+				bsdfVal[0] *= ac; bsdfVal[1] *= ac; bsdfVal[2] *= ac;
+			}
+			if (spec_is_zero(bsdfVal))
+				continue;
+			{
+				float recip = 1.0f / bsdfPdf;
+				bsdfVal[0] *= recip; bsdfVal[1] *= recip; bsdfVal[2] *= recip;
+			}
+			float wo[3];
+			for (int i = 0; i < 3; ++i)
+				wo[i] = its.shS[i] * woL[0] + its.shT[i] * woL[1] + its.shN[i] * woL[2];
+			ray_t bsdfRay;
+			ray_init(&bsdfRay, its.p, wo);
+			if (scene_ray_intersect(sc, &bsdfRay, &bsdfIts, st)) {
+				int l = sc->shape_lum[bsdfIts.shape];
+				if (l < 0)
+					continue;
+				float nd[3] = { -bsdfRay.d[0], -bsdfRay.d[1], -bsdfRay.d[2] };
+				for (int i = 0; i < 3; ++i) { lRec.p[i] = bsdfIts.p[i]; lRec.n[i] = bsdfIts.geoN[i]; lRec.d[i] = nd[i]; }
+				lRec.lum = l;
+				area_le(sc, l, bsdfIts.geoN, nd, lRec.value);
+			} else {
+				if (sc->background_lum < 0)
+					continue;
+				const float *P = sc->lum_params + MTSGPU_LUM_NPARAMS * (size_t) sc->background_lum;
+				lRec.lum = sc->background_lum;
+				lRec.value[0] = P[0]; lRec.value[1] = P[1]; lRec.value[2] = P[2];
+				if (sc->lum_type[sc->background_lum] == MTSGPU_LUM_ENVMAP) env_le_ray(sc, P, bsdfRay.d, lRec.value);
+				lRec.d[0] = -bsdfRay.d[0]; lRec.d[1] = -bsdfRay.d[1]; lRec.d[2] = -bsdfRay.d[2];
+			}
+			const float lumPdf = (!(sampledType & T_DELTA)) ? scene_pdf_luminaire(sc, its.p, &lRec) : 0;
+			const float weight = mi_weight(bsdfPdf * fracBSDF, lumPdf * fracLum) * weightBSDF;
+			for (int i = 0; i < 3; ++i)
+				Li[i] += lRec.value[i] * bsdfVal[i] * weight;
+		}
+	}
+done:
+	res->Li[0] = Li[0]; res->Li[1] = Li[1]; res->Li[2] = Li[2];
+}
+
+/* Integrator::Li of the configured integrator plugin */
+static void integrator_li(const mtsgpu_scene *sc, const orc_render_params *prm, const ray_t *r, sampler_t *smp,
+                          li_result *res, mtsgpu_stats *st) {
+	if (prm->integrator == 1) direct_li(sc, prm, r, smp, res, st);
+	else path_li(sc, prm, r, smp, res, st);
 }
 
 /* ========================================================================== */
@@ -1656,7 +1772,7 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 					ray_t eyeRay;
 					camera_generate_ray(cam, sample, lens, &eyeRay);
 					li_result res;
-					path_li(sc, prm, &eyeRay, &smp, &res, &st);
+					integrator_li(sc, prm, &eyeRay, &smp, &res, &st);
 					put_sample(film, W, H, &filter, sample[0], sample[1], res.Li, res.alpha);
 				}
 			}
@@ -1696,7 +1812,7 @@ void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_
 		ray_t eyeRay;
 		camera_generate_ray(cam, sample, lens, &eyeRay);
 		li_result res;
-		path_li(sc, prm, &eyeRay, &smp, &res, NULL);
+		integrator_li(sc, prm, &eyeRay, &smp, &res, NULL);
 		float *o = out + 8 * (size_t) i;
 		o[0] = res.Li[0]; o[1] = res.Li[1]; o[2] = res.Li[2]; o[3] = res.alpha;
 		o[4] = sample[0]; o[5] = sample[1]; o[6] = (float) res.depth; o[7] = 0.0f;
@@ -1732,7 +1848,7 @@ void orc_render_rect_mt(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const 
 				ray_t eyeRay;
 				camera_generate_ray(cam, sample, lens, &eyeRay);
 				li_result res;
-				path_li(sc, prm, &eyeRay, &smp, &res, NULL);
+				integrator_li(sc, prm, &eyeRay, &smp, &res, NULL);
 				put_sample(film, W, H, &filter, sample[0], sample[1], res.Li, res.alpha);
 			}
 		}
@@ -1834,7 +1950,7 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 					ray_t eyeRay;
 					camera_generate_ray(cam, sample, lens, &eyeRay);
 					li_result res;
-					path_li(sc, prm, &eyeRay, &s, &res, &st);
+					integrator_li(sc, prm, &eyeRay, &s, &res, &st);
 					tsample_t *o = &smp[((size_t) py * w + px) * spp + j];
 					o->L[0] = res.Li[0]; o->L[1] = res.Li[1]; o->L[2] = res.Li[2]; o->alpha = res.alpha;
 					o->sx = sample[0]; o->sy = sample[1];

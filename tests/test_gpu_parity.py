@@ -96,6 +96,35 @@ def test_film_matches_oracle(gpu_lib, mts, orc, name, sampler, spp):
     assert np.array_equal(film.view(np.uint32), ofilm.view(np.uint32)), "film not bit-identical (RMSE %g)" % rmse
 
 
+@pytest.mark.parametrize("name,nl,nb", [("c5_small", 1, 1), ("spheres", 1, 1), ("envlit", 1, 1), ("next_rows", 1, 0), ("c5_small", 0, 1)])
+def test_direct_integrator_matches_oracle(gpu_lib, mts, orc, name, nl, nb):
+    """the `direct` integrator plugin (src/integrators/direct/direct.cpp): per-sample Li and the film"""
+    sd = SCENES[name](mts.scenes)
+    scene = mts.Scene(sd); oscene = orc.FlatScene(sd)
+    cam = mts.PerspectiveCamera.for_description(sd, 40, 32); ocam = orc.make_camera(sd, 40, 32)
+    it = mts.MIDirectIntegrator(luminaireSamples=nl, bsdfSamples=nb)
+    it.preprocess(scene, cam, sampler="ldsampler", sampleCount=16, seed=11)
+    op = orc.render_params(-1, sampler=mts.abi.SAMPLER_LD_KEYED, spp=16, seed=11, integrator="direct",
+                           luminaire_samples=nl, bsdf_samples=nb)
+    rng = np.random.RandomState(3)
+    ps = np.stack([rng.randint(0, 40, 3000), rng.randint(0, 32, 3000), rng.randint(0, 16, 3000)], axis=1).astype(np.uint32)
+    got = it.li_samples(ps)
+    exp = orc.li_samples(oscene.scene, ocam, op, ps)
+    bad = (got.view(np.uint32) != exp.view(np.uint32)).any(axis=1)
+    assert not bad.any(), "%d of %d samples differ; first: got %s exp %s" % (bad.sum(), len(ps), got[bad][:1], exp[bad][:1])
+    assert exp[:, :3].max() > 0
+    assert it.render()
+    ofilm, ost = orc.render(oscene.scene, ocam, op)
+    assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32))
+    st = it.stats()
+    # Scene::sampleLuminaire tests visibility before the BSDF is evaluated; the wavefront only queues a shadow ray
+    # when the term it guards is non-zero: fewer shadow rays, same sums
+    assert st["rays_closest"] == ost.rays_closest and st["rays_shadow"] <= ost.rays_shadow and (st["rays_shadow"] > 0) == (nl > 0)
+    # unsupported sample counts are refused, not approximated
+    with pytest.raises(mts.MtsGpuError):
+        mts.MIDirectIntegrator(luminaireSamples=4).configure()
+
+
 def test_tile_sharding_is_exact(gpu_lib, mts, orc):
     """ImageBlock sharding: the union of the parts equals the unsharded film bit for bit"""
     sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "c1", W=80, H=72, sampler="ldsampler", spp=8)

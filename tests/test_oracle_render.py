@@ -390,6 +390,27 @@ def test_roughglass_energy_and_reciprocity(orc):
     assert 0.3 < tot / 4000 < 1.0       # transmitted radiance is scaled by (etaI/etaT)^2 = 1/2.25 on the way in
 
 
+def test_direct_integrator(mts, orc):
+    """MIDirectIntegrator (direct.cpp): equals the path tracer truncated after one bounce in expectation; either
+    strategy alone gives the same picture; background-only pixels return LeBackground"""
+    sd = mts.scenes.cornell_c5(sphere_subdiv=2)
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 40, 40)
+    kw = dict(sampler=mts.abi.SAMPLER_LD_KEYED, spp=64, seed=7)
+    ref, _ = orc.render(fs.scene, cam, orc.render_params(2, **kw))                      # path, maxDepth = 2
+    both, st = orc.render(fs.scene, cam, orc.render_params(-1, integrator="direct", **kw))
+    lum, _ = orc.render(fs.scene, cam, orc.render_params(-1, integrator="direct", luminaire_samples=1, bsdf_samples=0, **kw))
+    bs, _ = orc.render(fs.scene, cam, orc.render_params(-1, integrator="direct", luminaire_samples=0, bsdf_samples=1, **kw))
+    m = [orc.develop(f).mean() for f in (ref, both, lum, bs)]
+    assert abs(m[1] / m[0] - 1) < 0.03 and abs(m[2] / m[0] - 1) < 0.05 and abs(m[3] / m[0] - 1) < 0.15, m
+    # at most two closest-hit rays and one shadow ray per camera sample
+    n = 40 * 40 * 64
+    assert n < st.rays_closest <= 2 * n and 0 < st.rays_shadow <= n
+    # MIS with both strategies has less variance than BSDF sampling alone
+    err = lambda f: float(np.mean((orc.develop(f) - orc.develop(ref)) ** 2))
+    assert err(both) < err(bs)
+
+
 def test_atan2_is_faithful(orc):
     L = orc.lib()
     rng = np.random.RandomState(2)
