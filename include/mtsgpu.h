@@ -80,7 +80,14 @@ enum {
  * so that samples are independent of traversal order. */
 enum {
 	MTSGPU_SAMPLER_INDEPENDENT_KEYED = 0,
-	MTSGPU_SAMPLER_LD_KEYED = 1
+	MTSGPU_SAMPLER_LD_KEYED = 1,
+	/* The two purely deterministic QMC samplers (src/samplers/{halton,hammersley}.cpp): no Random involved, so the
+	 * sample values are the reference's own, not a keyed variant: sample j of EVERY pixel is
+	 * radicalInverse(primeTable[depth], j) (generate() resets the index for each pixel, halton.cpp:58-61).  The
+	 * evaluation order inside Point2(nextValue(), nextValue()) (halton.cpp:88) is left to the compiler by the
+	 * reference; x first is used here. */
+	MTSGPU_SAMPLER_HALTON = 2,
+	MTSGPU_SAMPLER_HAMMERSLEY = 3
 };
 
 /* shape_flags bits */

@@ -54,6 +54,7 @@ struct mtsgpu_ctx {
 	uint32_t *queueA = nullptr, *queueB = nullptr;
 	uint32_t *pixelList = nullptr; size_t pixelListCap = 0;
 	uint32_t *ldScr = nullptr; uint16_t *ldPerm = nullptr; size_t ldScrCap = 0, ldPermCap = 0;
+	uint16_t *primes = nullptr;        // primeTable (util.cpp:64-122) on the device
 	uint32_t *explicitSamples = nullptr; size_t explicitCap = 0;
 	uint32_t *hostCounters = nullptr;       // pinned
 	std::vector<void *> pathAllocs;
@@ -161,7 +162,7 @@ DConfig makeConfig(const mtsgpu_ctx *c, bool slotPerPath) {
 	cfg.sampler_kind = c->samplerKind;
 	cfg.spp = effectiveSpp(c); cfg.ld_depth = c->ldDepth; cfg.seed = c->seed;
 	cfg.slot_per_path = slotPerPath ? 1 : 0;
-	cfg.ld_scr = c->ldScr; cfg.ld_perm = c->ldPerm;
+	cfg.ld_scr = c->ldScr; cfg.ld_perm = c->ldPerm; cfg.primes = c->primes;
 	cfg.filt_size_x = c->filtSizeX; cfg.filt_size_y = c->filtSizeY; cfg.filt_border = c->filtBorder; cfg.filt_values = c->filtValues;
 	return cfg;
 }
@@ -312,6 +313,19 @@ int mtsgpu_create(int device, mtsgpu_ctx **out) {
 	if (hipHostMalloc((void **) &c->hostCounters, kNumCounters * kCounterStride * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
 		(void) hipStreamDestroy(c->stream); delete c; return fail(nullptr, MTSGPU_EHIP, "hipHostMalloc failed");
 	}
+	{
+		// the first 1000 primes (primeTable, src/libcore/util.cpp:64-122) for the halton / hammersley samplers
+		std::vector<uint16_t> primes;
+		for (uint32_t v = 2; primes.size() < 1000; ++v) {
+			bool isPrime = true;
+			for (uint32_t d = 2; d * d <= v; ++d) if (v % d == 0) { isPrime = false; break; }
+			if (isPrime) primes.push_back((uint16_t) v);
+		}
+		if (hipMalloc((void **) &c->primes, primes.size() * sizeof(uint16_t)) != hipSuccess
+		    || hipMemcpy(c->primes, primes.data(), primes.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) {
+			mtsgpu_destroy(c); return fail(nullptr, MTSGPU_EHIP, "prime table upload failed");
+		}
+	}
 	*out = c;
 	return 0;
 }
@@ -325,6 +339,7 @@ void mtsgpu_destroy(mtsgpu_ctx *c) {
 	if (c->pixelList) (void) hipFree(c->pixelList);
 	if (c->ldScr) (void) hipFree(c->ldScr);
 	if (c->ldPerm) (void) hipFree(c->ldPerm);
+	if (c->primes) (void) hipFree(c->primes);
 	if (c->explicitSamples) (void) hipFree(c->explicitSamples);
 	if (c->filtValues) (void) hipFree(c->filtValues);
 	if (c->tileMeta) (void) hipFree(c->tileMeta);
@@ -586,7 +601,7 @@ int mtsgpu_set_direct_integrator(mtsgpu_ctx *c, int luminaire_samples, int bsdf_
 
 int mtsgpu_set_sampler(mtsgpu_ctx *c, int kind, uint32_t spp, int ld_depth, uint64_t seed) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
-	if (kind != MTSGPU_SAMPLER_INDEPENDENT_KEYED && kind != MTSGPU_SAMPLER_LD_KEYED) return fail(c, MTSGPU_EINVAL, "unknown sampler kind %d", kind);
+	if (kind < MTSGPU_SAMPLER_INDEPENDENT_KEYED || kind > MTSGPU_SAMPLER_HAMMERSLEY) return fail(c, MTSGPU_EINVAL, "unknown sampler kind %d", kind);
 	if (spp == 0) return fail(c, MTSGPU_EINVAL, "sampleCount must be > 0");
 	if (kind == MTSGPU_SAMPLER_LD_KEYED && (roundToPow2(spp) > 65536u || ld_depth < 1 || ld_depth > 64))
 		return fail(c, MTSGPU_EINVAL, "ldsampler: sampleCount <= 65536 and 1 <= depth <= 64 required");

@@ -324,6 +324,18 @@ HD uint32_t sobol2Bits(uint32_t n, uint32_t scramble) {
 // (Float) n / (Float) 0x100000000LL -- can be exactly 1.0f
 HD float u32ToUnit(uint32_t n) { return (float) n / 4294967296.0f; }
 
+// radicalInverse (src/libcore/util.cpp:740-750)
+HD float radicalInverse(int b, uint64_t i) {
+	const float invB = (float) 1 / (float) b;
+	float x = 0.0f, f = invB;
+	while (i) {
+		x += f * (float) (i % (uint64_t) b);
+		i /= (uint64_t) b;
+		f *= invB;
+	}
+	return x;
+}
+
 // ---------------------------------------------------------------------------
 // Warps / frames / Fresnel (src/libcore/util.cpp:543-738)
 // ---------------------------------------------------------------------------

@@ -99,6 +99,7 @@ struct DConfig {
 	const float *filt_values;     // [16][16] on the device
 	const uint32_t *ld_scr;       // [slot][3*ld_depth]
 	const uint16_t *ld_perm;      // [slot][2*ld_depth][spp]
+	const uint16_t *primes;       // primeTable (util.cpp:64-122) for the halton / hammersley samplers
 };
 
 struct DQueues {

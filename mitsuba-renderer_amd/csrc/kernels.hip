@@ -92,7 +92,23 @@ struct PathSampler {
 	uint32_t d1, d2;
 };
 
+// HaltonSequence::nextValue (halton.cpp:73-75) / HammersleySequence::nextValue (hammersley.cpp:75-82);
+// m_sampleDepth is kept in d1 (low byte) and d2 (high byte)
+__device__ __forceinline__ float qmc_next_value(const DConfig &cfg, PathSampler &s) {
+	const uint32_t depth = s.d1 | (s.d2 << 8);
+	const uint32_t next = depth + 1u;
+	s.d1 = next & 0xFFu; s.d2 = (next >> 8) & 0xFFu;
+	if (cfg.sampler_kind == 3) {
+		if (depth == 0u)
+			return s.j * (1.0f / cfg.spp);
+		return radicalInverse((int) cfg.primes[min(depth - 1u, 999u)], (uint64_t) s.j);
+	}
+	return radicalInverse((int) cfg.primes[min(depth, 999u)], (uint64_t) s.j);
+}
+
 __device__ __forceinline__ float sampler_next1d(const DConfig &cfg, PathSampler &s) {
+	if (cfg.sampler_kind >= 2)
+		return qmc_next_value(cfg, s);
 	if (cfg.sampler_kind == 1 && (int) s.d1 < cfg.ld_depth) {
 		const int i = (int) s.d1++;
 		const uint32_t k = cfg.ld_perm[((size_t) s.slot * 2 * cfg.ld_depth + 2 * i) * cfg.spp + s.j];
@@ -102,6 +118,11 @@ __device__ __forceinline__ float sampler_next1d(const DConfig &cfg, PathSampler 
 }
 
 __device__ __forceinline__ void sampler_next2d(const DConfig &cfg, PathSampler &s, float &x, float &y) {
+	if (cfg.sampler_kind >= 2) {
+		x = qmc_next_value(cfg, s);
+		y = qmc_next_value(cfg, s);
+		return;
+	}
 	if (cfg.sampler_kind == 1 && (int) s.d2 < cfg.ld_depth) {
 		const int i = (int) s.d2++;
 		const uint32_t k = cfg.ld_perm[((size_t) s.slot * 2 * cfg.ld_depth + 2 * i + 1) * cfg.spp + s.j];

@@ -1301,7 +1301,8 @@ static void bsdf_sample_base(uint32_t type, const float *P, const float wi[3], c
 /* Samplers                                                                   */
 /* ========================================================================== */
 typedef struct {
-	int kind;            /* 0 keyed independent, 1 keyed LD, 2 MT independent, 3 MT LD */
+	int kind;            /* 0 keyed independent, 1 keyed LD, 2 MT independent, 3 MT LD, 4 halton, 5 hammersley */
+	int qdepth;          /* m_sampleDepth of the QMC samplers */
 	uint64_t stream;     /* keyed overflow / independent stream */
 	orc_random *mt;
 	/* LD state */
@@ -1310,6 +1311,34 @@ typedef struct {
 	const float *t1d, *t2d;          /* MT tables */
 } sampler_t;
 
+/* primeTable (src/libcore/util.cpp:64-122): the first 1000 primes */
+static int orc_prime(int i) {
+	static int table[1000], ready = 0;
+	if (!ready) {
+		int n = 0;
+		for (int c = 2; n < 1000; ++c) {
+			int isPrime = 1;
+			for (int d = 2; d * d <= c; ++d) if (c % d == 0) { isPrime = 0; break; }
+			if (isPrime) table[n++] = c;
+		}
+		ready = 1;
+	}
+	return table[i];
+}
+void orc_prime_table_init(void) { (void) orc_prime(0); }
+
+/* HaltonSequence::nextValue (halton.cpp:73-75) / HammersleySequence::nextValue (hammersley.cpp:75-82) */
+static float qmc_next_value(sampler_t *s) {
+	if (s->kind == 5) {
+		if (s->qdepth == 0) {
+			s->qdepth++;
+			return s->index * (1.0f / s->spp);          /* m_sampleIndex * m_invSamplesPerPixel (hammersley.cpp:40) */
+		}
+		return orc_radical_inverse(orc_prime((s->qdepth++) - 1), s->index);
+	}
+	return orc_radical_inverse(orc_prime(s->qdepth++), s->index);
+}
+
 static float sampler_next_float(sampler_t *s) {
 	if (s->mt) return orc_random_next_float(s->mt);
 	return orc_ulong_to_float(orc_keyed_next(&s->stream));
@@ -1317,6 +1346,8 @@ static float sampler_next_float(sampler_t *s) {
 
 /* next1D (independent.cpp:72-74, ldsampler.cpp:172-178) */
 static float sampler_next1d(sampler_t *s) {
+	if (s->kind >= 4)
+		return qmc_next_value(s);
 	if ((s->kind == 1 || s->kind == 3) && s->d1 < s->depth) {
 		int i = s->d1++;
 		if (s->kind == 3) return s->t1d[(size_t) i * s->spp + s->index];
@@ -1329,6 +1360,11 @@ static float sampler_next1d(sampler_t *s) {
  * ldsampler.cpp:185 leaves the evaluation order of its two nextFloat() calls to
  * the compiler; x-then-y is used here, as independent.cpp enforces. */
 static void sampler_next2d(sampler_t *s, float out[2]) {
+	if (s->kind >= 4) {
+		out[0] = qmc_next_value(s);
+		out[1] = qmc_next_value(s);
+		return;
+	}
 	if ((s->kind == 1 || s->kind == 3) && s->d2 < s->depth) {
 		int i = s->d2++;
 		if (s->kind == 3) {
@@ -1730,6 +1766,15 @@ static int put_sample(float *film, int W, int H, const tabfilter_t *filter, floa
 /* ========================================================================== */
 static uint32_t round_to_pow2(uint32_t v) { uint32_t r = 1; while (r < v) r <<= 1; return r; }
 
+static int sampler_kind_of(const orc_render_params *p) {
+	switch (p->sampler_kind) {
+		case MTSGPU_SAMPLER_LD_KEYED: return 1;
+		case MTSGPU_SAMPLER_HALTON: return 4;
+		case MTSGPU_SAMPLER_HAMMERSLEY: return 5;
+		default: return 0;
+	}
+}
+
 static uint32_t effective_spp(const orc_render_params *p) {
 	/* ldsampler.cpp:52-57: rounded up to a power of two */
 	if (p->sampler_kind == MTSGPU_SAMPLER_LD_KEYED) return round_to_pow2(p->spp);
@@ -1738,6 +1783,7 @@ static uint32_t effective_spp(const orc_render_params *p) {
 
 void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *prm,
                      int x0, int y0, int x1, int y1, float *film, mtsgpu_stats *stats) {
+	(void) orc_prime(0);            /* fill the prime table before any thread needs it */
 	const uint32_t spp = effective_spp(prm);
 	const int W = cam->width, H = cam->height;
 	tabfilter_t filter; tabfilter_box(&filter);
@@ -1762,7 +1808,7 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 					orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);   /* sampler->generate() */
 				for (uint32_t j = 0; j < spp; ++j) {
 					sampler_t smp; memset(&smp, 0, sizeof(smp));
-					smp.kind = isLD ? 1 : 0;
+					smp.kind = sampler_kind_of(prm);
 					smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 					smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm;
 					float sample[2], lens[2] = { 0, 0 };
@@ -1788,6 +1834,7 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 
 void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *prm,
                     const uint32_t *pix_samples, uint32_t n, float *out) {
+	(void) orc_prime(0);            /* fill the prime table before any thread needs it */
 	const uint32_t spp = effective_spp(prm);
 	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED;
 	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
@@ -1802,7 +1849,7 @@ void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_
 			lastKey = pixelKey;
 		}
 		sampler_t smp; memset(&smp, 0, sizeof(smp));
-		smp.kind = isLD ? 1 : 0;
+		smp.kind = sampler_kind_of(prm);
 		smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 		smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm;
 		float sample[2], lens[2] = { 0, 0 };
@@ -1824,6 +1871,7 @@ void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_
  * un-cloned sampler), scanline order inside the rectangle (integrator.cpp:204-226) */
 void orc_render_rect_mt(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *prm,
                         int kind, int x0, int y0, int x1, int y1, float *film) {
+	(void) orc_prime(0);            /* fill the prime table before any thread needs it */
 	const int W = cam->width, H = cam->height;
 	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
 	const uint32_t spp = kind == 1 ? round_to_pow2(prm->spp) : prm->spp;
@@ -1901,6 +1949,7 @@ typedef struct { float L[3], alpha, sx, sy; int valid; } tsample_t;
 void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *prm,
                       const orc_tabfilter *filter, int bs, int part, int n_parts, int hq_edges,
                       float *film, mtsgpu_stats *stats) {
+	(void) orc_prime(0);            /* fill the prime table before any thread needs it */
 	const uint32_t spp = effective_spp(prm);
 	const int W = cam->width, H = cam->height;
 	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED;
@@ -1940,7 +1989,7 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 				if (isLD) orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);
 				for (uint32_t j = 0; j < spp; ++j) {
 					sampler_t s; memset(&s, 0, sizeof(s));
-					s.kind = isLD ? 1 : 0;
+					s.kind = sampler_kind_of(prm);
 					s.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 					s.depth = depth; s.spp = spp; s.index = j; s.scr = scr; s.perm = perm;
 					float sample[2], lens[2] = { 0, 0 };

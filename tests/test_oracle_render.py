@@ -390,6 +390,33 @@ def test_roughglass_energy_and_reciprocity(orc):
     assert 0.3 < tot / 4000 < 1.0       # transmitted radiance is scaled by (etaI/etaT)^2 = 1/2.25 on the way in
 
 
+def test_halton_and_hammersley_samplers(mts, orc):
+    """src/samplers/{halton,hammersley}.cpp are purely deterministic: every pixel sees the same points
+    radicalInverse(primeTable[depth], j), so the raster offsets of sample j agree across pixels and equal the
+    reference's own radical inverses (the golden vectors of src/tests/test_samplers.cpp pin orc_radical_inverse)"""
+    sd = mts.scenes.cornell_c1()
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 16, 16)
+    L = orc.lib()
+    for name, kind in (("halton", mts.abi.SAMPLER_HALTON), ("hammersley", mts.abi.SAMPLER_HAMMERSLEY)):
+        prm = orc.render_params(4, sampler=kind, spp=12, seed=1)
+        ps = np.array([[x, y, j] for (x, y) in ((0, 0), (5, 9), (15, 3)) for j in range(12)], dtype=np.uint32)
+        out = orc.li_samples(fs.scene, cam, prm, ps)
+        off = out[:, 4:6] - ps[:, 0:2]                         # raster position - pixel = the first 2D sample
+        for j in range(12):
+            if name == "halton":
+                exp = (L.orc_radical_inverse(2, j), L.orc_radical_inverse(3, j))
+            else:
+                exp = (np.float32(j) * (np.float32(1) / np.float32(12)), L.orc_radical_inverse(2, j))
+            for k in range(3):
+                assert abs(off[12 * k + j, 0] - exp[0]) < 2e-6 and abs(off[12 * k + j, 1] - exp[1]) < 2e-6
+        film, _ = orc.render(fs.scene, cam, prm)
+        assert np.isfinite(film).all() and orc.develop(film).mean() > 0.05
+        # no dependence on the seed: there is no random number in these samplers
+        film2, _ = orc.render(fs.scene, cam, orc.render_params(4, sampler=kind, spp=12, seed=99))
+        assert np.array_equal(film.view(np.uint32), film2.view(np.uint32))
+
+
 def test_direct_integrator(mts, orc):
     """MIDirectIntegrator (direct.cpp): equals the path tracer truncated after one bounce in expectation; either
     strategy alone gives the same picture; background-only pixels return LeBackground"""
