@@ -510,10 +510,11 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 		}
 		rc |= upload(c, (const uint32_t **) &d.leaf_ta, ta.data(), ta.size());
 		// per-primitive position / normal records for the shading kernels
-		std::vector<float> triPos(12 * ((size_t) sc->n_tris + 1), 0.0f), triNrm(12 * ((size_t) sc->n_tris + 1), 0.0f);
+		const size_t TS = 4 * (size_t) kTriStride;                    // floats per record (one 128-byte line)
+		std::vector<float> triRec(TS * ((size_t) sc->n_tris + 1), 0.0f);
 		for (uint32_t s = 0; s < sc->n_shapes; ++s)
 			for (uint32_t t = sc->shape_tri_offset[s]; t < sc->shape_tri_offset[s + 1]; ++t) {
-				float *P = &triPos[12 * (size_t) t], *Nn = &triNrm[12 * (size_t) t];
+				float *P = &triRec[TS * (size_t) t], *Nn = P + 12;
 				if (shapeType(s) != MTSGPU_SHAPE_TRIMESH) {
 					// non-mesh shape: centre + radius, flag bit 31 (the rest comes from shape_params)
 					const uint32_t flags = sc->shape_flags[s] | 0x80000000u;
@@ -529,8 +530,8 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 				const uint32_t flags = sc->shape_flags[s];
 				std::memcpy(P + 10, &s, 4); std::memcpy(P + 11, &flags, 4);
 			}
-		rc |= upload(c, (const float **) &d.tri_pos, triPos.data(), triPos.size());
-		rc |= upload(c, (const float **) &d.tri_nrm, triNrm.data(), triNrm.size());
+		rc |= upload(c, (const float **) &d.tri_pos, triRec.data(), triRec.size());
+		d.tri_nrm = d.tri_pos ? d.tri_pos + 3 : nullptr;
 	}
 	rc |= upload(c, &d.shape_bsdf, sc->shape_bsdf, sc->n_shapes);
 	rc |= upload(c, &d.shape_lum, sc->shape_lum, sc->n_shapes);

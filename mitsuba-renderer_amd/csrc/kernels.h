@@ -11,6 +11,7 @@ constexpr int kTraceBlock = 256;
 constexpr unsigned kTraceGridBlocks = 256 * 8;   // largest persistent traversal grid: 256 CUs x resident workgroups
 constexpr unsigned trace_blocks_per_cu(int mode) { return mode == 0 ? 7u : 8u; }   // closest-hit state needs 72 VGPRs, shadow rays 64
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
+constexpr int kTriStride = 8;         // float4 per primitive record: one 128-byte line holds positions AND normals
 constexpr int kLumStride = 32;        // MTSGPU_LUM_NPARAMS
 constexpr int kCounterStride = 32;    // one 128-byte line per queue counter (atomics on one line serialise)
 constexpr int kBinShards = 16;        // the closest-hit kernel appends to bins[b] through 16 independent segments
@@ -24,8 +25,8 @@ struct DScene {
 	// TriAccel of primitive kd_indices[e] (dword 0 = k << 30 | "not an occluder" << 29 | global
 	// primitive id, dword 10 = shape), so a leaf's primitives are one contiguous run
 	const uint4    *leaf_ta;
-	// per-primitive gather records (3 x 16 B each): p0.xyz p1.xyz p2.xyz | shape, flags, 0   and
-	// n0.xyz n1.xyz n2.xyz | 0 0 0 -- one line instead of 3 index + 9 scattered vertex fetches
+	// per-primitive gather record, one 128-byte line (kTriStride float4): p0.xyz p1.xyz p2.xyz -, shape, flags |
+	// n0.xyz n1.xyz n2.xyz | pad -- one line instead of 3 index + 18 scattered vertex fetches; tri_nrm = tri_pos + 3
 	const float4   *tri_pos;
 	const float4   *tri_nrm;
 	const int32_t  *shape_bsdf, *shape_lum;

@@ -642,7 +642,7 @@ struct Its {
 
 // fillIntersectionRecord<true> (include/mitsuba/render/skdtree.h:352-432)
 __device__ __forceinline__ void fill_its(const DScene &sc, V3 rayO, V3 rayD, float t, uint32_t prim, float u, float v, Its &its) {
-	const float4 *TP = sc.tri_pos + 3 * (size_t) prim;
+	const float4 *TP = sc.tri_pos + kTriStride * (size_t) prim;
 	const float4 t0 = TP[0], t1 = TP[1], t2 = TP[2];
 	V3 sS, sT;
 	if (__float_as_uint(t2.w) & 0x80000000u) {
@@ -688,7 +688,7 @@ __device__ __forceinline__ void fill_its(const DScene &sc, V3 rayO, V3 rayD, flo
 	its.geoN = faceNormal;
 	its.shape = __float_as_uint(t2.z);
 	if (__float_as_uint(t2.w) & 1u) {
-		const float4 *TN = sc.tri_nrm + 3 * (size_t) prim;
+		const float4 *TN = sc.tri_nrm + kTriStride * (size_t) prim;
 		const float4 m0 = TN[0], m1 = TN[1], m2 = TN[2];
 		const V3 n0(m0.x, m0.y, m0.z), n1(m0.w, m1.x, m1.y), n2(m1.z, m1.w, m2.x);
 		its.shN = normalize(V3(n0.x * bx + n1.x * by + n2.x * bz, n0.y * bx + n1.y * by + n2.y * bz, n0.z * bx + n1.z * by + n2.z * bz));
@@ -851,7 +851,7 @@ __device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s
 		const uint32_t t0 = sc.shape_tri_offset[s], nT = sc.shape_tri_offset[s + 1] - t0;
 		const int index = dpdf_sample_reuse(sc.lum_tri_cdf + sc.lum_cdf_offset[l], nT, sy);
 		const size_t tri = (size_t) t0 + (uint32_t) index;
-		const float4 *TP = sc.tri_pos + 3 * tri;
+		const float4 *TP = sc.tri_pos + kTriStride * tri;
 		const float4 q0 = TP[0], q1 = TP[1], q2 = TP[2];
 		const V3 p0(q0.x, q0.y, q0.z), p1(q0.w, q1.x, q1.y), p2(q1.z, q1.w, q2.x);
 		float bx, by;
@@ -859,7 +859,7 @@ __device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s
 		const V3 sideA = p1 - p0, sideB = p2 - p0;
 		lRec.p = V3(p0.x + (sideA.x * bx) + (sideB.x * by), p0.y + (sideA.y * bx) + (sideB.y * by), p0.z + (sideA.z * bx) + (sideB.z * by));
 		if (__float_as_uint(q2.w) & 1u) {
-			const float4 *TN = sc.tri_nrm + 3 * tri;
+			const float4 *TN = sc.tri_nrm + kTriStride * tri;
 			const float4 m0 = TN[0], m1 = TN[1], m2 = TN[2];
 			const V3 n0(m0.x, m0.y, m0.z), n1(m0.w, m1.x, m1.y), n2(m1.z, m1.w, m2.x);
 			const float b0 = 1.0f - bx - by;
