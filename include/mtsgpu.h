@@ -298,6 +298,14 @@ void mtsgpu_flat_scene_free(mtsgpu_flat_scene *fs);
 /* kd-tree statistics logged by the reference builder (gkdtree.h:1178-1213) */
 int  mtsgpu_flat_scene_kdstats(const mtsgpu_flat_scene *fs, double *out6 /* inner, leaf, idx, expTrav, expLeaves, expPrims */);
 
+/* One shape of a Mitsuba `.serialized` mesh file, as <shape type="serialized"> with `shapeIndex` loads it
+ * (TriMesh::TriMesh(Stream *, int index), src/librender/trimesh.cpp:156-236): header 0x041C / version 3, zlib
+ * stream, single or double precision.  *mesh points into *out and stays valid until mtsgpu_loaded_mesh_free;
+ * `bsdf` and `lum` are -1, `normals` is NULL when the file has none, `face_normals` follows the file's flag. */
+typedef struct mtsgpu_loaded_mesh mtsgpu_loaded_mesh;
+int  mtsgpu_load_serialized(const char *path, int shape_index, mtsgpu_loaded_mesh **out, mtsgpu_mesh *mesh);
+void mtsgpu_loaded_mesh_free(mtsgpu_loaded_mesh *m);
+
 /* TabulatedFilter for the `box` (kind 0) and `gaussian` (kind 1; halfSize, stddev properties,
  * src/rfilters/gaussian.cpp:30-42,62-65) plugins: size_xy[2], values[256] */
 int  mtsgpu_tabulate_filter(int kind, float half_size, float stddev, float *size_xy, float *values);

@@ -27,12 +27,28 @@ EXPORTS = [
     "mtsgpu_set_tiles", "mtsgpu_set_rfilter", "mtsgpu_set_film_edges", "mtsgpu_tabulate_filter", "mtsgpu_set_film_buffer", "mtsgpu_set_options", "mtsgpu_render", "mtsgpu_sync",
     "mtsgpu_read_film", "mtsgpu_clear_film", "mtsgpu_get_stats", "mtsgpu_trace_rays", "mtsgpu_ld_tables",
     "mtsgpu_li_samples", "mtsgpu_flatten", "mtsgpu_flat_scene_get", "mtsgpu_flat_scene_free",
-    "mtsgpu_flat_scene_kdstats", "mtsgpu_make_camera",
+    "mtsgpu_flat_scene_kdstats", "mtsgpu_make_camera", "mtsgpu_load_serialized", "mtsgpu_loaded_mesh_free",
 ]
 
 
 class MtsGpuError(RuntimeError):
     pass
+
+
+def load_serialized(path, shape_index=0, bsdf=-1, lum=-1, name=None):
+    """<shape type="serialized"> (TriMesh::TriMesh(Stream *, int), src/librender/trimesh.cpp:156-236) -> MeshDesc"""
+    h = C.c_void_p(); m = abi.Mesh()
+    rc = lib().mtsgpu_load_serialized(os.fsencode(path), int(shape_index), C.byref(h), C.byref(m))
+    if rc != 0:
+        raise MtsGpuError("mtsgpu_load_serialized: %s" % lib().mtsgpu_last_error(None).decode())
+    try:
+        pos = abi.np_from(m.positions, (m.n_verts, 3), np.float32)
+        tri = abi.np_from(m.triangles, (m.n_tris, 3), np.uint32)
+        nrm = abi.np_from(m.normals, (m.n_verts, 3), np.float32) if m.normals else None
+        return scenes.MeshDesc(pos, tri, bsdf=bsdf, lum=lum, face_normals=bool(m.face_normals), normals=nrm,
+                               name=name or "%s#%d" % (os.path.basename(path), shape_index))
+    finally:
+        lib().mtsgpu_loaded_mesh_free(h)
 
 
 def build(force=False):
@@ -85,6 +101,8 @@ def lib():
     L.mtsgpu_flat_scene_free.argtypes = [vp]; L.mtsgpu_flat_scene_free.restype = None
     L.mtsgpu_flat_scene_kdstats.argtypes = [vp, C.POINTER(C.c_double)]
     L.mtsgpu_make_camera.argtypes = [f32p, f32p, f32p, C.c_float, C.c_int, C.c_int, C.POINTER(abi.Camera)]
+    L.mtsgpu_load_serialized.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(abi.Mesh)]
+    L.mtsgpu_loaded_mesh_free.argtypes = [vp]; L.mtsgpu_loaded_mesh_free.restype = None
     _lib = L
     return L
 

@@ -635,6 +635,31 @@ int mtsgpu_set_film_edges(mtsgpu_ctx *c, int high_quality_edges) {
 	return 0;
 }
 
+struct mtsgpu_loaded_mesh { mg::LoadedMesh m; };
+
+int mtsgpu_load_serialized(const char *path, int shape_index, mtsgpu_loaded_mesh **out, mtsgpu_mesh *mesh) {
+	if (!path || !out || !mesh) return fail(nullptr, MTSGPU_EINVAL, "null argument");
+	*out = nullptr;
+	mtsgpu_loaded_mesh *lm = new mtsgpu_loaded_mesh();
+	try {
+		loadSerializedMesh(path, shape_index, lm->m);
+	} catch (const std::exception &e) {
+		delete lm;
+		return fail(nullptr, MTSGPU_EINVAL, "%s", e.what());
+	}
+	std::memset(mesh, 0, sizeof(*mesh));
+	mesh->n_verts = (uint32_t) (lm->m.positions.size() / 3); mesh->n_tris = (uint32_t) (lm->m.triangles.size() / 3);
+	mesh->positions = lm->m.positions.data();
+	mesh->normals = lm->m.normals.empty() ? nullptr : lm->m.normals.data();
+	mesh->triangles = lm->m.triangles.data();
+	mesh->face_normals = lm->m.faceNormals ? 1 : 0;
+	mesh->bsdf = -1; mesh->lum = -1; mesh->shape_type = MTSGPU_SHAPE_TRIMESH;
+	*out = lm;
+	return 0;
+}
+
+void mtsgpu_loaded_mesh_free(mtsgpu_loaded_mesh *m) { delete m; }
+
 int mtsgpu_tabulate_filter(int kind, float half_size, float stddev, float *size_xy, float *values) {
 	if (!size_xy || !values || (kind != 0 && kind != 1)) return fail(nullptr, MTSGPU_EINVAL, "bad filter arguments");
 	tabulateFilter(kind, half_size, stddev, size_xy, values);

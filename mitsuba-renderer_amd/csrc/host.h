@@ -31,6 +31,14 @@ struct FlatScene {
 };
 
 void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatScene &fs);
+
+// One shape of a `.serialized` file (TriMesh::TriMesh(Stream *, int), src/librender/trimesh.cpp:156-236)
+struct LoadedMesh {
+	std::vector<float> positions, normals;     // normals empty when the file has none
+	std::vector<uint32_t> triangles;
+	bool faceNormals = false;
+};
+void loadSerializedMesh(const char *path, int index, LoadedMesh &out);   // throws std::runtime_error
 // TabulatedFilter of the box (kind 0) / gaussian (kind 1) plugins: sizeXY[2], values[16*16]
 void tabulateFilter(int kind, float halfSize, float stddev, float *sizeXY, float *values);
 void makeCamera(const float origin[3], const float target[3], const float up[3], float fovDeg, int width, int height,

@@ -424,5 +424,33 @@ def envlit():
     return sd
 
 
+def matpreview(serialized_path, loader, material="roughglass"):
+    """The reference's material-preview scene (data/blender/mitsuba/matpreview/matpreview.xml): the three shapes of
+    matpreview.serialized (interior, exterior, ground plane) with the toWorld transforms, camera and envmap rotation
+    of the XML; the EXR of the original is replaced by the synthetic lat-long bitmap (no OpenEXR here) and the
+    checkerboard of the plane by its mean reflectance.  `loader(path, index)` -> MeshDesc (the product's
+    mtsgpu_load_serialized in tests)."""
+    sd = SceneDescription("matpreview")
+    diff = sd.lambertian(0.18)
+    plane = sd.lambertian(0.3)
+    mat = {"roughglass": lambda: sd.roughglass(0.1, 1.5046, 1.0, "beckmann"), "roughmetal": lambda: sd.roughmetal(0.1),
+           "phong": lambda: sd.phong(30.0, 0.2, 0.7), "dielectric": lambda: sd.dielectric()}[material]()
+    inner = loader(serialized_path, 0)
+    inner.positions = (inner.positions + np.array([0, 0, 0.0252155], dtype=np.float32)).astype(np.float32)
+    inner.bsdf = diff
+    outer = loader(serialized_path, 1)
+    outer.bsdf = mat
+    ground = loader(serialized_path, 2)
+    ground.positions = (ground.positions * F(20.0) + np.array([-10, 10, 0], dtype=np.float32)).astype(np.float32)
+    ground.bsdf = plane
+    sd.meshes += [inner, outer, ground]
+    sd.envmap(env_bitmap(), 1.0, to_world=[[-0.224951, -0.000001, -0.974370], [-0.974370, 0.0, 0.224951], [0.0, 1.0, -0.000001]])
+    o = np.array([3.69558, -3.46243, 3.25463], dtype=np.float32)
+    fwd = np.array([-0.654862, 0.610666, -0.445245], dtype=np.float32)
+    sd.camera = dict(origin=tuple(o), target=tuple(o + fwd), up=(-0.31737, 0.312469, 0.895343), fov=28.8415)
+    sd.max_depth = 8
+    return sd
+
+
 def by_name(name, **kw):
     return {"c1": cornell_c1, "c3": cornell_c3, "c5": cornell_c5, "next": next_rows, "spheres": spheres, "envlit": envlit}[name](**kw)

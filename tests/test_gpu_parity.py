@@ -1,4 +1,6 @@
 """GPU parity: the HIP path through the C ABI vs the CPU oracle, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -13,7 +15,15 @@ SCENES = {
     "next_rows": lambda s: s.next_rows(sphere_subdiv=2),
     "spheres": lambda s: s.spheres(),
     "envlit": lambda s: s.envlit(),
+    # the reference's own material-preview meshes (data/blender/mitsuba/matpreview/matpreview.serialized), read by
+    # the product's loader of the `.serialized` container
+    "matpreview": lambda s: s.matpreview(os.path.join(os.path.dirname(__file__), "golden", "matpreview.serialized"), _loader()),
 }
+
+
+def _loader():
+    import _pkgload
+    return _pkgload.load().load_serialized
 
 
 def _setup(mts, orc, name, W=64, H=64, sampler="independent", spp=8, max_depth=None, seed=0x5EED):
@@ -66,7 +76,8 @@ def test_ld_tables_bit_exact(gpu_lib, mts, orc):
                                           ("next_rows", "independent"), ("next_rows", "ldsampler"),
                                           ("spheres", "independent"), ("spheres", "ldsampler"),
                                           ("envlit", "independent"), ("envlit", "ldsampler"),
-                                          ("c5_small", "halton"), ("c5_small", "hammersley"), ("spheres", "halton")])
+                                          ("c5_small", "halton"), ("c5_small", "hammersley"), ("spheres", "halton"),
+                                          ("matpreview", "ldsampler")])
 def test_li_samples_bit_exact(gpu_lib, mts, orc, name, sampler):
     """MIPathTracer::Li per camera sample: radiance, alpha, raster position and path depth"""
     sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, name, W=32, H=32, sampler=sampler, spp=16)
@@ -82,7 +93,7 @@ def test_li_samples_bit_exact(gpu_lib, mts, orc, name, sampler):
 @pytest.mark.parametrize("name,sampler,spp", [("c1", "independent", 16), ("c1", "ldsampler", 32), ("c3_small", "ldsampler", 16),
                                               ("c5_small", "ldsampler", 16), ("next_rows", "ldsampler", 16),
                                               ("spheres", "ldsampler", 16), ("envlit", "ldsampler", 16),
-                                              ("c5_small", "halton", 24), ("c5_small", "hammersley", 24)])
+                                              ("c5_small", "halton", 24), ("c5_small", "hammersley", 24), ("matpreview", "ldsampler", 8)])
 def test_film_matches_oracle(gpu_lib, mts, orc, name, sampler, spp):
     """whole renderBlock + putSample pipeline; tolerance stated by north_star: pixel RMSE < 1e-5
     (the target is bit-identical, which is what is asserted first and reported)"""

@@ -116,3 +116,60 @@ def test_tiles_of_rank_partition(mts):
     parts = [mts.filmreduce.tiles_of_rank(W, H, 32, r, 3) for r in range(3)]
     allp = np.concatenate(parts)
     assert len(allp) == W * H and len(np.unique(allp)) == W * H
+
+
+def test_serialized_mesh_loader(mts, tmp_path):
+    """mtsgpu_load_serialized == TriMesh::TriMesh(Stream *, int) (src/librender/trimesh.cpp:156-236) on the reference's
+    own data file (data/blender/mitsuba/matpreview/matpreview.serialized, kept under tests/golden/) and on files
+    written by an independent Python implementation of the format (tests/serialized_io.py)"""
+    import hashlib
+    import os
+    import serialized_io as sio
+    path = os.path.join(os.path.dirname(__file__), "golden", "matpreview.serialized")
+    data = open(path, "rb").read()
+    assert sio.shape_count(data) == 3
+    golden = {0: (2078, 3936, "ebdc487819cb"), 1: (7529, 14288, "f67fc789ac10"), 2: (25, 32, "7aa5b07f5656")}
+    for i in range(3):
+        ref = sio.read(path, i)
+        m = mts.load_serialized(path, i)
+        assert np.array_equal(ref["positions"].view(np.uint32), m.positions.view(np.uint32))
+        assert np.array_equal(ref["triangles"], m.triangles)
+        assert np.array_equal(ref["normals"].view(np.uint32), m.normals.view(np.uint32)) and not m.face_normals
+        nv, nt, sha = golden[i]
+        assert (len(m.positions), len(m.triangles)) == (nv, nt)
+        assert hashlib.sha1(m.positions.tobytes() + m.triangles.tobytes()).hexdigest()[:12] == sha
+    # double precision, texture coordinates and colours (skipped), face normals; several shapes per file
+    rng = np.random.RandomState(4)
+    meshes = []
+    for k in range(3):
+        nv = 50 + 17 * k
+        meshes.append(dict(positions=rng.randn(nv, 3), triangles=rng.randint(0, nv, (80 + k, 3)),
+                           normals=rng.randn(nv, 3) if k != 1 else None, texcoords=rng.rand(nv, 2) if k == 0 else None,
+                           colors=rng.rand(nv, 3) if k == 2 else None, face_normals=(k == 1)))
+    for double in (False, True):
+        f = str(tmp_path / ("m%d.serialized" % double))
+        sio.write(f, meshes, double=double)
+        for k, src in enumerate(meshes):
+            m = mts.load_serialized(f, k)
+            assert np.array_equal(m.positions, np.asarray(src["positions"]).astype(np.float32))
+            assert np.array_equal(m.triangles, np.asarray(src["triangles"], dtype=np.uint32))
+            assert (m.normals is None) == (src["normals"] is None) and m.face_normals == bool(src["face_normals"])
+            if m.normals is not None:
+                assert np.array_equal(m.normals, np.asarray(src["normals"]).astype(np.float32))
+    # malformed input is refused with an error, never read out of bounds
+    f = str(tmp_path / "m0.serialized")
+    good = open(f, "rb").read()
+    bad = {"index": (good, 7), "header": (b"\x04\x1c" + good[2:], 0), "version": (good[:2] + b"\x02\x00" + good[4:], 0),
+           "truncated": (good[:200], 0), "garbage": (good[:4] + b"\x00" * 64, 0), "empty": (b"", 0)}
+    for name, (blob, idx) in bad.items():
+        g = str(tmp_path / ("bad_%s.serialized" % name))
+        open(g, "wb").write(blob)
+        with pytest.raises(mts.MtsGpuError):
+            mts.load_serialized(g, idx)
+    with pytest.raises(mts.MtsGpuError):
+        mts.load_serialized(str(tmp_path / "does_not_exist.serialized"), 0)
+    # an index that points outside the vertex array
+    broken = [dict(positions=rng.randn(4, 3), triangles=np.array([[0, 1, 9]]))]
+    sio.write(str(tmp_path / "oob.serialized"), broken)
+    with pytest.raises(mts.MtsGpuError):
+        mts.load_serialized(str(tmp_path / "oob.serialized"), 0)
