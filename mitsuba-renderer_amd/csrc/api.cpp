@@ -567,6 +567,8 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	}
 	if (rc) { freeAll(c->sceneAllocs); return rc; }
 	d.lum_sel_sum = sc->lum_sel_sum; d.background_lum = sc->background_lum;
+	d.has_shapes = 0;
+	for (uint32_t s = 0; s < sc->n_shapes; ++s) if (shapeType(s) != MTSGPU_SHAPE_TRIMESH) d.has_shapes = 1;
 	d.n_lums = sc->n_lums; d.n_nodes = sc->n_nodes; d.n_tris = sc->n_tris; d.n_shapes = sc->n_shapes;
 	for (int a = 0; a < 3; ++a) { d.aabb_min[a] = sc->aabb_min[a]; d.aabb_max[a] = sc->aabb_max[a]; }
 	c->dsc = d; c->nTris = sc->n_tris;

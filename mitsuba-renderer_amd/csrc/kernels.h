@@ -35,6 +35,7 @@ struct DScene {
 	// environment map (level 0 of the MIPMap, RGB) and its sampling density (envmap.cpp:95-110)
 	const float    *env_pixels, *env_pdf, *env_cdf;
 	uint32_t        env_width, env_height, env_pdf_width, env_pdf_height;
+	uint32_t        has_shapes;   // the scene has non-triangle shapes (lets the traversal skip their test with one scalar branch)
 	const uint32_t *shape_flags, *shape_tri_offset;
 	const uint32_t *bsdf_type;
 	const float    *bsdf_params;

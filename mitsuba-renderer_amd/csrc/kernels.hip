@@ -537,7 +537,7 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 						const bool occl = !(MODE != 0 && (A.x & 0x20000000u));   // shape->isOccluder() (skdtree.h:318-333)
 						const bool ok = fresh && occl && (k != 3u);               // k == 3: degenerate triangle or another shape
 						if (COUNT && fresh) c_tri++;
-						if (k == 3u && A.y != 0u && fresh && occl) {
+						if (sc.has_shapes && k == 3u && A.y != 0u && fresh && occl) {     // has_shapes is uniform: one scalar branch
 							// a non-triangle shape (skdtree.h:287-296 / :328-332); A.y = shape type, B = centre + radius
 							const uint4 B = sc.leaf_ta[3 * (size_t) e + 1];
 							const V3 ctr(__uint_as_float(B.x), __uint_as_float(B.y), __uint_as_float(B.z));
