@@ -306,9 +306,11 @@ typedef struct mtsgpu_loaded_mesh mtsgpu_loaded_mesh;
 int  mtsgpu_load_serialized(const char *path, int shape_index, mtsgpu_loaded_mesh **out, mtsgpu_mesh *mesh);
 void mtsgpu_loaded_mesh_free(mtsgpu_loaded_mesh *m);
 
-/* TabulatedFilter for the `box` (kind 0) and `gaussian` (kind 1; halfSize, stddev properties,
- * src/rfilters/gaussian.cpp:30-42,62-65) plugins: size_xy[2], values[256] */
-int  mtsgpu_tabulate_filter(int kind, float half_size, float stddev, float *size_xy, float *values);
+/* TabulatedFilter (src/librender/rfilter.cpp:40-69) of the reconstruction filter plugins: kind 0 `box`,
+ * 1 `gaussian` (p0 = stddev; src/rfilters/gaussian.cpp:30-42,62-65), 2 `mitchell` (p0 = B, p1 = C; mitchell.cpp),
+ * 3 `catmullrom`, 4 `wsinc` (p0 = cycles; wsinc.cpp).  half_size / p0 / p1 <= 0 (mitchell: < 0) select the
+ * plugin's defaults.  size_xy[2], values[256] */
+int  mtsgpu_tabulate_filter(int kind, float half_size, float p0, float p1, float *size_xy, float *values);
 
 /* PerspectiveCameraImpl::configure for a lookAt camera (perspective.cpp:43-71,
  * transform.cpp:100-124,174-190).  fov in degrees along the smaller image side. */

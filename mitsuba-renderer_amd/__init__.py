@@ -86,7 +86,7 @@ def lib():
     L.mtsgpu_set_film_buffer.argtypes = [vp, vp]
     L.mtsgpu_set_rfilter.argtypes = [vp, C.c_float, C.c_float, f32p]
     L.mtsgpu_set_film_edges.argtypes = [vp, C.c_int]
-    L.mtsgpu_tabulate_filter.argtypes = [C.c_int, C.c_float, C.c_float, f32p, f32p]
+    L.mtsgpu_tabulate_filter.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, f32p, f32p]
     L.mtsgpu_set_options.argtypes = [vp, C.c_uint64, C.c_int, C.c_int]
     L.mtsgpu_render.argtypes = [vp, C.POINTER(C.c_int)]
     L.mtsgpu_sync.argtypes = [vp]
@@ -215,13 +215,16 @@ class MIPathTracer:
     def set_tiles(self, block_size=32, part=0, n_parts=1):
         self._chk(lib().mtsgpu_set_tiles(self._ctx, block_size, part, n_parts), "set_tiles")
 
-    def set_rfilter(self, kind="box", halfSize=2.0, stddev=0.5):
-        """Film reconstruction filter plugin: `box` (src/rfilters/box.cpp) or `gaussian` (src/rfilters/gaussian.cpp)"""
+    def set_rfilter(self, kind="box", halfSize=-1.0, stddev=-1.0, B=-1.0, C=-1.0, cycles=-1.0):
+        """Film reconstruction filter plugin (src/rfilters/{box,gaussian,mitchell,catmullrom,wsinc}.cpp); negative
+        values select the plugin defaults"""
         if kind == "box":
             self._chk(lib().mtsgpu_set_rfilter(self._ctx, 0.5, 0.5, None), "set_rfilter")
             return
         size = np.zeros(2, dtype=np.float32); values = np.zeros(256, dtype=np.float32)
-        rc = lib().mtsgpu_tabulate_filter({"gaussian": 1}[kind], halfSize, stddev, abi.ptr(size, abi.f32p), abi.ptr(values, abi.f32p))
+        k = {"gaussian": 1, "mitchell": 2, "catmullrom": 3, "wsinc": 4}[kind]
+        p0, p1 = {1: (stddev, -1.0), 2: (B, C), 3: (-1.0, -1.0), 4: (cycles, -1.0)}[k]
+        rc = lib().mtsgpu_tabulate_filter(k, halfSize, p0, p1, abi.ptr(size, abi.f32p), abi.ptr(values, abi.f32p))
         if rc != 0:
             raise MtsGpuError("mtsgpu_tabulate_filter: %s" % lib().mtsgpu_last_error(None).decode())
         self._chk(lib().mtsgpu_set_rfilter(self._ctx, float(size[0]), float(size[1]), abi.ptr(values, abi.f32p)), "set_rfilter")

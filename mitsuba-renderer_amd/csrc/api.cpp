@@ -662,9 +662,9 @@ int mtsgpu_load_serialized(const char *path, int shape_index, mtsgpu_loaded_mesh
 
 void mtsgpu_loaded_mesh_free(mtsgpu_loaded_mesh *m) { delete m; }
 
-int mtsgpu_tabulate_filter(int kind, float half_size, float stddev, float *size_xy, float *values) {
-	if (!size_xy || !values || (kind != 0 && kind != 1)) return fail(nullptr, MTSGPU_EINVAL, "bad filter arguments");
-	tabulateFilter(kind, half_size, stddev, size_xy, values);
+int mtsgpu_tabulate_filter(int kind, float half_size, float p0, float p1, float *size_xy, float *values) {
+	if (!size_xy || !values || kind < 0 || kind > 4) return fail(nullptr, MTSGPU_EINVAL, "bad filter arguments");
+	tabulateFilter(kind, half_size, p0, p1, size_xy, values);
 	return 0;
 }
 

@@ -282,28 +282,68 @@ void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatSc
 // TabulatedFilter::TabulatedFilter (src/librender/rfilter.cpp:40-69) over BoxFilter::evaluate
 // (src/rfilters/box.cpp:42-44) or GaussianFilter (src/rfilters/gaussian.cpp:30-42,62-65).
 // Host-side configure step; std::exp is the same libm call the reference makes.
-void tabulateFilter(int kind, float halfSize, float stddev, float *sizeXY, float *values) {
+namespace {
+
+// mitchellNetravali (src/rfilters/mitchell.cpp:60-74, catmullrom.cpp with B = 0, C = 1/2)
+float mitchellNetravali(float x, float B, float C) {
+	x = std::fabs(x);
+	const float xSquared = x * x, xCubed = xSquared * x;
+	if (x < 1)
+		return 1.0f / 6.0f * ((12 - 9 * B - 6 * C) * xCubed + (-18 + 12 * B + 6 * C) * xSquared + (6 - 2 * B));
+	if (x < 2)
+		return 1.0f / 6.0f * ((-B - 6 * C) * xCubed + (6 * B + 30 * C) * xSquared + (-12 * B - 48 * C) * x + (8 * B + 24 * C));
+	return 0.0f;
+}
+
+// lanczosSinc (src/libcore/util.cpp:664-674)
+float windowedSinc(float t, float tau) {
+	t = std::fabs(t);
+	if (t < kEpsilon) return 1.0f;
+	if (t > 1.0f) return 0.0f;
+	t *= kPi;
+	const float sincTerm = std::sin(t * tau) / (t * tau);
+	const float windowTerm = std::sin(t) / t;
+	return sincTerm * windowTerm;
+}
+
+} // namespace
+
+// TabulatedFilter::TabulatedFilter (src/librender/rfilter.cpp:40-69) over ReconstructionFilter::evaluate of
+// box (0), gaussian (1; p0 = stddev), mitchell (2; p0 = B, p1 = C), catmullrom (3), wsinc (4; p0 = cycles)
+void tabulateFilter(int kind, float halfSize, float p0, float p1, float *sizeXY, float *values) {
 	constexpr int R = 15;                                    // FILTER_RESOLUTION
-	float alpha = 0, cst = 0, sx, sy;
+	float alpha = 0, cst = 0, sx = 0.5f, sy = 0.5f;
 	if (kind == 1) {
 		if (halfSize <= 0) halfSize = 2.0f;
-		if (stddev <= 0) stddev = 0.5f;
-		alpha = 1 / (2 * stddev * stddev);
+		if (p0 <= 0) p0 = 0.5f;
+		alpha = 1 / (2 * p0 * p0);
 		sx = sy = halfSize;
 		cst = std::exp(-alpha * sx * sx);
-	} else {
-		sx = sy = 0.5f;
+	} else if (kind == 2 || kind == 3) {
+		if (halfSize <= 0) halfSize = 2.0f;
+		if (kind == 3) { p0 = 0.0f; p1 = 0.5f; }
+		else { if (p0 < 0) p0 = 1.0f / 3.0f; if (p1 < 0) p1 = 1.0f / 3.0f; }
+		sx = sy = halfSize;
+	} else if (kind == 4) {
+		if (halfSize <= 0) halfSize = 3.0f;
+		if (p0 <= 0) p0 = 3.0f;
+		sx = sy = halfSize;
 	}
+	auto evaluate = [&](float x, float y) -> float {
+		switch (kind) {
+			case 1: return std::max(0.0f, std::exp(-alpha * x * x) - cst) * std::max(0.0f, std::exp(-alpha * y * y) - cst);
+			case 2: case 3: return mitchellNetravali(2.0f * x / sx, p0, p1) * mitchellNetravali(2.0f * y / sy, p0, p1);
+			case 4: return windowedSinc(x / sx, p0) * windowedSinc(y / sy, p0);
+			default: return 1.0f;
+		}
+	};
 	float sum = 0;
 	for (int y = 0; y < R + 1; ++y) {
 		const float yPos = (y + 0.5f) / R * sy;
 		for (int x = 0; x < R + 1; ++x) {
 			float v = 0;
-			if (x != R && y != R) {
-				const float xPos = (x + 0.5f) / R * sx;
-				v = (kind == 1) ? std::max(0.0f, std::exp(-alpha * xPos * xPos) - cst) * std::max(0.0f, std::exp(-alpha * yPos * yPos) - cst)
-				                : 1.0f;
-			}
+			if (x != R && y != R)
+				v = evaluate((x + 0.5f) / R * sx, yPos);
 			values[y * 16 + x] = v;
 			sum += v;
 		}

@@ -39,8 +39,8 @@ struct LoadedMesh {
 	bool faceNormals = false;
 };
 void loadSerializedMesh(const char *path, int index, LoadedMesh &out);   // throws std::runtime_error
-// TabulatedFilter of the box (kind 0) / gaussian (kind 1) plugins: sizeXY[2], values[16*16]
-void tabulateFilter(int kind, float halfSize, float stddev, float *sizeXY, float *values);
+// TabulatedFilter of the box / gaussian / mitchell / catmullrom / wsinc plugins (kinds 0..4): sizeXY[2], values[16*16]
+void tabulateFilter(int kind, float halfSize, float p0, float p1, float *sizeXY, float *values);
 void makeCamera(const float origin[3], const float target[3], const float up[3], float fovDeg, int width, int height,
                 mtsgpu_camera &out);
 

@@ -130,7 +130,7 @@ void orc_render_rect_mt(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const 
 /* TabulatedFilter (src/librender/rfilter.cpp:40-69): kind 0 = box (src/rfilters/box.cpp),
  * 1 = gaussian (src/rfilters/gaussian.cpp, halfSize / stddev properties) */
 typedef struct orc_tabfilter { float size_x, size_y, values[16][16]; } orc_tabfilter;
-void orc_tabulate_filter(int kind, float half_size, float stddev, orc_tabfilter *out);
+void orc_tabulate_filter(int kind, float half_size, float p0, float p1, orc_tabfilter *out);
 /* BlockedRenderProcess: every ImageBlock tile (imageproc.cpp:43-78) with t % n_parts == part is
  * rendered into a block with a border of ceil(size - 0.5) pixels (renderproc.cpp:143-144) through
  * ImageBlock::putSample, then added to the film (Film::putImageBlock, mfilm.cpp:118-143).

@@ -94,7 +94,7 @@ def lib():
                                  u32p, C.c_uint32, f32p]
     L.orc_render_rect_mt.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(RenderParams),
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
-    L.orc_tabulate_filter.argtypes = [C.c_int, C.c_float, C.c_float, C.POINTER(TabFilter)]
+    L.orc_tabulate_filter.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(TabFilter)]
     L.orc_render_tiles.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(RenderParams), C.POINTER(TabFilter),
                                    C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(abi.Stats)]
     L.orc_luminaire_sample.argtypes = [C.POINTER(abi.Scene), C.c_int, f32p, f32p, f32p]
@@ -190,9 +190,13 @@ def develop(film):
     return (film[..., :3] * inv).astype(np.float32)
 
 
-def tabulate_filter(kind="gaussian", half_size=2.0, stddev=0.5):
+RFILTERS = {"box": 0, "gaussian": 1, "mitchell": 2, "catmullrom": 3, "wsinc": 4}
+
+
+def tabulate_filter(kind="gaussian", half_size=-1.0, p0=-1.0, p1=-1.0):
+    """half_size / p0 / p1 <= 0 select the plugin defaults (gaussian: stddev; mitchell: B, C; wsinc: cycles)"""
     f = TabFilter()
-    lib().orc_tabulate_filter({"box": 0, "gaussian": 1}[kind], half_size, stddev, C.byref(f))
+    lib().orc_tabulate_filter(RFILTERS[kind], half_size, p0, p1, C.byref(f))
     return f
 
 

@@ -1910,14 +1910,62 @@ void orc_render_rect_mt(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const 
 /* TabulatedFilter::TabulatedFilter (rfilter.cpp:40-69) over BoxFilter::evaluate (box.cpp:42-44)
  * or GaussianFilter::evaluate (gaussian.cpp:62-65, ctor :30-42).  std::exp here is the host libm,
  * as in the reference's configure step (not on the per-sample path). */
-void orc_tabulate_filter(int kind, float half_size, float stddev, orc_tabfilter *out) {
+/* mitchellNetravali (src/rfilters/mitchell.cpp:60-74 == catmullrom.cpp) */
+static float mitchell_netravali(float x, float B, float C) {
+	x = fabsf(x);
+	float xSquared = x*x, xCubed = xSquared*x;
+	if (x < 1) {
+		return 1.0f/6.0f * ((12-9*B-6*C)*xCubed + (-18+12*B+6*C) * xSquared + (6-2*B));
+	} else if (x < 2) {
+		return 1.0f/6.0f * ((-B-6*C)*xCubed + (6*B+30*C) * xSquared + (-12*B-48*C) * x + (8*B + 24*C));
+	} else {
+		return 0.0f;
+	}
+}
+
+/* lanczosSinc (src/libcore/util.cpp:664-674); host libm as in the reference */
+static float lanczos_sinc_(float t, float tau) {
+	t = fabsf(t);
+	if (t < ORC_EPS)
+		return 1.0f;
+	else if (t > 1.0f)
+		return 0.0f;
+	t *= ORC_PI;
+	float sincTerm = sinf(t*tau)/(t*tau);
+	float windowTerm = sinf(t)/t;
+	return sincTerm * windowTerm;
+}
+
+/* ReconstructionFilter::evaluate of the five plugins: box (box.cpp), gaussian (gaussian.cpp:62-65),
+ * mitchell (mitchell.cpp:55-58), catmullrom (catmullrom.cpp), wsinc (wsinc.cpp:53-56) */
+static float rfilter_evaluate(int kind, float x, float y, float sx, float sy, float p0, float p1, float alpha, float cst) {
+	switch (kind) {
+		case 1: return fmaxf_((float) 0.0f, expf(-alpha * x * x) - cst) * fmaxf_((float) 0.0f, expf(-alpha * y * y) - cst);
+		case 2: case 3: return mitchell_netravali(2.0f * x / sx, p0, p1) * mitchell_netravali(2.0f * y / sy, p0, p1);
+		case 4: return lanczos_sinc_(x / sx, p0) * lanczos_sinc_(y / sy, p0);
+		default: return 1.0f;
+	}
+}
+
+/* TabulatedFilter::TabulatedFilter (src/librender/rfilter.cpp:40-69).  kind: 0 box, 1 gaussian (p0 = stddev),
+ * 2 mitchell (p0 = B, p1 = C), 3 catmullrom, 4 wsinc (p0 = cycles); half_size <= 0 selects the plugin default */
+void orc_tabulate_filter(int kind, float half_size, float p0, float p1, orc_tabfilter *out) {
 	float alpha = 0, cst = 0;
 	if (kind == 1) {
 		if (half_size <= 0) half_size = 2.0f;
-		if (stddev <= 0) stddev = 0.5f;
-		alpha = 1 / (2*stddev*stddev);
+		if (p0 <= 0) p0 = 0.5f;
+		alpha = 1 / (2*p0*p0);
 		out->size_x = out->size_y = half_size;
 		cst = expf(-alpha * out->size_x * out->size_x);
+	} else if (kind == 2 || kind == 3) {
+		if (half_size <= 0) half_size = 2.0f;
+		if (kind == 3) { p0 = 0.0f; p1 = 0.5f; }
+		else { if (p0 < 0) p0 = 1.0f / 3.0f; if (p1 < 0) p1 = 1.0f / 3.0f; }
+		out->size_x = out->size_y = half_size;
+	} else if (kind == 4) {
+		if (half_size <= 0) half_size = 3.0f;
+		if (p0 <= 0) p0 = 3.0f;
+		out->size_x = out->size_y = half_size;
 	} else {
 		out->size_x = out->size_y = 0.5f;
 	}
@@ -1929,11 +1977,7 @@ void orc_tabulate_filter(int kind, float half_size, float stddev, orc_tabfilter 
 				out->values[y][x] = 0;
 			} else {
 				float xPos = (x + 0.5f) / FILTER_RESOLUTION * out->size_x;
-				if (kind == 1)
-					out->values[y][x] = fmaxf_((float) 0.0f, expf(-alpha * xPos * xPos) - cst)
-					                  * fmaxf_((float) 0.0f, expf(-alpha * yPos * yPos) - cst);
-				else
-					out->values[y][x] = 1.0f;
+				out->values[y][x] = rfilter_evaluate(kind, xPos, yPos, out->size_x, out->size_y, p0, p1, alpha, cst);
 			}
 			sum += out->values[y][x];
 		}

@@ -268,6 +268,11 @@ def test_gaussian_rfilter_matches_oracle(gpu_lib, mts, orc):
     assert it.stats()["camera_samples"] == ohst.camera_samples == (80 + 4) * (72 + 4) * 8
     assert not np.array_equal(ohq.view(np.uint32), ofilm.view(np.uint32))
     it.set_film_edges(False)
+    # the other reconstruction filter plugins (negative lobes)
+    for kind in ("mitchell", "catmullrom", "wsinc"):
+        it.set_rfilter(kind); it.clear_film(); assert it.render()
+        ok, _ = orc.render_tiles(oscene.scene, ocam, op, orc.tabulate_filter(kind))
+        assert np.array_equal(it.film().view(np.uint32), ok.view(np.uint32)), kind
     # back to the box filter
     it.set_rfilter("box"); it.set_tiles(32, 0, 1); it.clear_film(); assert it.render()
     obox, _ = orc.render(oscene.scene, ocam, op)

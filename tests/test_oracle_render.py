@@ -233,8 +233,30 @@ def test_bordered_tiles_and_gaussian_filter(mts, orc):
     assert abs(c[10:-10, 10:-10, 4].mean() / 8 - 1) < 0.05
     # host tabulation of the product == oracle
     size = np.zeros(2, dtype=np.float32); vals = np.zeros(256, dtype=np.float32)
-    assert mts.lib().mtsgpu_tabulate_filter(1, 2.0, 0.5, mts.abi.ptr(size, mts.abi.f32p), mts.abi.ptr(vals, mts.abi.f32p)) == 0
+    assert mts.lib().mtsgpu_tabulate_filter(1, 2.0, 0.5, -1.0, mts.abi.ptr(size, mts.abi.f32p), mts.abi.ptr(vals, mts.abi.f32p)) == 0
     assert np.array_equal(vals.reshape(16, 16).view(np.uint32), tab.view(np.uint32)) and size[0] == 2.0
+
+
+def test_other_reconstruction_filters(mts, orc):
+    """mitchell / catmullrom / wsinc (src/rfilters): negative lobes, tables that integrate to one, product == oracle"""
+    sd = mts.scenes.cornell_c1()
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 70, 50)
+    prm = orc.render_params(4, sampler=mts.abi.SAMPLER_LD_KEYED, spp=8, seed=3)
+    ref, _ = orc.render(fs.scene, cam, prm)
+    for kind, k, hs in (("mitchell", 2, 2.0), ("catmullrom", 3, 2.0), ("wsinc", 4, 3.0)):
+        g = orc.tabulate_filter(kind)
+        tab = np.array(g.values, dtype=np.float32)
+        assert g.size_x == hs and tab.min() < 0 and tab[0, 0] == tab.max()
+        assert abs(tab.sum() * 4 * g.size_x * g.size_y / 225.0 - 1.0) < 1e-5
+        size = np.zeros(2, dtype=np.float32); vals = np.zeros(256, dtype=np.float32)
+        assert mts.lib().mtsgpu_tabulate_filter(k, -1.0, -1.0, -1.0, mts.abi.ptr(size, mts.abi.f32p), mts.abi.ptr(vals, mts.abi.f32p)) == 0
+        assert np.array_equal(vals.reshape(16, 16).view(np.uint32), tab.view(np.uint32)) and size[0] == hs
+        film, _ = orc.render_tiles(fs.scene, cam, prm, g)
+        assert abs(orc.develop(film)[8:-8, 8:-8].mean() / orc.develop(ref)[8:-8, 8:-8].mean() - 1) < 0.03
+    # Mitchell's B and C properties
+    a = np.array(orc.tabulate_filter("mitchell", p0=0.0, p1=0.5).values); b = np.array(orc.tabulate_filter("catmullrom").values)
+    assert np.array_equal(a, b)
 
 
 def test_high_quality_edges(mts, orc):
