@@ -177,6 +177,60 @@ def test_cancel_and_error_paths(gpu_lib, mts, orc):
         fresh.render()                                  # no scene uploaded
 
 
+def test_edge_cases(gpu_lib, mts, orc):
+    """empty and ragged inputs, degenerate geometry, non-finite rays, the largest LD sample count"""
+    F = np.float32
+    # --- a scene whose camera sees nothing: every ray misses, the film stays black, no kernel hangs ---
+    sd = mts.scenes.cornell_c1()
+    sd.camera = dict(origin=(0.0, 1.0, 5.0), target=(0.0, 1.0, 9.0), up=(0.0, 1.0, 0.0), fov=30.0)
+    scene = mts.Scene(sd); oscene = orc.FlatScene(sd)
+    cam = mts.PerspectiveCamera.for_description(sd, 33, 17); ocam = orc.make_camera(sd, 33, 17)     # ragged tiles
+    it = mts.MIPathTracer(maxDepth=4)
+    it.preprocess(scene, cam, sampler="ldsampler", sampleCount=4, seed=2)
+    assert it.render()
+    film = it.film()
+    assert film[..., :4].max() == 0 and (film[..., 4] > 0).all()
+    ofilm, _ = orc.render(oscene.scene, ocam, orc.render_params(4, sampler=mts.abi.SAMPLER_LD_KEYED, spp=4, seed=2))
+    assert np.array_equal(film.view(np.uint32), ofilm.view(np.uint32))
+    # --- empty inputs of the test hooks ---
+    assert it.trace_rays(np.zeros((0, 8), dtype=np.float32)).shape == (0, 4)
+    assert it.li_samples(np.zeros((0, 3), dtype=np.uint32)).shape == (0, 8)
+    # --- non-finite and degenerate rays: same answers as the oracle, and the kernel terminates ---
+    rays = np.zeros((8, 8), dtype=np.float32)
+    rays[:, 0:3] = (0.0, 1.0, 3.0); rays[:, 3] = 1e-4; rays[:, 4:7] = (0.0, 0.0, -1.0); rays[:, 7] = np.inf
+    rays[1, 4] = np.nan; rays[2, 4:7] = 0.0; rays[3, 4:7] = (np.inf, 0.0, -1.0); rays[4, 0] = np.nan
+    rays[5, 7] = 0.0; rays[6, 3] = np.inf; rays[7, 4:7] = (0.0, 0.0, 1.0)
+    sd1 = mts.scenes.cornell_c1(); sc1 = mts.Scene(sd1); osc1 = orc.FlatScene(sd1)
+    it1 = mts.MIPathTracer(maxDepth=4)
+    it1.preprocess(sc1, mts.PerspectiveCamera.for_description(sd1, 16, 16), sampler="independent", sampleCount=1)
+    assert np.array_equal(it1.trace_rays(rays), orc.trace_rays(osc1.scene, rays))
+    assert np.array_equal(it1.trace_rays(rays, shadow=True)[:, 3], orc.trace_rays(osc1.scene, rays, shadow=True)[:, 3])
+    # --- degenerate (zero-area) and duplicated triangles next to ordinary ones ---
+    sd2 = mts.scenes.cornell_c1()
+    pos = np.array([[-0.3, 0.5, 0.0], [0.3, 0.5, 0.0], [0.0, 1.1, 0.0], [0.1, 0.1, 0.1]], dtype=F)
+    tri = np.array([[0, 1, 2], [0, 1, 2], [3, 3, 3], [0, 1, 1], [2, 1, 0]], dtype=np.uint32)
+    sd2.add_mesh(pos, tri, bsdf=sd2.lambertian(0.5), face_normals=True, name="degenerate")
+    sc2 = mts.Scene(sd2); osc2 = orc.FlatScene(sd2)
+    assert np.array_equal(sc2.arrays()["kd_nodes"], osc2.arrays()["kd_nodes"])
+    it2 = mts.MIPathTracer(maxDepth=5)
+    cam2 = mts.PerspectiveCamera.for_description(sd2, 31, 29)
+    it2.preprocess(sc2, cam2, sampler="independent", sampleCount=8, seed=3)
+    assert it2.render()
+    o2, _ = orc.render(osc2.scene, orc.make_camera(sd2, 31, 29), orc.render_params(5, spp=8, seed=3))
+    assert np.array_equal(it2.film().view(np.uint32), o2.view(np.uint32))
+    chords = chord_rays(5000, (0, 1, 0), 2.2, seed=5)
+    assert np.array_equal(it2.trace_rays(chords), orc.trace_rays(osc2.scene, chords))      # equal-t ties between the duplicates
+    # --- the largest sample count of the LD sampler's 16-bit permutations, on a 2 x 1 image ---
+    it3 = mts.MIPathTracer(maxDepth=3)
+    cam3 = mts.PerspectiveCamera.for_description(sd1, 2, 1)
+    it3.preprocess(sc1, cam3, sampler="ldsampler", sampleCount=65536, seed=4)
+    assert it3.render()
+    o3, _ = orc.render(osc1.scene, orc.make_camera(sd1, 2, 1), orc.render_params(3, sampler=mts.abi.SAMPLER_LD_KEYED, spp=65536, seed=4))
+    assert np.array_equal(it3.film().view(np.uint32), o3.view(np.uint32))
+    with pytest.raises(mts.MtsGpuError):
+        it3.preprocess(sc1, cam3, sampler="ldsampler", sampleCount=65537)                 # would not fit the tables
+
+
 # --------------------------------------------------------------------------------------------
 # BASELINE.json full size: the 1 044 482-triangle C3 scene at 1024 x 1024
 # --------------------------------------------------------------------------------------------
