@@ -115,6 +115,9 @@ def _chi2_bsdf(orc, btype, params, wi, n=200000, nt=10, nph=20, seed=3, full_sph
     ("lambertian", 0, [0.5, 0.5, 0.5], (0.3, 0.2, 0.9)),
     ("roughmetal", 2, [0.3, 0.37, 0.37, 0.37, 2.82, 2.82, 2.82, 1, 1, 1], (0.4, 0.0, 0.9)),
     ("microfacet", 3, [0.3, 0.5, 0.5, 1.5, 1.0, 1, 1, 1, 1, 1, 1], (0.5, 0.1, 0.8)),
+    # the parameter sets of the reference's own chi-square list (data/tests/test_bsdf.xml:62-73)
+    ("roughmetal alphaB=0.1", 2, [0.1, 0.37, 0.37, 0.37, 2.82, 2.82, 2.82, 1, 1, 1], (0.4, 0.0, 0.9)),
+    ("microfacet alphaB=0.1", 3, [0.1, 0.5, 0.5, 1.5, 1.0, 1, 1, 1, 1, 1, 1], (0.5, 0.1, 0.8)),
 ])
 def test_bsdf_sampling_matches_pdf_chi_square(orc, name, btype, params, wi):
     """sample() histogram vs integrated pdf(); significance level 0.005 as in test_chisquare.cpp:28"""
