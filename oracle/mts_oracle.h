@@ -136,6 +136,9 @@ void orc_tabulate_filter(int kind, float half_size, float p0, float p1, orc_tabf
  * ImageBlock::putSample, then added to the film (Film::putImageBlock, mfilm.cpp:118-143).
  * Summation order is fixed: inside a block by (pixel row-major, sample index),
  * blocks by (tx%2 + 2*(ty%2)) colour. */
+/* rays of the reference's traversal benchmark (src/tests/test_kd.cpp:96-116) */
+void orc_chord_rays(const float center[3], float radius, uint32_t n, float *rays);
+
 /* test hooks for the luminaires: Luminaire::sample without the visibility test (out = p, n, d, value, pdf) and
  * Scene::pdfLuminaire */
 void orc_luminaire_sample(const mtsgpu_scene *sc, int l, const float p[3], const float sample[2], float out[13]);

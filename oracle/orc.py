@@ -97,6 +97,7 @@ def lib():
     L.orc_tabulate_filter.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(TabFilter)]
     L.orc_render_tiles.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(RenderParams), C.POINTER(TabFilter),
                                    C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(abi.Stats)]
+    L.orc_chord_rays.argtypes = [f32p, C.c_float, C.c_uint32, f32p]
     L.orc_luminaire_sample.argtypes = [C.POINTER(abi.Scene), C.c_int, f32p, f32p, f32p]
     L.orc_luminaire_pdf.argtypes = [C.POINTER(abi.Scene), C.c_int, f32p, f32p, f32p, f32p]; L.orc_luminaire_pdf.restype = C.c_float
     L.orc_bsdf_f.argtypes = [C.c_uint32, f32p, f32p, f32p, f32p]
@@ -191,6 +192,14 @@ def develop(film):
 
 
 RFILTERS = {"box": 0, "gaussian": 1, "mitchell": 2, "catmullrom": 3, "wsinc": 4}
+
+
+def chord_rays(center, radius, n):
+    """the rays of src/tests/test_kd.cpp:96-116 (default-seeded Random)"""
+    c = np.asarray(center, dtype=np.float32)
+    rays = np.zeros((n, 8), dtype=np.float32)
+    lib().orc_chord_rays(abi.ptr(c, abi.f32p), float(radius), n, abi.ptr(rays, abi.f32p))
+    return rays
 
 
 def tabulate_filter(kind="gaussian", half_size=-1.0, p0=-1.0, p1=-1.0):

@@ -337,9 +337,33 @@ static int scene_is_occluded(const mtsgpu_scene *sc, const float p1[3], const fl
 	return 0;
 }
 
+/* The ray generator of the reference's own traversal benchmark (src/tests/test_kd.cpp:96-116): chords between two
+ * uniform points of a sphere, drawn from a default-seeded Random.  rays: [n][8] = o, mint, d, maxt with the
+ * defaults of Ray(o, d, time) (mint = Epsilon, maxt = inf).  Point2(nextFloat(), nextFloat()) leaves the order of
+ * its two draws to the compiler; x first is used. */
+void orc_chord_rays(const float center[3], float radius, uint32_t n, float *rays) {
+	orc_random rnd;
+	orc_random_seed(&rnd, 5489ULL);                     /* Random::Random() (random.cpp:61-76) */
+	for (uint32_t i = 0; i < n; ++i) {
+		float s1[2], s2[2], d1[3], d2[3], p1[3], p2[3], dir[3];
+		s1[0] = orc_random_next_float(&rnd); s1[1] = orc_random_next_float(&rnd);
+		s2[0] = orc_random_next_float(&rnd); s2[1] = orc_random_next_float(&rnd);
+		orc_square_to_sphere(s1, d1); orc_square_to_sphere(s2, d2);
+		for (int k = 0; k < 3; ++k) { p1[k] = center[k] + d1[k] * radius; p2[k] = center[k] + d2[k] * radius; }
+		v3_sub(dir, p2, p1);
+		v3_normalize(dir, dir);
+		float *r = rays + 8 * (size_t) i;
+		r[0] = p1[0]; r[1] = p1[1]; r[2] = p1[2]; r[3] = ORC_EPS;
+		r[4] = dir[0]; r[5] = dir[1]; r[6] = dir[2]; r[7] = INFINITY;
+	}
+}
+
 void orc_trace_rays(const mtsgpu_scene *sc, const float *rays, uint32_t n, int shadow,
                     uint32_t *hits, orc_trace_counts *counts) {
 	if (counts) memset(counts, 0, sizeof(*counts));
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4096) if (!counts && n > 100000)
+#endif
 	for (uint32_t i = 0; i < n; ++i) {
 		const float *r = rays + 8 * (size_t) i;
 		ray_t ray;

@@ -177,6 +177,29 @@ def test_cancel_and_error_paths(gpu_lib, mts, orc):
         fresh.render()                                  # no scene uploaded
 
 
+def test_bunny_benchmark_rays(gpu_lib, mts, orc):
+    """the reference's own traversal benchmark (src/tests/test_kd.cpp:85-130): chords of the test's sphere through the
+    kd-tree of data/tests/bunny.ply (tests/golden/bunny.ply), rays drawn exactly as the test draws them"""
+    import ply_io
+    pos, tri = ply_io.read(os.path.join(os.path.dirname(__file__), "golden", "bunny.ply"))
+    assert pos.shape == (35947, 3) and tri.shape == (69451, 3)
+    sd = mts.scenes.SceneDescription("bunny")
+    sd.add_mesh(pos, tri, bsdf=sd.lambertian(0.5), face_normals=False, name="bunny")
+    sd.point_light((0.0, 0.5, 0.5), 1.0)                               # a scene needs a luminaire (scene.cpp:310-318)
+    scene = mts.Scene(sd); oscene = orc.FlatScene(sd)
+    a, b = scene.arrays(), oscene.arrays()
+    assert all(np.asarray(a[k]).tobytes() == np.asarray(b[k]).tobytes() for k in a)      # both builders, 160 701 nodes
+    assert scene.sc.n_nodes == 160701 and scene.sc.n_indices == 235974
+    it = mts.MIPathTracer(maxDepth=2)
+    it.preprocess(scene, mts.PerspectiveCamera.for_description(sd, 16, 16), sampler="independent", sampleCount=1)
+    rays = orc.chord_rays((-0.016840, 0.110154, -0.001537), 0.2, 300000)
+    got = it.trace_rays(rays, shadow=True); exp = orc.trace_rays(oscene.scene, rays, shadow=True)
+    assert np.array_equal(got[:, 3], exp[:, 3])
+    assert abs(exp[:, 3].mean() - 0.1044) < 0.003                      # 10.44 % of the chords hit the bunny
+    got = it.trace_rays(rays); exp = orc.trace_rays(oscene.scene, rays)
+    assert np.array_equal(got, exp)
+
+
 def test_edge_cases(gpu_lib, mts, orc):
     """empty and ragged inputs, degenerate geometry, non-finite rays, the largest LD sample count"""
     F = np.float32
