@@ -51,7 +51,8 @@ enum {
 	                                       2/alpha^2 - 2 the constructor derives, roughglass.cpp:130-136) [2] intIOR
 	                                       [3] extIOR [4..6] specularReflectance [7..9] specularTransmittance
 	                                       (src/bsdfs/roughglass.cpp)                                              */
-	MTSGPU_BSDF_NTYPES = 7,
+	MTSGPU_BSDF_DIFFTRANS = 7,  /* params: [0..2] transmittance                          (src/bsdfs/difftrans.cpp)  */
+	MTSGPU_BSDF_NTYPES = 8,
 	/* OR-ed into bsdf_type: the BSDF is wrapped in a `twosided` adapter (src/bsdfs/twosided.cpp) */
 	MTSGPU_BSDF_TWOSIDED = 0x100
 };
@@ -68,6 +69,8 @@ enum {
 	MTSGPU_LUM_SPOT = 4,     /* [0..2] intensity [3..5] position [6] cos(beamWidth) [7] cos(cutoffAngle)
 	                            [8] cutoffAngle (rad) [9] 1/(cutoffAngle-beamWidth) [10..18] world->luminaire
 	                            3x3 (row major) [19] beamWidth (rad)           (src/luminaires/spot.cpp:33-118) */
+	MTSGPU_LUM_COLLIMATED = 6, /* [0..2] intensity [3] radius [4..15] world->luminaire 3x4 (row major, affine)
+	                            [16..27] luminaire->world 3x4              (src/luminaires/collimated.cpp) */
 	MTSGPU_LUM_ENVMAP = 5    /* [0] intensityScale [3..5] bsphere centre [6] radius (envmap.cpp:112-126)
 	                            [7..15] world->luminaire 3x3 [16..24] luminaire->world 3x3 (row major); the image and
 	                            its sampling density are the env_* arrays of the scene   (src/luminaires/envmap.cpp) */

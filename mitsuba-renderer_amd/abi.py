@@ -6,10 +6,10 @@ import ctypes as C
 import numpy as np
 
 ABI_VERSION = 2
-BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET, BSDF_MIRROR, BSDF_PHONG, BSDF_ROUGHGLASS = 0, 1, 2, 3, 4, 5, 6
+BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET, BSDF_MIRROR, BSDF_PHONG, BSDF_ROUGHGLASS, BSDF_DIFFTRANS = 0, 1, 2, 3, 4, 5, 6, 7
 BSDF_TWOSIDED = 0x100
 BSDF_NPARAMS = 16
-LUM_AREA, LUM_CONSTANT, LUM_POINT, LUM_DIRECTIONAL, LUM_SPOT, LUM_ENVMAP = 0, 1, 2, 3, 4, 5
+LUM_AREA, LUM_CONSTANT, LUM_POINT, LUM_DIRECTIONAL, LUM_SPOT, LUM_ENVMAP, LUM_COLLIMATED = 0, 1, 2, 3, 4, 5, 6
 LUM_NPARAMS = 32
 SAMPLER_INDEPENDENT_KEYED, SAMPLER_LD_KEYED, SAMPLER_HALTON, SAMPLER_HAMMERSLEY = 0, 1, 2, 3
 SHAPE_HAS_NORMALS = 1

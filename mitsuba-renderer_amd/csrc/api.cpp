@@ -433,7 +433,7 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 				if (!(sc->env_cdf[i] <= sc->env_cdf[i + 1]) || !(sc->env_pdf[i] >= 0.0f)) return fail(c, MTSGPU_EINVAL, "luminaire %u: the environment map's CDF is not monotone", l);
 			const float *LP = sc->lum_params + (size_t) MTSGPU_LUM_NPARAMS * l;
 			for (int i = 0; i < 25; ++i) if (!std::isfinite(LP[i])) return fail(c, MTSGPU_EINVAL, "luminaire %u: non-finite parameter", l);
-		} else if (sc->lum_type[l] > MTSGPU_LUM_ENVMAP) {
+		} else if (sc->lum_type[l] > MTSGPU_LUM_COLLIMATED) {
 			return fail(c, MTSGPU_EINVAL, "luminaire %u: unknown type", l);
 		}
 	}

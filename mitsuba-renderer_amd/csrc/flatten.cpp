@@ -236,7 +236,7 @@ void flattenScene(const mtsgpu_scene_desc &d, const mtsgpu_kd_params *kp, FlatSc
 				throw std::runtime_error("flatten: more than one background luminaire");
 			buildEnvMap(d, P, fs);
 			background = (int32_t) l;
-		} else if (fs.lumType[l] == MTSGPU_LUM_POINT) {
+		} else if (fs.lumType[l] == MTSGPU_LUM_POINT || fs.lumType[l] == MTSGPU_LUM_COLLIMATED) {
 			// nothing to derive (point.cpp:28-33)
 		} else if (fs.lumType[l] == MTSGPU_LUM_DIRECTIONAL) {
 			P[6] = radius;                          // DirectionalLuminaire::preprocess (directional.cpp:65-72)

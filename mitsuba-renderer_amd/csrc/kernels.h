@@ -5,7 +5,7 @@
 
 namespace mg {
 
-constexpr int kNumBsdfTypes = 7;      // lambertian, dielectric, roughmetal, microfacet, mirror, phong, roughglass
+constexpr int kNumBsdfTypes = 8;      // lambertian, dielectric, roughmetal, microfacet, mirror, phong, roughglass, difftrans
 constexpr int kNumBins = kNumBsdfTypes + 1;   // + "terminal" (miss / no BSDF)
 constexpr int kTraceBlock = 256;
 constexpr unsigned kTraceGridBlocks = 256 * 8;   // largest persistent traversal grid: 256 CUs x resident workgroups

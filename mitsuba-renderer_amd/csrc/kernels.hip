@@ -923,6 +923,21 @@ __device__ __forceinline__ bool sample_luminaire(const DScene &sc, V3 p, float s
 		} else {
 			lRec.pdf = 0.0f;
 		}
+	} else if (sc.lum_type[l] == 6u) {
+		// CollimatedBeamLuminaire::sample (src/luminaires/collimated.cpp:62-76)
+		const float *Wm = LP + 4, *Lm = LP + 16;
+		const V3 local(Wm[0] * p.x + Wm[1] * p.y + Wm[2] * p.z + Wm[3], Wm[4] * p.x + Wm[5] * p.y + Wm[6] * p.z + Wm[7],
+		               Wm[8] * p.x + Wm[9] * p.y + Wm[10] * p.z + Wm[11]);
+		if (sqrtf(local.x * local.x + local.y * local.y) > LP[3] || local.z < 0) {
+			lRec.pdf = 0.0f;
+		} else {
+			lRec.p = V3(Lm[0] * local.x + Lm[1] * local.y + Lm[2] * 0.0f + Lm[3], Lm[4] * local.x + Lm[5] * local.y + Lm[6] * 0.0f + Lm[7],
+			            Lm[8] * local.x + Lm[9] * local.y + Lm[10] * 0.0f + Lm[11]);
+			lRec.d = V3(Lm[0] * 0.0f + Lm[1] * 0.0f + Lm[2] * 1.0f, Lm[4] * 0.0f + Lm[5] * 0.0f + Lm[6] * 1.0f, Lm[8] * 0.0f + Lm[9] * 0.0f + Lm[10] * 1.0f);
+			lRec.n = V3(0, 0, 0);
+			lRec.pdf = 1.0f;
+			lRec.value = V3(LP[0], LP[1], LP[2]);
+		}
 	} else if (sc.lum_type[l] == 3u) {
 		// DirectionalLuminaire::sample (directional.cpp:84-91)
 		const V3 dir(LP[3], LP[4], LP[5]);
@@ -990,7 +1005,7 @@ __device__ __forceinline__ float pdf_luminaire(const DScene &sc, V3 p, int lum, 
 }
 
 // --- BSDF building blocks (roughmetal.cpp:75-117 == microfacet.cpp:95-136) ---
-enum : uint32_t { T_DIFFUSE_REFL = 0x1, T_DELTA_REFL = 0x4, T_DELTA_TRANS = 0x8, T_GLOSSY_REFL = 0x10, T_GLOSSY_TRANS = 0x20,
+enum : uint32_t { T_DIFFUSE_REFL = 0x1, T_DIFFUSE_TRANS = 0x2, T_DELTA_REFL = 0x4, T_DELTA_TRANS = 0x8, T_GLOSSY_REFL = 0x10, T_GLOSSY_TRANS = 0x20,
                   T_DELTA = 0xC, T_TRANSMISSION = 0x2A };
 
 __device__ __forceinline__ float frame_tan_theta(V3 v) {      // frame.h:98-103
@@ -1392,6 +1407,26 @@ template <> struct Bsdf<6> {
 		if (isZero(qv)) return V3(0, 0, 0);
 		pdfv = pdf(P, wi, wo);
 		return f(P, wi, wo);
+	}
+};
+
+// DiffuseTransmitter (src/bsdfs/difftrans.cpp:92-131)
+template <> struct Bsdf<7> {
+	static __device__ __forceinline__ V3 f(const float *P, V3 wi, V3 wo) {
+		if (wi.z * wo.z >= 0) return V3(0, 0, 0);
+		return V3(P[0] * kInvPi, P[1] * kInvPi, P[2] * kInvPi);
+	}
+	static __device__ __forceinline__ float pdf(const float *, V3 wi, V3 wo) {
+		if (wi.z * wo.z >= 0) return 0.0f;
+		return fabsf(wo.z) * kInvPi;
+	}
+	static __device__ __forceinline__ V3 sample(const float *P, V3 wi, float sx, float sy, V3 &wo, float &pdfv, uint32_t &st) {
+		wo = squareToHemispherePSA(sx, sy);
+		if (wi.z > 0) wo.z *= -1;
+		st = T_DIFFUSE_TRANS;
+		pdfv = fabsf(wo.z) * kInvPi;
+		if (wo.z == 0) return V3(0, 0, 0);
+		return V3(P[0] * kInvPi, P[1] * kInvPi, P[2] * kInvPi);
 	}
 };
 
@@ -1827,6 +1862,7 @@ void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, co
 		case 4: hipLaunchKernelGGL(k_shade<4>, g, b, 0, s, sc, ps, cfg, q, view); break;
 		case 5: hipLaunchKernelGGL(k_shade<5>, g, b, 0, s, sc, ps, cfg, q, view); break;
 		case 6: hipLaunchKernelGGL(k_shade<6>, g, b, 0, s, sc, ps, cfg, q, view); break;
+		case 7: hipLaunchKernelGGL(k_shade<7>, g, b, 0, s, sc, ps, cfg, q, view); break;
 		default: hipLaunchKernelGGL(k_shade<kNumBsdfTypes>, g, b, 0, s, sc, ps, cfg, q, view); break;
 	}
 }

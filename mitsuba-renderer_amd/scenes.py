@@ -90,6 +90,9 @@ class SceneDescription:
             a = F(2) / (a * a) - F(2)
         return self.add_bsdf(abi.BSDF_ROUGHGLASS, [d, a, int_ior, ext_ior, refl, refl, refl, trans, trans, trans])
 
+    def difftrans(self, t=0.5):
+        return self.add_bsdf(abi.BSDF_DIFFTRANS, [t, t, t])
+
     def twosided(self, bsdf):
         """wrap an existing BSDF block in the `twosided` adapter (src/bsdfs/twosided.cpp)"""
         self.bsdf_type[bsdf] |= abi.BSDF_TWOSIDED
@@ -120,6 +123,23 @@ class SceneDescription:
         P[8] = F(cutoff_deg) * (F(np.pi) / F(180.0))         # degToRad
         P[19] = F(beam) * (F(np.pi) / F(180.0))
         P[10:13] = right; P[13:16] = new_up; P[16:19] = d    # world -> luminaire rotation (rows)
+        return l
+
+    def collimated_beam(self, position, target, intensity, radius=0.01):
+        """<luminaire type="collimated"> with toWorld = lookAt(position, target) (src/luminaires/collimated.cpp)"""
+        l = self.add_lum(abi.LUM_COLLIMATED, [intensity] * 3 if np.isscalar(intensity) else intensity)
+        P = self.lum_params[l]
+        pos, tgt = np.asarray(position, dtype=np.float32), np.asarray(target, dtype=np.float32)
+        d = tgt - pos; d = d / np.sqrt((d * d).sum(), dtype=np.float32)
+        up = np.array([0, 0, 1], dtype=np.float32) if abs(d[2]) < 0.9 else np.array([1, 0, 0], dtype=np.float32)
+        right = np.cross(d, up).astype(np.float32); right /= np.sqrt((right * right).sum(), dtype=np.float32)
+        new_up = np.cross(right, d).astype(np.float32)
+        R = np.stack([right, new_up, d], axis=1).astype(np.float32)          # luminaire -> world (columns)
+        P[3] = radius
+        L2W = np.concatenate([R, pos.reshape(3, 1)], axis=1).astype(np.float32)
+        Rt = R.T.astype(np.float32)
+        W2L = np.concatenate([Rt, (-(Rt @ pos)).reshape(3, 1)], axis=1).astype(np.float32)
+        P[4:16] = W2L.ravel(); P[16:28] = L2W.ravel()
         return l
 
     def envmap(self, bitmap, intensity_scale=1.0, to_world=None):
@@ -358,6 +378,10 @@ def next_rows(sphere_subdiv=2):
     for m, c in zip(mats, centres):
         pos, tri = icosphere(sphere_subdiv, 0.3, c)
         sd.add_mesh(pos, tri, bsdf=m, face_normals=False, name="sphere")
+    # a diffusely transmitting sheet in front of the back wall and a collimated beam onto the floor
+    pos, tri = _quad((-0.6, 0.9, -0.7), (1.2, 0, 0), (0, 0.7, 0), (0, 0, 1))
+    sd.add_mesh(pos, tri, bsdf=sd.difftrans(0.6), face_normals=True, name="sheet")
+    sd.collimated_beam((0.1, 1.9, 0.1), (0.1, 0.0, 0.1), 6.0, radius=0.15)
     sd.point_light((0.0, 1.2, 0.6), 0.6)
     sd.spot_light((-0.8, 1.8, 0.8), (0.4, 0.0, -0.3), 25.0, cutoff_deg=25.0)
     sd.directional_light((0.3, -1.0, -0.4), 0.4)

@@ -654,6 +654,21 @@ static void luminaire_sample(const mtsgpu_scene *sc, int l, const float p[3], lr
 		} else {
 			lRec->pdf = 0.0f;
 		}
+	} else if (sc->lum_type[l] == MTSGPU_LUM_COLLIMATED) {
+		/* CollimatedBeamLuminaire::sample (src/luminaires/collimated.cpp:62-76) */
+		const float *W = P + 4, *L = P + 16;
+		const float local[3] = { W[0]*p[0] + W[1]*p[1] + W[2]*p[2] + W[3], W[4]*p[0] + W[5]*p[1] + W[6]*p[2] + W[7],
+		                         W[8]*p[0] + W[9]*p[1] + W[10]*p[2] + W[11] };
+		if (sqrtf(local[0]*local[0] + local[1]*local[1]) > P[3] || local[2] < 0) {
+			lRec->pdf = 0.0f;
+		} else {
+			for (int i = 0; i < 3; ++i) lRec->p[i] = L[4*i] * local[0] + L[4*i+1] * local[1] + L[4*i+2] * 0.0f + L[4*i+3];
+			/* m_direction = m_luminaireToWorld(Vector(0, 0, 1)) (collimated.cpp:36) */
+			for (int i = 0; i < 3; ++i) lRec->d[i] = L[4*i] * 0.0f + L[4*i+1] * 0.0f + L[4*i+2] * 1.0f;
+			lRec->n[0] = lRec->n[1] = lRec->n[2] = 0.0f;
+			lRec->pdf = 1.0f;
+			lRec->value[0] = P[0]; lRec->value[1] = P[1]; lRec->value[2] = P[2];
+		}
 	} else if (sc->lum_type[l] == MTSGPU_LUM_DIRECTIONAL) {
 		/* DirectionalLuminaire::sample (directional.cpp:84-91) */
 		const float k = 2 * P[6];
@@ -764,7 +779,7 @@ static void area_le(const mtsgpu_scene *sc, int l, const float n[3], const float
 /* ========================================================================== */
 /* BSDFs (local shading frame)                                                */
 /* ========================================================================== */
-enum { T_DIFFUSE_REFL = 0x1, T_DELTA_REFL = 0x4, T_DELTA_TRANS = 0x8, T_GLOSSY_REFL = 0x10, T_GLOSSY_TRANS = 0x20,
+enum { T_DIFFUSE_REFL = 0x1, T_DIFFUSE_TRANS = 0x2, T_DELTA_REFL = 0x4, T_DELTA_TRANS = 0x8, T_GLOSSY_REFL = 0x10, T_GLOSSY_TRANS = 0x20,
        T_DELTA = 0x4 | 0x8, T_TRANSMISSION = 0x2 | 0x8 | 0x20 };
 
 static inline int spec_is_zero(const float s[3]) { return !(s[0] != 0.0f) && !(s[1] != 0.0f) && !(s[2] != 0.0f); }
@@ -1175,6 +1190,10 @@ static void bsdf_f_base(uint32_t type, const float *P, const float wi[3], const 
 		case MTSGPU_BSDF_MICROFACET: microfacet_f(P, wi, wo, out); break;
 		case MTSGPU_BSDF_PHONG: phong_f(P, wi, wo, out); break;
 		case MTSGPU_BSDF_ROUGHGLASS: roughglass_f(P, wi, wo, out); break;
+		case MTSGPU_BSDF_DIFFTRANS:          /* difftrans.cpp:92-98 */
+			if (wi[2]*wo[2] >= 0) { out[0] = out[1] = out[2] = 0.0f; }
+			else { out[0] = P[0] * ORC_INV_PI; out[1] = P[1] * ORC_INV_PI; out[2] = P[2] * ORC_INV_PI; }
+			break;
 		default: out[0] = out[1] = out[2] = 0.0f; break;   /* dielectric.cpp:101-103, mirror.cpp:60-62 */
 	}
 }
@@ -1186,6 +1205,7 @@ static float bsdf_pdf_base(uint32_t type, const float *P, const float wi[3], con
 		case MTSGPU_BSDF_MICROFACET: return microfacet_pdf(P, wi, wo);
 		case MTSGPU_BSDF_PHONG: return phong_pdf(P, wi, wo);
 		case MTSGPU_BSDF_ROUGHGLASS: return roughglass_pdf(P, wi, wo);
+		case MTSGPU_BSDF_DIFFTRANS: return (wi[2]*wo[2] >= 0) ? 0.0f : fabsf(wo[2]) * ORC_INV_PI;     /* difftrans.cpp:100-104 */
 		default: return 0.0f;                              /* dielectric.cpp:105-107, mirror.cpp:64-66 */
 	}
 }
@@ -1315,6 +1335,18 @@ static void bsdf_sample_base(uint32_t type, const float *P, const float wi[3], c
 			return;
 		*pdf = roughglass_pdf(P, wi, wo);
 		roughglass_f(P, wi, wo, out);
+		return;
+	}
+	case MTSGPU_BSDF_DIFFTRANS: {
+		/* difftrans.cpp:119-131 */
+		orc_square_to_hemisphere_psa(s, wo);
+		if (wi[2] > 0)
+			wo[2] *= -1;
+		*stype = T_DIFFUSE_TRANS;
+		*pdf = fabsf(wo[2]) * ORC_INV_PI;
+		if (wo[2] == 0)
+			return;
+		out[0] = P[0] * ORC_INV_PI; out[1] = P[1] * ORC_INV_PI; out[2] = P[2] * ORC_INV_PI;
 		return;
 	}
 	default: return;
