@@ -176,6 +176,9 @@ typedef struct mtsgpu_camera {
 	int32_t width, height;      /* film size == crop size                                     */
 	float aperture_radius;      /* thin lens (perspective.cpp:90-103); 0 = pinhole            */
 	float focus_depth;          /* camera.cpp:164                                             */
+	int32_t kind;               /* 0 = perspective (src/cameras/perspective.cpp), 1 = orthographic
+	                               (src/cameras/orthographic.cpp:104-118: origin = rasterToCamera(sample), d = +z,
+	                               mint = 0, maxt = far - near; no lens sample)               */
 } mtsgpu_camera;
 
 /* Per-kernel-class counters/timings of the last render (measurement, section 8d) */
@@ -319,6 +322,10 @@ int  mtsgpu_tabulate_filter(int kind, float half_size, float p0, float p1, float
  * transform.cpp:100-124,174-190).  fov in degrees along the smaller image side. */
 int  mtsgpu_make_camera(const float origin[3], const float target[3], const float up[3],
                         float fov_deg, int width, int height, mtsgpu_camera *out);
+/* OrthographicCamera::configure (orthographic.cpp:46-82, transform.cpp:155-158) with toWorld =
+ * lookAt(origin, target, up) * scale(scale_x, scale_y, 1): the view volume is 2*scale wide along its smaller side. */
+int  mtsgpu_make_camera_ortho(const float origin[3], const float target[3], const float up[3],
+                              float scale_x, float scale_y, int width, int height, mtsgpu_camera *out);
 
 #ifdef __cplusplus
 }

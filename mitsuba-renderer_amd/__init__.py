@@ -27,7 +27,7 @@ EXPORTS = [
     "mtsgpu_set_tiles", "mtsgpu_set_rfilter", "mtsgpu_set_film_edges", "mtsgpu_tabulate_filter", "mtsgpu_set_film_buffer", "mtsgpu_set_options", "mtsgpu_render", "mtsgpu_sync",
     "mtsgpu_read_film", "mtsgpu_clear_film", "mtsgpu_get_stats", "mtsgpu_trace_rays", "mtsgpu_ld_tables",
     "mtsgpu_li_samples", "mtsgpu_flatten", "mtsgpu_flat_scene_get", "mtsgpu_flat_scene_free",
-    "mtsgpu_flat_scene_kdstats", "mtsgpu_make_camera", "mtsgpu_load_serialized", "mtsgpu_loaded_mesh_free",
+    "mtsgpu_flat_scene_kdstats", "mtsgpu_make_camera", "mtsgpu_make_camera_ortho", "mtsgpu_load_serialized", "mtsgpu_loaded_mesh_free",
 ]
 
 
@@ -101,6 +101,7 @@ def lib():
     L.mtsgpu_flat_scene_free.argtypes = [vp]; L.mtsgpu_flat_scene_free.restype = None
     L.mtsgpu_flat_scene_kdstats.argtypes = [vp, C.POINTER(C.c_double)]
     L.mtsgpu_make_camera.argtypes = [f32p, f32p, f32p, C.c_float, C.c_int, C.c_int, C.POINTER(abi.Camera)]
+    L.mtsgpu_make_camera_ortho.argtypes = [f32p, f32p, f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(abi.Camera)]
     L.mtsgpu_load_serialized.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(abi.Mesh)]
     L.mtsgpu_loaded_mesh_free.argtypes = [vp]; L.mtsgpu_loaded_mesh_free.restype = None
     _lib = L
@@ -160,6 +161,8 @@ class PerspectiveCamera:
     @classmethod
     def for_description(cls, desc, width, height):
         c = desc.camera
+        if "ortho_scale" in c:
+            return OrthographicCamera(c["origin"], c["target"], c["up"], c["ortho_scale"], width, height)
         return cls(c["origin"], c["target"], c["up"], c["fov"], width, height,
                    apertureRadius=c.get("aperture", 0.0), focusDepth=c.get("focus"))
 
@@ -170,6 +173,18 @@ class PerspectiveCamera:
     @property
     def height(self):
         return self.c.height
+
+
+class OrthographicCamera(PerspectiveCamera):
+    """`orthographic` camera plugin (src/cameras/orthographic.cpp): toWorld = lookAt * scale(sx, sy, 1)"""
+
+    def __init__(self, origin, target, up, scale, width, height):
+        self.c = abi.Camera()
+        sx, sy = (scale, scale) if np.isscalar(scale) else scale
+        rc = lib().mtsgpu_make_camera_ortho(abi.ptr(_f(origin), abi.f32p), abi.ptr(_f(target), abi.f32p), abi.ptr(_f(up), abi.f32p),
+                                            C.c_float(sx), C.c_float(sy), int(width), int(height), C.byref(self.c))
+        if rc != 0:
+            raise MtsGpuError("mtsgpu_make_camera_ortho: %s" % lib().mtsgpu_last_error(None).decode())
 
 
 class MIPathTracer:

@@ -47,7 +47,7 @@ class Camera(C.Structure):
         ("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
         ("near_clip", C.c_float), ("far_clip", C.c_float),
         ("width", C.c_int32), ("height", C.c_int32),
-        ("aperture_radius", C.c_float), ("focus_depth", C.c_float),
+        ("aperture_radius", C.c_float), ("focus_depth", C.c_float), ("kind", C.c_int32),
     ]
 
 

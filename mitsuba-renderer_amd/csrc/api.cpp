@@ -150,7 +150,7 @@ DConfig makeConfig(const mtsgpu_ctx *c, bool slotPerPath) {
 	std::memcpy(cfg.r2c, c->cam.raster_to_camera, sizeof(cfg.r2c));
 	std::memcpy(cfg.c2w, c->cam.camera_to_world, sizeof(cfg.c2w));
 	cfg.near_clip = c->cam.near_clip; cfg.far_clip = c->cam.far_clip;
-	cfg.aperture_radius = c->cam.aperture_radius; cfg.focus_depth = c->cam.focus_depth;
+	cfg.aperture_radius = c->cam.aperture_radius; cfg.focus_depth = c->cam.focus_depth; cfg.camera_kind = c->cam.kind;
 	cfg.width = c->cam.width; cfg.height = c->cam.height;
 	cfg.pix_w = c->cam.width; cfg.pix_off = 0;
 	cfg.max_depth = c->maxDepth; cfg.rr_depth = c->rrDepth; cfg.strict_normals = c->strictNormals;
@@ -580,6 +580,7 @@ int mtsgpu_set_camera(mtsgpu_ctx *c, const mtsgpu_camera *cam) {
 	if (!c || !cam) return fail(c, MTSGPU_EINVAL, "null argument");
 	if (cam->width <= 0 || cam->height <= 0 || (uint64_t) cam->width * (uint64_t) cam->height > 0x7FFFFFFFull)
 		return fail(c, MTSGPU_EINVAL, "bad film size %dx%d", cam->width, cam->height);
+	if (cam->kind != 0 && cam->kind != 1) return fail(c, MTSGPU_EINVAL, "unknown camera kind %d", cam->kind);
 	c->cam = *cam; c->haveCamera = true;
 	return 0;
 }
@@ -960,6 +961,14 @@ int mtsgpu_make_camera(const float origin[3], const float target[3], const float
                        float fov_deg, int width, int height, mtsgpu_camera *out) {
 	if (!origin || !target || !up || !out || width <= 0 || height <= 0) return fail(nullptr, MTSGPU_EINVAL, "bad camera arguments");
 	makeCamera(origin, target, up, fov_deg, width, height, *out);
+	return 0;
+}
+
+int mtsgpu_make_camera_ortho(const float origin[3], const float target[3], const float up[3],
+                             float scale_x, float scale_y, int width, int height, mtsgpu_camera *out) {
+	if (!origin || !target || !up || !out || width <= 0 || height <= 0 || !(scale_x > 0) || !(scale_y > 0))
+		return fail(nullptr, MTSGPU_EINVAL, "bad camera arguments");
+	makeCameraOrtho(origin, target, up, scale_x, scale_y, width, height, *out);
 	return 0;
 }
 

@@ -592,6 +592,35 @@ void makeCamera(const float origin[3], const float target[3], const float up[3],
 	out.near_clip = nearClip; out.far_clip = farClip;
 	out.width = width; out.height = height;
 	out.aperture_radius = 0.0f; out.focus_depth = farClip;     // camera.cpp:164-166 defaults
+	out.kind = 0;
+}
+
+// OrthographicCamera::configure (src/cameras/orthographic.cpp:46-82) with toWorld = lookAt * scale(sx, sy, 1)
+void makeCameraOrtho(const float origin[3], const float target[3], const float up[3], float scaleX, float scaleY,
+                     int width, int height, mtsgpu_camera &out) {
+	const V3 p = ld3(origin);
+	const V3 dir = normalize(ld3(target) - p);
+	const V3 right = normalize(cross(dir, ld3(up)));
+	const V3 newUp = cross(right, dir);
+	Xf lookAt;
+	lookAt.fwd = M4{ { { right.x, newUp.x, dir.x, p.x }, { right.y, newUp.y, dir.y, p.y }, { right.z, newUp.z, dir.z, p.z }, { 0, 0, 0, 1 } } };
+	invert(lookAt.fwd, lookAt.inv);
+	const Xf cameraToWorld = lookAt * scale(scaleX, scaleY, 1.0f);
+	const float nearClip = 1e-2f, farClip = 1e4f;
+	const float aspect = (float) width / (float) height;
+	Xf screenToRaster;
+	if (aspect >= 1.0f)
+		screenToRaster = scale((float) width, (float) height, 1.0f) * scale(1 / (2 * aspect), -0.5f, 1.0f) * translate(aspect, -1.0f, 0);
+	else
+		screenToRaster = scale((float) width, (float) height, 1.0f) * scale(0.5f, -0.5f * aspect, 1.0f) * translate(1.0f, -1 / aspect, 0);
+	const Xf cameraToScreen = scale(1.0f, 1.0f, 1.0f / (farClip - nearClip)) * translate(0.0f, 0.0f, -nearClip);   // transform.cpp:155-158
+	const Xf rasterToCamera = inverse(cameraToScreen) * inverse(screenToRaster);
+	std::memcpy(out.raster_to_camera, rasterToCamera.fwd.m, sizeof(float) * 16);
+	std::memcpy(out.camera_to_world, cameraToWorld.fwd.m, sizeof(float) * 16);
+	out.near_clip = nearClip; out.far_clip = farClip;
+	out.width = width; out.height = height;
+	out.aperture_radius = 0.0f; out.focus_depth = farClip;
+	out.kind = 1;
 }
 
 } // namespace mg

@@ -43,5 +43,7 @@ void loadSerializedMesh(const char *path, int index, LoadedMesh &out);   // thro
 void tabulateFilter(int kind, float halfSize, float p0, float p1, float *sizeXY, float *values);
 void makeCamera(const float origin[3], const float target[3], const float up[3], float fovDeg, int width, int height,
                 mtsgpu_camera &out);
+void makeCameraOrtho(const float origin[3], const float target[3], const float up[3], float scaleX, float scaleY,
+                     int width, int height, mtsgpu_camera &out);
 
 } // namespace mg

@@ -85,6 +85,7 @@ struct DConfig {
 	float r2c[16], c2w[16];       // rasterToCamera, cameraToWorld (row major)
 	float near_clip, far_clip;
 	float aperture_radius, focus_depth;   // thin lens (perspective.cpp:90-103); 0 = pinhole
+	int32_t camera_kind;                  // 0 perspective, 1 orthographic (orthographic.cpp:104-118)
 	int32_t width, height;
 	int32_t pix_w, pix_off;            // rendered rectangle: pixel ids index a pix_w-wide grid whose origin is (pix_off, pix_off)
 	int32_t max_depth, rr_depth, strict_normals;

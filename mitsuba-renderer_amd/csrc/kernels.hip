@@ -162,7 +162,7 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 	smp.stream = keyedInit(cfg.seed, pixel, 1 + (uint64_t) j);
 	smp.slot = slot; smp.j = j; smp.d1 = 0; smp.d2 = 0;
 	float sx, sy, lensX = 0, lensY = 0;
-	if (cfg.aperture_radius > 0.0f) sampler_next2d(cfg, smp, lensX, lensY);     // needsLensSample (integrator.cpp:156-157)
+	if (cfg.aperture_radius > 0.0f && cfg.camera_kind == 0) sampler_next2d(cfg, smp, lensX, lensY);     // needsLensSample (integrator.cpp:156-157)
 	sampler_next2d(cfg, smp, sx, sy);
 	sx += (float) px; sy += (float) py;
 
@@ -175,8 +175,11 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 	V3 ic(ix, iy, iz);
 	if (iw != 1.0f)
 		ic = divs(ic, iw);
+	const bool ortho = cfg.camera_kind == 1;
 	V3 lo(0.0f, 0.0f, 0.0f);
-	if (cfg.aperture_radius > 0.0f) {
+	if (ortho)
+		lo = ic;                                   // OrthographicCamera::generateRay (orthographic.cpp:104-118)
+	else if (cfg.aperture_radius > 0.0f) {
 		// perspective.cpp:90-103: sample the aperture, aim at the focal plane
 		float lpx, lpy;
 		squareToDiskConcentric(lensX, lensY, lpx, lpy);
@@ -187,9 +190,10 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 		lo.y += lpy;
 		ic = itsFocal - lo;
 	}
-	V3 ld = normalize(ic);
+	V3 ld = ortho ? V3(0.0f, 0.0f, 1.0f) : normalize(ic);
 	float invZ = 1.0f / ld.z;
 	float mint = cfg.near_clip * invZ, maxt = cfg.far_clip * invZ;
+	if (ortho) { mint = 0; maxt = cfg.far_clip - cfg.near_clip; }
 	// m_cameraToWorld(localRay, ray) (transform.h:219-235)
 	const float *w = cfg.c2w;
 	V3 o(w[0] * lo.x + w[1] * lo.y + w[2] * lo.z + w[3],

@@ -98,6 +98,8 @@ void orc_flat_scene_free(orc_flat_scene *fs);
 int  orc_flat_scene_kdstats(const orc_flat_scene *fs, double *out6);
 int  orc_make_camera(const float origin[3], const float target[3], const float up[3],
                      float fov_deg, int width, int height, mtsgpu_camera *out);
+int orc_make_camera_ortho(const float origin[3], const float target[3], const float up[3],
+                          float scale_x, float scale_y, int width, int height, mtsgpu_camera *out);
 
 /* ---------------- traversal (skdtree.cpp:108-199, sahkdtree3.h:170-300) ---- */
 typedef struct orc_trace_counts { uint64_t n_inner, n_leaf, n_idx, n_tri_tested; } orc_trace_counts;

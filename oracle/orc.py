@@ -87,6 +87,7 @@ def lib():
     L.orc_flat_scene_free.argtypes = [C.c_void_p]
     L.orc_flat_scene_kdstats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.orc_make_camera.argtypes = [f32p, f32p, f32p, C.c_float, C.c_int, C.c_int, C.POINTER(abi.Camera)]
+    L.orc_make_camera_ortho.argtypes = [f32p, f32p, f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(abi.Camera)]
     L.orc_trace_rays.argtypes = [C.POINTER(abi.Scene), f32p, C.c_uint32, C.c_int, u32p, C.POINTER(TraceCounts)]
     L.orc_render_rect.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(RenderParams),
                                   C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(abi.Stats)]
@@ -144,6 +145,11 @@ class FlatScene:
 def make_camera(desc, width, height):
     cam = abi.Camera()
     c = desc.camera
+    if "ortho_scale" in c:                       # <camera type="orthographic"> with toWorld = lookAt * scale
+        sx, sy = c["ortho_scale"]
+        lib().orc_make_camera_ortho(abi.ptr(_f(c["origin"]), abi.f32p), abi.ptr(_f(c["target"]), abi.f32p),
+                                    abi.ptr(_f(c["up"]), abi.f32p), C.c_float(sx), C.c_float(sy), width, height, C.byref(cam))
+        return cam
     lib().orc_make_camera(abi.ptr(_f(c["origin"]), abi.f32p), abi.ptr(_f(c["target"]), abi.f32p),
                           abi.ptr(_f(c["up"]), abi.f32p), C.c_float(c["fov"]), width, height, C.byref(cam))
     if c.get("aperture", 0.0) > 0:

@@ -1453,6 +1453,21 @@ static void camera_generate_ray(const mtsgpu_camera *cam, const float dirSample[
 	float wv = m[3][0] * px + m[3][1] * py + m[3][2] * pz + m[3][3];
 	if (wv != 1.0f)
 		v3_div(ic, ic, wv);
+	if (cam->kind == 1) {
+		/* OrthographicCamera::generateRay (src/cameras/orthographic.cpp:104-118) */
+		const float ldir[3] = { 0, 0, 1 };
+		float o[3], d[3];
+		for (int i = 0; i < 3; ++i) {
+			o[i] = w[i][0] * ic[0] + w[i][1] * ic[1] + w[i][2] * ic[2] + w[i][3];
+			d[i] = w[i][0] * ldir[0] + w[i][1] * ldir[1] + w[i][2] * ldir[2];
+		}
+		float wo_ = w[3][0] * ic[0] + w[3][1] * ic[1] + w[3][2] * ic[2] + w[3][3];
+		if (wo_ != 1.0f)
+			v3_div(o, o, wo_);
+		ray_init(ray, o, d);
+		ray->mint = 0; ray->maxt = cam->far_clip - cam->near_clip;
+		return;
+	}
 	float lo[3] = { 0, 0, 0 };
 	if (cam->aperture_radius > 0.0f) {
 		/* perspective.cpp:90-103: sample the aperture, aim at the focal plane */
@@ -1868,7 +1883,7 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 					smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 					smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm;
 					float sample[2], lens[2] = { 0, 0 };
-					if (cam->aperture_radius > 0.0f) sampler_next2d(&smp, lens);     /* needsLensSample (integrator.cpp:156-157) */
+					if (cam->aperture_radius > 0.0f && cam->kind == 0) sampler_next2d(&smp, lens);     /* needsLensSample (integrator.cpp:156-157) */
 					sampler_next2d(&smp, sample);
 					sample[0] += x; sample[1] += y;
 					ray_t eyeRay;
@@ -1909,7 +1924,7 @@ void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_
 		smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 		smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm;
 		float sample[2], lens[2] = { 0, 0 };
-		if (cam->aperture_radius > 0.0f) sampler_next2d(&smp, lens);
+		if (cam->aperture_radius > 0.0f && cam->kind == 0) sampler_next2d(&smp, lens);
 		sampler_next2d(&smp, sample);
 		sample[0] += x; sample[1] += y;
 		ray_t eyeRay;
@@ -1946,7 +1961,7 @@ void orc_render_rect_mt(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const 
 				smp.mt = &rnd;
 				smp.depth = depth; smp.spp = spp; smp.index = j; smp.t1d = t1d; smp.t2d = t2d;
 				float sample[2], lens[2] = { 0, 0 };
-				if (cam->aperture_radius > 0.0f) sampler_next2d(&smp, lens);
+				if (cam->aperture_radius > 0.0f && cam->kind == 0) sampler_next2d(&smp, lens);
 				sampler_next2d(&smp, sample);
 				sample[0] += x; sample[1] += y;
 				ray_t eyeRay;
@@ -2093,7 +2108,7 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 					s.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 					s.depth = depth; s.spp = spp; s.index = j; s.scr = scr; s.perm = perm;
 					float sample[2], lens[2] = { 0, 0 };
-					if (cam->aperture_radius > 0.0f) sampler_next2d(&s, lens);
+					if (cam->aperture_radius > 0.0f && cam->kind == 0) sampler_next2d(&s, lens);
 					sampler_next2d(&s, sample);
 					sample[0] += x0 + px; sample[1] += y0 + py;
 					ray_t eyeRay;

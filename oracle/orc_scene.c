@@ -583,5 +583,53 @@ int orc_make_camera(const float origin[3], const float target[3], const float up
 	out->near_clip = nearClip; out->far_clip = farClip;
 	out->width = width; out->height = height;
 	out->aperture_radius = 0.0f; out->focus_depth = farClip;    /* camera.cpp:164-166 defaults */
+	out->kind = 0;
+	return 0;
+}
+
+/* OrthographicCamera::configure (src/cameras/orthographic.cpp:46-82) with toWorld = lookAt * scale(sx, sy, 1) */
+int orc_make_camera_ortho(const float origin[3], const float target[3], const float up[3],
+                          float scale_x, float scale_y, int width, int height, mtsgpu_camera *out) {
+	float dirct[3], right[3], newUp[3], t[3];
+	v3_sub(t, target, origin); v3_normalize(dirct, t);
+	v3_cross(t, dirct, up); v3_normalize(right, t);
+	v3_cross(newUp, right, dirct);
+	float look[4][4] = {
+		{ right[0], newUp[0], dirct[0], origin[0] },
+		{ right[1], newUp[1], dirct[1], origin[1] },
+		{ right[2], newUp[2], dirct[2], origin[2] },
+		{ 0, 0, 0, 1 } };
+	xform_t lookAt, sc, cameraToWorld;
+	xf_from_matrix(&lookAt, look);
+	xf_scale(&sc, scale_x, scale_y, 1.0f);
+	xf_mul(&cameraToWorld, &lookAt, &sc);
+	const float nearClip = 1e-2f, farClip = 1e4f;
+	float aspect = (float) width / (float) height;
+	xform_t s1, s2, tr, screenToRaster, tmp;
+	if (aspect >= 1.0f) {                        /* mapSmallerSide = true -> mapYToNDC01 (orthographic.cpp:57-59) */
+		xf_scale(&s1, (float) width, (float) height, 1.0f);
+		xf_scale(&s2, 1/(2*aspect), -0.5f, 1.0f);
+		xf_translate(&tr, aspect, -1.0f, 0);
+	} else {
+		xf_scale(&s1, (float) width, (float) height, 1.0f);
+		xf_scale(&s2, 0.5f, -0.5f * aspect, 1.0f);
+		xf_translate(&tr, 1.0f, -1 / aspect, 0);
+	}
+	xf_mul(&tmp, &s1, &s2);
+	xf_mul(&screenToRaster, &tmp, &tr);
+	/* Transform::orthographic (transform.cpp:155-158) */
+	xform_t osc, otr, cameraToScreen, a, b, rasterToCamera;
+	xf_scale(&osc, 1.0f, 1.0f, 1.0f / (farClip - nearClip));
+	xf_translate(&otr, 0.0f, 0.0f, -nearClip);
+	xf_mul(&cameraToScreen, &osc, &otr);
+	xf_inverse(&a, &cameraToScreen);
+	xf_inverse(&b, &screenToRaster);
+	xf_mul(&rasterToCamera, &a, &b);
+	memcpy(out->raster_to_camera, rasterToCamera.m, sizeof(float) * 16);
+	memcpy(out->camera_to_world, cameraToWorld.m, sizeof(float) * 16);
+	out->near_clip = nearClip; out->far_clip = farClip;
+	out->width = width; out->height = height;
+	out->aperture_radius = 0.0f; out->focus_depth = farClip;
+	out->kind = 1;
 	return 0;
 }

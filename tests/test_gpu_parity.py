@@ -177,6 +177,23 @@ def test_cancel_and_error_paths(gpu_lib, mts, orc):
         fresh.render()                                  # no scene uploaded
 
 
+def test_orthographic_camera(gpu_lib, mts, orc):
+    """`orthographic` camera plugin (src/cameras/orthographic.cpp:104-118): parallel rays, mint = 0, maxt = far - near"""
+    sd = mts.scenes.cornell_c5(sphere_subdiv=2)
+    sd.camera = dict(origin=(0.1, 1.0, 3.4), target=(0.0, 0.9, 0.0), up=(0.0, 1.0, 0.0), ortho_scale=(0.95, 0.95))
+    scene = mts.Scene(sd); oscene = orc.FlatScene(sd)
+    cam = mts.PerspectiveCamera.for_description(sd, 44, 36); ocam = orc.make_camera(sd, 44, 36)
+    assert cam.c.kind == 1 and bytes(cam.c) == bytes(ocam)
+    it = mts.MIPathTracer(maxDepth=6)
+    it.preprocess(scene, cam, sampler="ldsampler", sampleCount=16, seed=5)
+    assert it.render()
+    op = orc.render_params(6, sampler=mts.abi.SAMPLER_LD_KEYED, spp=16, seed=5)
+    ofilm, _ = orc.render(oscene.scene, ocam, op)
+    assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32)) and ofilm[..., :3].max() > 0
+    ps = np.array([[x, y, j] for x in (0, 21, 43) for y in (0, 17, 35) for j in (0, 7)], dtype=np.uint32)
+    assert np.array_equal(it.li_samples(ps).view(np.uint32), orc.li_samples(oscene.scene, ocam, op, ps).view(np.uint32))
+
+
 def test_bunny_benchmark_rays(gpu_lib, mts, orc):
     """the reference's own traversal benchmark (src/tests/test_kd.cpp:85-130): chords of the test's sphere through the
     kd-tree of data/tests/bunny.ply (tests/golden/bunny.ply), rays drawn exactly as the test draws them"""

@@ -98,6 +98,16 @@ def test_camera_matches_oracle(mts, orc):
     m = np.array(list(mts.PerspectiveCamera.for_description(sd, 256, 256).c.raster_to_camera)).reshape(4, 4)
     p = m @ np.array([128, 128, 0, 1.0]); p = p[:3] / p[3]
     assert abs(p[0]) < 1e-6 and abs(p[1]) < 1e-6
+    # orthographic camera (src/cameras/orthographic.cpp): both hosts agree; raster corners map to +-scale
+    sd.camera = dict(origin=(0.0, 1.0, 3.4), target=(0.0, 1.0, 0.0), up=(0.0, 1.0, 0.0), ortho_scale=(1.1, 1.1))
+    for (w, h) in ((256, 256), (320, 200), (200, 320)):
+        a = mts.PerspectiveCamera.for_description(sd, w, h).c
+        b = orc.make_camera(sd, w, h)
+        assert bytes(a) == bytes(b) and a.kind == 1
+    c = mts.PerspectiveCamera.for_description(sd, 256, 256).c
+    r2c = np.array(list(c.raster_to_camera)).reshape(4, 4); c2w = np.array(list(c.camera_to_world)).reshape(4, 4)
+    q = c2w @ (r2c @ np.array([0, 0, 0, 1.0]))
+    assert abs(abs(q[0]) - 1.1) < 1e-5 and abs(abs(q[1] - 1.0) - 1.1) < 1e-5
 
 
 def test_flatten_rejects_bad_input(mts):
