@@ -476,5 +476,23 @@ def matpreview(serialized_path, loader, material="roughglass"):
     return sd
 
 
+def bunny(serialized_path, loader, material="roughglass"):
+    """The Stanford bunny of the reference's kd-tree test (data/tests/bunny.ply) read back from a `.serialized`
+    container through `loader(path, index)`, on a ground plane under the synthetic environment map"""
+    sd = SceneDescription("bunny")
+    mat = {"roughglass": lambda: sd.roughglass(0.1, 1.5046, 1.0, "beckmann"), "roughmetal": lambda: sd.roughmetal(0.1),
+           "lambertian": lambda: sd.lambertian(0.6)}[material]()
+    mesh = loader(serialized_path, 0)
+    mesh.bsdf = mat
+    mesh.face_normals = False
+    ground = loader(serialized_path, 1)
+    ground.bsdf = sd.lambertian(0.4)
+    sd.meshes += [mesh, ground]
+    sd.envmap(env_bitmap(), 0.6)
+    sd.camera = dict(origin=(-0.05, 0.2, 0.35), target=(-0.02, 0.1, 0.0), up=(0.0, 1.0, 0.0), fov=35.0)
+    sd.max_depth = 8
+    return sd
+
+
 def by_name(name, **kw):
     return {"c1": cornell_c1, "c3": cornell_c3, "c5": cornell_c5, "next": next_rows, "spheres": spheres, "envlit": envlit}[name](**kw)

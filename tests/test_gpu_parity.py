@@ -15,10 +15,22 @@ SCENES = {
     "next_rows": lambda s: s.next_rows(sphere_subdiv=2),
     "spheres": lambda s: s.spheres(),
     "envlit": lambda s: s.envlit(),
-    # the reference's own material-preview meshes (data/blender/mitsuba/matpreview/matpreview.serialized), read by
-    # the product's loader of the `.serialized` container
-    "matpreview": lambda s: s.matpreview(os.path.join(os.path.dirname(__file__), "golden", "matpreview.serialized"), _loader()),
+    # the bunny of the reference's kd-tree test, written to a `.serialized` container (double precision, two shapes)
+    # by the independent Python writer and read back by the product's loader
+    "bunny": lambda s: s.bunny(_bunny_serialized(), _loader()),
 }
+
+
+def _bunny_serialized():
+    import tempfile
+    import ply_io
+    import serialized_io as sio
+    path = os.path.join(tempfile.gettempdir(), "mtsgpu_test_bunny.serialized")
+    pos, tri = ply_io.read(os.path.join(os.path.dirname(__file__), "golden", "bunny.ply"))
+    plane = dict(positions=np.array([[-1, 0.033, -1], [1, 0.033, -1], [1, 0.033, 1], [-1, 0.033, 1]], dtype=np.float64),
+                 triangles=np.array([[0, 2, 1], [0, 3, 2]]), face_normals=True)
+    sio.write(path, [dict(positions=pos.astype(np.float64), triangles=tri), plane], double=True)
+    return path
 
 
 def _loader():
@@ -77,7 +89,7 @@ def test_ld_tables_bit_exact(gpu_lib, mts, orc):
                                           ("spheres", "independent"), ("spheres", "ldsampler"),
                                           ("envlit", "independent"), ("envlit", "ldsampler"),
                                           ("c5_small", "halton"), ("c5_small", "hammersley"), ("spheres", "halton"),
-                                          ("matpreview", "ldsampler")])
+                                          ("bunny", "ldsampler")])
 def test_li_samples_bit_exact(gpu_lib, mts, orc, name, sampler):
     """MIPathTracer::Li per camera sample: radiance, alpha, raster position and path depth"""
     sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, name, W=32, H=32, sampler=sampler, spp=16)
@@ -93,7 +105,7 @@ def test_li_samples_bit_exact(gpu_lib, mts, orc, name, sampler):
 @pytest.mark.parametrize("name,sampler,spp", [("c1", "independent", 16), ("c1", "ldsampler", 32), ("c3_small", "ldsampler", 16),
                                               ("c5_small", "ldsampler", 16), ("next_rows", "ldsampler", 16),
                                               ("spheres", "ldsampler", 16), ("envlit", "ldsampler", 16),
-                                              ("c5_small", "halton", 24), ("c5_small", "hammersley", 24), ("matpreview", "ldsampler", 8)])
+                                              ("c5_small", "halton", 24), ("c5_small", "hammersley", 24), ("bunny", "ldsampler", 8)])
 def test_film_matches_oracle(gpu_lib, mts, orc, name, sampler, spp):
     """whole renderBlock + putSample pipeline; tolerance stated by north_star: pixel RMSE < 1e-5
     (the target is bit-identical, which is what is asserted first and reported)"""
