@@ -90,7 +90,11 @@ enum {
 	 * evaluation order inside Point2(nextValue(), nextValue()) (halton.cpp:88) is left to the compiler by the
 	 * reference; x first is used here. */
 	MTSGPU_SAMPLER_HALTON = 2,
-	MTSGPU_SAMPLER_HAMMERSLEY = 3
+	MTSGPU_SAMPLER_HAMMERSLEY = 3,
+	/* src/samplers/stratified.cpp, keyed like the LD sampler: generate() shuffles the per-depth stratum
+	 * permutations with the (seed, pixel, 0) stream, the jitter comes from the per-sample stream; sampleCount is
+	 * rounded up to a perfect square (stratified.cpp:36-44) */
+	MTSGPU_SAMPLER_STRATIFIED_KEYED = 4
 };
 
 /* shape_flags bits */

@@ -223,7 +223,7 @@ class MIPathTracer:
         self.camera = camera
         self._chk(lib().mtsgpu_set_camera(self._ctx, C.byref(camera.c if hasattr(camera, "c") else camera)), "set_camera")
         kind = {"independent": abi.SAMPLER_INDEPENDENT_KEYED, "ldsampler": abi.SAMPLER_LD_KEYED, "halton": abi.SAMPLER_HALTON,
-                "hammersley": abi.SAMPLER_HAMMERSLEY}[sampler] if isinstance(sampler, str) else int(sampler)
+                "hammersley": abi.SAMPLER_HAMMERSLEY, "stratified": abi.SAMPLER_STRATIFIED_KEYED}[sampler] if isinstance(sampler, str) else int(sampler)
         self._chk(lib().mtsgpu_set_sampler(self._ctx, kind, int(sampleCount), int(depth), int(seed)), "set_sampler")
         return True
 

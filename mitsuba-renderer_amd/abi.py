@@ -11,7 +11,7 @@ BSDF_TWOSIDED = 0x100
 BSDF_NPARAMS = 16
 LUM_AREA, LUM_CONSTANT, LUM_POINT, LUM_DIRECTIONAL, LUM_SPOT, LUM_ENVMAP, LUM_COLLIMATED = 0, 1, 2, 3, 4, 5, 6
 LUM_NPARAMS = 32
-SAMPLER_INDEPENDENT_KEYED, SAMPLER_LD_KEYED, SAMPLER_HALTON, SAMPLER_HAMMERSLEY = 0, 1, 2, 3
+SAMPLER_INDEPENDENT_KEYED, SAMPLER_LD_KEYED, SAMPLER_HALTON, SAMPLER_HAMMERSLEY, SAMPLER_STRATIFIED_KEYED = 0, 1, 2, 3, 4
 SHAPE_HAS_NORMALS = 1
 SHAPE_TRIMESH, SHAPE_SPHERE = 0, 1
 SHAPE_NPARAMS = 24

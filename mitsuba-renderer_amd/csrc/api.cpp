@@ -99,8 +99,17 @@ void freeAll(std::vector<void *> &v) { for (void *p : v) (void) hipFree(p); v.cl
 
 uint32_t roundToPow2(uint32_t v) { uint32_t r = 1; while (r < v) r <<= 1; return r; }
 
+uint32_t squareAtLeast(uint32_t v) { uint32_t i = 1; while ((uint64_t) i * i < v) ++i; return i * i; }
+
 uint32_t effectiveSpp(const mtsgpu_ctx *c) {
-	return c->samplerKind == MTSGPU_SAMPLER_LD_KEYED ? roundToPow2(c->spp) : c->spp;   // ldsampler.cpp:52-57
+	if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED) return roundToPow2(c->spp);                 // ldsampler.cpp:52-57
+	if (c->samplerKind == MTSGPU_SAMPLER_STRATIFIED_KEYED) return squareAtLeast(c->spp);       // stratified.cpp:36-44
+	return c->spp;
+}
+
+// the samplers whose generate() fills per-pixel tables (permutations, scrambles)
+bool samplerHasTables(const mtsgpu_ctx *c) {
+	return c->samplerKind == MTSGPU_SAMPLER_LD_KEYED || c->samplerKind == MTSGPU_SAMPLER_STRATIFIED_KEYED;
 }
 
 int ensurePaths(mtsgpu_ctx *c, size_t cap) {
@@ -161,6 +170,7 @@ DConfig makeConfig(const mtsgpu_ctx *c, bool slotPerPath) {
 	cfg.frac_lum = c->nLumSamples / (float) (c->nLumSamples + c->nBsdfSamples);
 	cfg.sampler_kind = c->samplerKind;
 	cfg.spp = effectiveSpp(c); cfg.ld_depth = c->ldDepth; cfg.seed = c->seed;
+	cfg.strat_res = 1; while ((uint32_t) cfg.strat_res * (uint32_t) cfg.strat_res < cfg.spp) ++cfg.strat_res;
 	cfg.slot_per_path = slotPerPath ? 1 : 0;
 	cfg.ld_scr = c->ldScr; cfg.ld_perm = c->ldPerm; cfg.primes = c->primes;
 	cfg.filt_size_x = c->filtSizeX; cfg.filt_size_y = c->filtSizeY; cfg.filt_border = c->filtBorder; cfg.filt_values = c->filtValues;
@@ -605,10 +615,12 @@ int mtsgpu_set_direct_integrator(mtsgpu_ctx *c, int luminaire_samples, int bsdf_
 
 int mtsgpu_set_sampler(mtsgpu_ctx *c, int kind, uint32_t spp, int ld_depth, uint64_t seed) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
-	if (kind < MTSGPU_SAMPLER_INDEPENDENT_KEYED || kind > MTSGPU_SAMPLER_HAMMERSLEY) return fail(c, MTSGPU_EINVAL, "unknown sampler kind %d", kind);
+	if (kind < MTSGPU_SAMPLER_INDEPENDENT_KEYED || kind > MTSGPU_SAMPLER_STRATIFIED_KEYED) return fail(c, MTSGPU_EINVAL, "unknown sampler kind %d", kind);
 	if (spp == 0) return fail(c, MTSGPU_EINVAL, "sampleCount must be > 0");
 	if (kind == MTSGPU_SAMPLER_LD_KEYED && (roundToPow2(spp) > 65536u || ld_depth < 1 || ld_depth > 64))
 		return fail(c, MTSGPU_EINVAL, "ldsampler: sampleCount <= 65536 and 1 <= depth <= 64 required");
+	if (kind == MTSGPU_SAMPLER_STRATIFIED_KEYED && (spp > 65536u || squareAtLeast(spp) > 65536u || ld_depth < 1 || ld_depth > 64))
+		return fail(c, MTSGPU_EINVAL, "stratified: sampleCount <= 65536 and 1 <= depth <= 64 required");
 	c->samplerKind = kind; c->spp = spp; c->ldDepth = ld_depth > 0 ? ld_depth : 3; c->seed = seed;
 	return 0;
 }
@@ -744,7 +756,7 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	if (wideFilter) slotsPerPass = std::max<size_t>(slotsPerPass, (size_t) bs * bs);     // passes hold whole tiles
 	if ((uint64_t) slotsPerPass * spp > 0x7FFFFFFFull) return fail(c, MTSGPU_EINVAL, "pass too large");
 	rc = ensurePaths(c, slotsPerPass * spp); if (rc) return rc;
-	if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED) {
+	if (samplerHasTables(c)) {
 		rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, slotsPerPass * 3 * c->ldDepth); if (rc) return rc;
 		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, slotsPerPass * 2 * c->ldDepth * spp); if (rc) return rc;
 	}
@@ -777,7 +789,7 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 			nSlots = (uint32_t) std::min(slotsPerPass, pixels.size() - base);
 		}
 		const uint32_t nPaths = nSlots * spp;
-		if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED)
+		if (samplerHasTables(c))
 			launch_ld_tables(c->stream, cfg, c->pixelList + base, nSlots, c->ldScr, c->ldPerm);
 		launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList + base, nSlots, nullptr, nPaths, c->queueA);
 		HIPCHK(c, hipGetLastError());
@@ -905,12 +917,12 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, n); if (rc) return rc;
 	HIPCHK(c, hipMemcpyAsync(c->explicitSamples, pix_samples, 3 * (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipMemcpyAsync(c->pixelList, keys.data(), (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-	if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED) {
+	if (samplerHasTables(c)) {
 		rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, (size_t) n * 3 * c->ldDepth); if (rc) return rc;
 		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, (size_t) n * 2 * c->ldDepth * spp); if (rc) return rc;
 	}
 	const DConfig cfg = makeConfig(c, true);
-	if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED)
+	if (samplerHasTables(c))
 		launch_ld_tables(c->stream, cfg, c->pixelList, n, c->ldScr, c->ldPerm);
 	launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList, n, c->explicitSamples, n, c->queueA);
 	HIPCHK(c, hipGetLastError());

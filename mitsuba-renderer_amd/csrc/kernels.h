@@ -94,6 +94,7 @@ struct DConfig {
 	float frac_lum, frac_bsdf, weight_lum, weight_bsdf;
 	int32_t sampler_kind;
 	uint32_t spp; int32_t ld_depth;
+	int32_t strat_res;            // StratifiedSampler::m_resolution (spp = strat_res^2)
 	uint64_t seed;
 	int32_t slot_per_path;        // 1: one sampler slot per path (explicit sample lists)
 	// TabulatedFilter (rfilter.h:65-102); border = ceil(max(size) - 0.5) (renderproc.cpp:143-144)

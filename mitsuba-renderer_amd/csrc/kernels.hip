@@ -56,13 +56,14 @@ __global__ void k_ld_tables(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_
 		return;
 	const uint32_t spp = cfg.spp;
 	const int depth = cfg.ld_depth;
+	const bool ld = cfg.sampler_kind == 1;     // 4: StratifiedSampler::generate (stratified.cpp:121-141), permutations only
 	uint64_t st = keyedInit(cfg.seed, pixel_keys[slot], 0);
 	uint32_t *s = scr + (size_t) slot * 3 * depth;
 	uint16_t *pbase = perm + (size_t) slot * 2 * depth * spp;
 	for (int i = 0; i < depth; ++i) {
 		// generate1D
 		uint16_t *p = pbase + (size_t) (2 * i) * spp;
-		s[i * 3 + 0] = (uint32_t) (keyedNext(st) & 0xFFFFFFFFull);
+		if (ld) s[i * 3 + 0] = (uint32_t) (keyedNext(st) & 0xFFFFFFFFull);     // the stratified sampler draws no scrambles
 		for (uint32_t k = 0; k < spp; ++k) p[k] = (uint16_t) k;
 		for (uint32_t it = spp - 1; it > 0; --it) {
 			uint32_t other = (uint32_t) keyedNextSize(st, it);
@@ -71,9 +72,11 @@ __global__ void k_ld_tables(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_
 		}
 		// generate2D: one 64-bit draw, dword[0] = low half, dword[1] = high half
 		p = pbase + (size_t) (2 * i + 1) * spp;
-		uint64_t q = keyedNext(st);
-		s[i * 3 + 1] = (uint32_t) (q & 0xFFFFFFFFull);
-		s[i * 3 + 2] = (uint32_t) (q >> 32);
+		if (ld) {
+			uint64_t q = keyedNext(st);
+			s[i * 3 + 1] = (uint32_t) (q & 0xFFFFFFFFull);
+			s[i * 3 + 2] = (uint32_t) (q >> 32);
+		}
 		for (uint32_t k = 0; k < spp; ++k) p[k] = (uint16_t) k;
 		for (uint32_t it = spp - 1; it > 0; --it) {
 			uint32_t other = (uint32_t) keyedNextSize(st, it);
@@ -107,6 +110,15 @@ __device__ __forceinline__ float qmc_next_value(const DConfig &cfg, PathSampler 
 }
 
 __device__ __forceinline__ float sampler_next1d(const DConfig &cfg, PathSampler &s) {
+	if (cfg.sampler_kind == 4) {
+		// StratifiedSampler::next1D (stratified.cpp:155-163)
+		if ((int) s.d1 < cfg.ld_depth) {
+			const int i = (int) s.d1++;
+			const int k = (int) cfg.ld_perm[((size_t) s.slot * 2 * cfg.ld_depth + 2 * i) * cfg.spp + s.j];
+			return (k + ulongToFloat(keyedNext(s.stream))) * (1 / (float) cfg.spp);
+		}
+		return ulongToFloat(keyedNext(s.stream));
+	}
 	if (cfg.sampler_kind >= 2)
 		return qmc_next_value(cfg, s);
 	if (cfg.sampler_kind == 1 && (int) s.d1 < cfg.ld_depth) {
@@ -118,6 +130,21 @@ __device__ __forceinline__ float sampler_next1d(const DConfig &cfg, PathSampler 
 }
 
 __device__ __forceinline__ void sampler_next2d(const DConfig &cfg, PathSampler &s, float &x, float &y) {
+	if (cfg.sampler_kind == 4) {
+		// StratifiedSampler::next2D (stratified.cpp:165-181); x is drawn first
+		if ((int) s.d2 < cfg.ld_depth) {
+			const int i = (int) s.d2++;
+			const int k = (int) cfg.ld_perm[((size_t) s.slot * 2 * cfg.ld_depth + 2 * i + 1) * cfg.spp + s.j];
+			const int kx = k % cfg.strat_res, ky = k / cfg.strat_res;
+			const float invResolution = 1 / (float) cfg.strat_res;
+			const float jx = ulongToFloat(keyedNext(s.stream)), jy = ulongToFloat(keyedNext(s.stream));
+			x = (kx + jx) * invResolution; y = (ky + jy) * invResolution;
+			return;
+		}
+		x = ulongToFloat(keyedNext(s.stream));
+		y = ulongToFloat(keyedNext(s.stream));
+		return;
+	}
 	if (cfg.sampler_kind >= 2) {
 		x = qmc_next_value(cfg, s);
 		y = qmc_next_value(cfg, s);

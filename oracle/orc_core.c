@@ -226,6 +226,19 @@ void orc_ld_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t sp
 	}
 }
 
+/* StratifiedSampler::generate (src/samplers/stratified.cpp:121-141) with the keyed stream: the stratum permutations
+ * [depth][2][spp] (1D, 2D) */
+void orc_strat_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth, uint32_t *perm) {
+	uint64_t st = orc_keyed_init(seed, pixel_key, 0);
+	for (int i = 0; i < depth; ++i) {
+		uint32_t *p1 = perm + ((size_t) i * 2 + 0) * spp, *p2 = perm + ((size_t) i * 2 + 1) * spp;
+		for (uint32_t k = 0; k < spp; ++k) p1[k] = k;
+		keyed_shuffle_u32(&st, p1, spp);
+		for (uint32_t k = 0; k < spp; ++k) p2[k] = k;
+		keyed_shuffle_u32(&st, p2, spp);
+	}
+}
+
 void orc_ld_generate_keyed(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth,
                            float *out1d, float *out2d) {
 	uint32_t *scr = (uint32_t *) malloc(sizeof(uint32_t) * 3 * (size_t) depth);

@@ -54,6 +54,7 @@ float    orc_ulong_to_float(uint64_t v);
 uint64_t orc_size_bitmask(uint64_t n);
 void     orc_ld_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth,
                                       uint32_t *scr, uint32_t *perm);
+void     orc_strat_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth, uint32_t *perm);
 
 /* kd-tree builder (orc_kdtree.c) */
 typedef struct orc_kdtree {

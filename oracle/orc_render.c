@@ -1357,7 +1357,8 @@ static void bsdf_sample_base(uint32_t type, const float *P, const float wi[3], c
 /* Samplers                                                                   */
 /* ========================================================================== */
 typedef struct {
-	int kind;            /* 0 keyed independent, 1 keyed LD, 2 MT independent, 3 MT LD, 4 halton, 5 hammersley */
+	int kind;            /* 0 keyed independent, 1 keyed LD, 2 MT independent, 3 MT LD, 4 halton, 5 hammersley, 6 keyed stratified */
+	int resolution;      /* StratifiedSampler::m_resolution */
 	int qdepth;          /* m_sampleDepth of the QMC samplers */
 	uint64_t stream;     /* keyed overflow / independent stream */
 	orc_random *mt;
@@ -1402,6 +1403,14 @@ static float sampler_next_float(sampler_t *s) {
 
 /* next1D (independent.cpp:72-74, ldsampler.cpp:172-178) */
 static float sampler_next1d(sampler_t *s) {
+	if (s->kind == 6) {
+		/* StratifiedSampler::next1D (stratified.cpp:155-163) */
+		if (s->d1 < s->depth) {
+			int k = (int) s->perm[((size_t) (s->d1++) * 2 + 0) * s->spp + s->index];
+			return (k + sampler_next_float(s)) * (1 / (float) s->spp);
+		}
+		return sampler_next_float(s);
+	}
 	if (s->kind >= 4)
 		return qmc_next_value(s);
 	if ((s->kind == 1 || s->kind == 3) && s->d1 < s->depth) {
@@ -1416,6 +1425,20 @@ static float sampler_next1d(sampler_t *s) {
  * ldsampler.cpp:185 leaves the evaluation order of its two nextFloat() calls to
  * the compiler; x-then-y is used here, as independent.cpp enforces. */
 static void sampler_next2d(sampler_t *s, float out[2]) {
+	if (s->kind == 6) {
+		/* StratifiedSampler::next2D (stratified.cpp:165-181); x is drawn first */
+		if (s->d2 < s->depth) {
+			int k = (int) s->perm[((size_t) (s->d2++) * 2 + 1) * s->spp + s->index];
+			int x = k % s->resolution, y = k / s->resolution;
+			const float invResolution = 1 / (float) s->resolution;
+			float jx = sampler_next_float(s), jy = sampler_next_float(s);
+			out[0] = (x + jx) * invResolution; out[1] = (y + jy) * invResolution;
+			return;
+		}
+		float v1 = sampler_next_float(s), v2 = sampler_next_float(s);
+		out[0] = v1; out[1] = v2;
+		return;
+	}
 	if (s->kind >= 4) {
 		out[0] = qmc_next_value(s);
 		out[1] = qmc_next_value(s);
@@ -1837,11 +1860,20 @@ static int put_sample(float *film, int W, int H, const tabfilter_t *filter, floa
 /* ========================================================================== */
 static uint32_t round_to_pow2(uint32_t v) { uint32_t r = 1; while (r < v) r <<= 1; return r; }
 
+/* Sampler::generate() of the two table-based samplers */
+static void sampler_generate_tables(const orc_render_params *prm, uint32_t pixelKey, uint32_t spp, int depth, uint32_t *scr, uint32_t *perm) {
+	if (prm->sampler_kind == MTSGPU_SAMPLER_STRATIFIED_KEYED) orc_strat_generate_keyed_tables(prm->seed, pixelKey, spp, depth, perm);
+	else orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);
+}
+
+static int isqrt_u32(uint32_t v) { uint32_t i = 1; while (i * i < v) ++i; return (int) i; }
+
 static int sampler_kind_of(const orc_render_params *p) {
 	switch (p->sampler_kind) {
 		case MTSGPU_SAMPLER_LD_KEYED: return 1;
 		case MTSGPU_SAMPLER_HALTON: return 4;
 		case MTSGPU_SAMPLER_HAMMERSLEY: return 5;
+		case MTSGPU_SAMPLER_STRATIFIED_KEYED: return 6;
 		default: return 0;
 	}
 }
@@ -1849,6 +1881,11 @@ static int sampler_kind_of(const orc_render_params *p) {
 static uint32_t effective_spp(const orc_render_params *p) {
 	/* ldsampler.cpp:52-57: rounded up to a power of two */
 	if (p->sampler_kind == MTSGPU_SAMPLER_LD_KEYED) return round_to_pow2(p->spp);
+	if (p->sampler_kind == MTSGPU_SAMPLER_STRATIFIED_KEYED) {      /* stratified.cpp:36-44: the next perfect square */
+		uint32_t i = 1;
+		while (i * i < p->spp) ++i;
+		return i * i;
+	}
 	return p->spp;
 }
 
@@ -1858,7 +1895,7 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 	const uint32_t spp = effective_spp(prm);
 	const int W = cam->width, H = cam->height;
 	tabfilter_t filter; tabfilter_box(&filter);
-	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED;
+	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED || prm->sampler_kind == MTSGPU_SAMPLER_STRATIFIED_KEYED;     /* per-pixel tables */
 	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
 	uint64_t nClosest = 0, nShadow = 0;
 #ifdef _OPENMP
@@ -1876,12 +1913,12 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 			for (int x = x0; x < x1; ++x) {
 				const uint32_t pixelKey = (uint32_t) y * (uint32_t) W + (uint32_t) x;
 				if (isLD)
-					orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);   /* sampler->generate() */
+					sampler_generate_tables(prm, pixelKey, spp, depth, scr, perm);   /* sampler->generate() */
 				for (uint32_t j = 0; j < spp; ++j) {
 					sampler_t smp; memset(&smp, 0, sizeof(smp));
 					smp.kind = sampler_kind_of(prm);
 					smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
-					smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm;
+					smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm; smp.resolution = isqrt_u32(spp);
 					float sample[2], lens[2] = { 0, 0 };
 					if (cam->aperture_radius > 0.0f && cam->kind == 0) sampler_next2d(&smp, lens);     /* needsLensSample (integrator.cpp:156-157) */
 					sampler_next2d(&smp, sample);
@@ -1907,7 +1944,7 @@ void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_
                     const uint32_t *pix_samples, uint32_t n, float *out) {
 	(void) orc_prime(0);            /* fill the prime table before any thread needs it */
 	const uint32_t spp = effective_spp(prm);
-	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED;
+	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED || prm->sampler_kind == MTSGPU_SAMPLER_STRATIFIED_KEYED;     /* per-pixel tables */
 	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
 	uint32_t *scr = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 3 * (size_t) depth) : NULL;
 	uint32_t *perm = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 2 * (size_t) depth * spp) : NULL;
@@ -1916,13 +1953,13 @@ void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_
 		const uint32_t x = pix_samples[3*(size_t)i], y = pix_samples[3*(size_t)i+1], j = pix_samples[3*(size_t)i+2];
 		const uint32_t pixelKey = y * (uint32_t) cam->width + x;
 		if (isLD && pixelKey != lastKey) {
-			orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);
+			sampler_generate_tables(prm, pixelKey, spp, depth, scr, perm);
 			lastKey = pixelKey;
 		}
 		sampler_t smp; memset(&smp, 0, sizeof(smp));
 		smp.kind = sampler_kind_of(prm);
 		smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
-		smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm;
+		smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm; smp.resolution = isqrt_u32(spp);
 		float sample[2], lens[2] = { 0, 0 };
 		if (cam->aperture_radius > 0.0f && cam->kind == 0) sampler_next2d(&smp, lens);
 		sampler_next2d(&smp, sample);
@@ -2067,7 +2104,7 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 	(void) orc_prime(0);            /* fill the prime table before any thread needs it */
 	const uint32_t spp = effective_spp(prm);
 	const int W = cam->width, H = cam->height;
-	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED;
+	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED || prm->sampler_kind == MTSGPU_SAMPLER_STRATIFIED_KEYED;     /* per-pixel tables */
 	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
 	/* m_borderSize (renderproc.cpp:143-144) */
 	const int border = (int) ceilf(fmaxf_(filter->size_x, filter->size_y) - (float) 0.5);
@@ -2101,12 +2138,12 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 			for (int py = 0; py < h; ++py) for (int px = 0; px < w; ++px) {
 				/* sampler key = index of the pixel inside the rendered rectangle */
 				const uint32_t pixelKey = (uint32_t) (y0 + py - off) * (uint32_t) RW + (uint32_t) (x0 + px - off);
-				if (isLD) orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);
+				if (isLD) sampler_generate_tables(prm, pixelKey, spp, depth, scr, perm);
 				for (uint32_t j = 0; j < spp; ++j) {
 					sampler_t s; memset(&s, 0, sizeof(s));
 					s.kind = sampler_kind_of(prm);
 					s.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
-					s.depth = depth; s.spp = spp; s.index = j; s.scr = scr; s.perm = perm;
+					s.depth = depth; s.spp = spp; s.index = j; s.scr = scr; s.perm = perm; s.resolution = isqrt_u32(spp);
 					float sample[2], lens[2] = { 0, 0 };
 					if (cam->aperture_radius > 0.0f && cam->kind == 0) sampler_next2d(&s, lens);
 					sampler_next2d(&s, sample);

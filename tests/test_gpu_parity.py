@@ -48,7 +48,8 @@ def _setup(mts, orc, name, W=64, H=64, sampler="independent", spp=8, max_depth=N
     it = mts.MIPathTracer(maxDepth=md)
     it.preprocess(scene, cam, sampler=sampler, sampleCount=spp, seed=seed)
     kind = {"independent": mts.abi.SAMPLER_INDEPENDENT_KEYED, "ldsampler": mts.abi.SAMPLER_LD_KEYED,
-            "halton": mts.abi.SAMPLER_HALTON, "hammersley": mts.abi.SAMPLER_HAMMERSLEY}[sampler]
+            "halton": mts.abi.SAMPLER_HALTON, "hammersley": mts.abi.SAMPLER_HAMMERSLEY,
+            "stratified": mts.abi.SAMPLER_STRATIFIED_KEYED}[sampler]
     op = orc.render_params(md, sampler=kind, spp=spp, seed=seed)
     return sd, scene, oscene, cam, ocam, it, op
 
@@ -89,7 +90,7 @@ def test_ld_tables_bit_exact(gpu_lib, mts, orc):
                                           ("spheres", "independent"), ("spheres", "ldsampler"),
                                           ("envlit", "independent"), ("envlit", "ldsampler"),
                                           ("c5_small", "halton"), ("c5_small", "hammersley"), ("spheres", "halton"),
-                                          ("bunny", "ldsampler")])
+                                          ("bunny", "ldsampler"), ("c5_small", "stratified"), ("next_rows", "stratified")])
 def test_li_samples_bit_exact(gpu_lib, mts, orc, name, sampler):
     """MIPathTracer::Li per camera sample: radiance, alpha, raster position and path depth"""
     sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, name, W=32, H=32, sampler=sampler, spp=16)
@@ -105,7 +106,7 @@ def test_li_samples_bit_exact(gpu_lib, mts, orc, name, sampler):
 @pytest.mark.parametrize("name,sampler,spp", [("c1", "independent", 16), ("c1", "ldsampler", 32), ("c3_small", "ldsampler", 16),
                                               ("c5_small", "ldsampler", 16), ("next_rows", "ldsampler", 16),
                                               ("spheres", "ldsampler", 16), ("envlit", "ldsampler", 16),
-                                              ("c5_small", "halton", 24), ("c5_small", "hammersley", 24), ("bunny", "ldsampler", 8)])
+                                              ("c5_small", "halton", 24), ("c5_small", "hammersley", 24), ("bunny", "ldsampler", 8), ("c5_small", "stratified", 16)])
 def test_film_matches_oracle(gpu_lib, mts, orc, name, sampler, spp):
     """whole renderBlock + putSample pipeline; tolerance stated by north_star: pixel RMSE < 1e-5
     (the target is bit-identical, which is what is asserted first and reported)"""

@@ -442,6 +442,26 @@ def test_halton_and_hammersley_samplers(mts, orc):
         assert np.array_equal(film.view(np.uint32), film2.view(np.uint32))
 
 
+def test_stratified_sampler(mts, orc):
+    """src/samplers/stratified.cpp (keyed): sampleCount is rounded up to a perfect square and the first 2D sample of
+    the spp camera samples of a pixel visits every stratum of the res x res grid exactly once"""
+    sd = mts.scenes.cornell_c1()
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 8, 8)
+    prm = orc.render_params(4, sampler=mts.abi.SAMPLER_STRATIFIED_KEYED, spp=14, seed=5)       # -> 16 = 4 x 4
+    for (x, y) in ((0, 0), (3, 5), (7, 7)):
+        ps = np.array([[x, y, j] for j in range(16)], dtype=np.uint32)
+        out = orc.li_samples(fs.scene, cam, prm, ps)
+        off = out[:, 4:6] - ps[:, 0:2]
+        assert (off >= 0).all() and (off < 1).all()
+        cells = set((int(o[0] * 4), int(o[1] * 4)) for o in off)
+        assert len(cells) == 16
+    film, st = orc.render(fs.scene, cam, prm)
+    assert st.camera_samples == 8 * 8 * 16 and np.isfinite(film).all()
+    ref, _ = orc.render(fs.scene, cam, orc.render_params(4, sampler=mts.abi.SAMPLER_LD_KEYED, spp=64, seed=5))
+    assert abs(orc.develop(film).mean() / orc.develop(ref).mean() - 1) < 0.15
+
+
 def test_direct_integrator(mts, orc):
     """MIDirectIntegrator (direct.cpp): equals the path tracer truncated after one bounce in expectation; either
     strategy alone gives the same picture; background-only pixels return LeBackground"""
