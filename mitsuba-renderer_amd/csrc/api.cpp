@@ -856,6 +856,7 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 8 * sizeof(unsigned long long), c->stream));
 	hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
 	if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
+	HIPCHK(c, hipMemsetAsync(c->q.counters, 0, kNumCounters * kCounterStride * sizeof(uint32_t), c->stream));     // dynamic batch head
 	launch_trace(c->stream, shadow ? 2 : 0, c->countTraversal, false, c->dsc, c->paths, c->q, c->queueA, n, false);
 	if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
 	HIPCHK(c, hipGetLastError());

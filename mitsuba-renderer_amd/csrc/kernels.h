@@ -15,7 +15,7 @@ constexpr int kTriStride = 8;         // float4 per primitive record: one 128-by
 constexpr int kLumStride = 32;        // MTSGPU_LUM_NPARAMS
 constexpr int kCounterStride = 32;    // one 128-byte line per queue counter (atomics on one line serialise)
 constexpr int kBinShards = 16;        // the closest-hit kernel appends to bins[b] through 16 independent segments
-constexpr int kNumCounters = kNumBins * kBinShards + 2;   // bins x shards, next, shadow
+constexpr int kNumCounters = kNumBins * kBinShards + 4;   // bins x shards, next, shadow, dynamic heads of the two traversal launches
 constexpr int kShadeBlock = 512;
 
 // Scene in HBM (all pointers are device pointers); see DESIGN.md section 3
@@ -117,6 +117,7 @@ struct DQueues {
 	uint32_t spill_stride;
 	uint32_t desc_min;                 // k_trace leaves its descent loop when fewer lanes than this are on inner nodes (>= 1)
 	uint32_t leaf_min;                 // ... and its primitive loop when fewer lanes than this have leaf entries left (>= 1)
+	uint32_t static_n, dyn_slot;       // k_trace: statically dealt queue prefix; counter (line index) of the dynamic head
 	uint32_t refill_min;               // k_trace refills its idle lanes once this many are idle (1..64)
 };
 

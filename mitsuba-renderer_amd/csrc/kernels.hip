@@ -346,18 +346,17 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 	uint32_t w_inner = 0, w_leaf = 0, w_outer = 0, w_batch = 0;   // COUNT: lane slots issued per loop (64 per wave iteration)
 #define MG_WSLOT(w) do { if (COUNT && lane == (uint32_t) __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) (w) += 64u; } while (0)
 
-	// Each wave owns the batches (64 consecutive queue entries) wave_id, wave_id + n_waves, ... and walks
-	// them with a private cursor (no work-queue atomic).  A lane whose ray has finished stays idle until
-	// at least q.refill_min lanes of the wave are idle; then the finished rays are retired together (one
-	// hit store + one binning step) and the idle lanes take the next rays of the wave's own batches.
+	// Ray supply of a wave.  The first q.static_n queue entries are dealt out statically: the wave owns the batches
+	// (64 consecutive entries) wave_id, wave_id + n_waves, ... and walks them without any atomic.  The rest of the
+	// queue (about a quarter) is claimed batch by batch through ONE counter once the static share is used up, which
+	// evens out the finishing times of the waves (measured: the mean wave used to live 0.90-0.94 of the kernel).
+	// A lane whose ray has finished stays idle until at least q.refill_min lanes of the wave are idle; then the
+	// finished rays are retired together (one hit store + one binning step) and the idle lanes take new rays.
 	const uint32_t first = blockIdx.x * kTraceBlock + (tid & ~63u);
-	uint32_t total = 0;                     // rays owned by this wave (uniform)
-	if (first < n) {
-		const uint32_t nb = (n - first - 1u) / stride + 1u;
-		const uint32_t lastBase = first + (nb - 1u) * stride;
-		total = (nb - 1u) * 64u + (n - lastBase < 64u ? n - lastBase : 64u);
-	}
-	uint32_t cursor = 0;                    // next unowned ray of the wave (uniform)
+	const uint32_t static_n = q.static_n;   // whole rounds of the grid (or the whole queue of a small launch)
+	uint32_t next_static = first;           // queue index of this wave's next static batch (uniform)
+	uint32_t sup_base = 0, sup_left = 0;    // the chunk being handed out: queue[sup_base .. sup_base + sup_left)
+	bool dyn_done = static_n >= n;          // nothing (left) to claim dynamically
 	const uint32_t refill_min = q.refill_min, desc_min = q.desc_min, leaf_min = q.leaf_min;
 
 	uint32_t id = 0;
@@ -377,8 +376,22 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 	while (true) {
 		const uint64_t liveMask = __builtin_amdgcn_ballot_w64(has);
 		const uint32_t nlive = (uint32_t) __popcll(liveMask);
-		const uint32_t remaining = total - cursor;
-		if (nlive == 0u || (remaining != 0u && 64u - nlive >= refill_min)) {
+		const bool wantRays = nlive == 0u || 64u - nlive >= refill_min;
+		if (wantRays && sup_left == 0u) {
+			// next chunk: a batch of the static share, or one claimed from the shared tail of the queue
+			if (next_static < static_n) {
+				sup_base = next_static; sup_left = (static_n - next_static < 64u) ? static_n - next_static : 64u; next_static += stride;
+			} else if (!dyn_done) {
+				uint32_t b = 0;
+				if (lane == 0) b = atomicAdd(&q.counters[q.dyn_slot * kCounterStride], 1u);
+				b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
+				const unsigned long long base = (unsigned long long) static_n + 64ull * b;
+				if (base < n) { sup_base = (uint32_t) base; sup_left = (n - sup_base < 64u) ? n - sup_base : 64u; }
+				else dyn_done = true;
+			}
+		}
+		const uint32_t remaining = sup_left;
+		if (nlive == 0u || (remaining != 0u && wantRays)) {
 			// ---- retire the finished rays (all lanes take part in the ballots) ----
 			if (MODE == 0) {
 				int bin = -1;
@@ -426,14 +439,14 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 			if (remaining == 0u)
 				break;          // nlive == 0 and nothing left: the wave is finished
 
-			// ---- refill: idle lane number r takes ray cursor + r ----
+			// ---- refill: idle lane number r takes ray r of the current chunk ----
 			const uint32_t r = (uint32_t) __popcll(~liveMask & ((1ull << lane) - 1ull));
-			const uint32_t j = cursor + r;
-			const bool take = !has && j < total;
-			cursor += (64u - nlive < remaining) ? 64u - nlive : remaining;
+			const bool take = !has && r < remaining;
+			const uint32_t taken = (64u - nlive < remaining) ? 64u - nlive : remaining;
+			const uint32_t my = sup_base + r;
+			sup_base += taken; sup_left -= taken;
 			MG_WSLOT(w_batch);
 			if (take) {
-				const uint32_t my = first + (j >> 6) * stride + (j & 63u);
 				id = queue[my];
 				float4 a, b;
 				float rmint, rmaxt;
@@ -1858,6 +1871,15 @@ static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, co
 	// persistent grid: enough workgroups to fill every CU, never more than there are rays
 	const unsigned blocks = std::min<unsigned>(blocks_for(n, kTraceBlock), 256u * trace_blocks_per_cu(MODE));
 	DQueues qq = q;
+	// static share of the queue: whole rounds of the grid; the last quarter of the rounds and the remainder are
+	// claimed dynamically (one atomic per 64-ray batch, far below the ~88 / us a single counter sustains)
+	const unsigned long long perRound = (unsigned long long) blocks * kTraceBlock;
+	const unsigned long long rounds = n / perRound;
+	static const int dynDiv = getenv("MTSGPU_DYNDIV") ? std::max(1, atoi(getenv("MTSGPU_DYNDIV"))) : 4;
+	// small launches stay fully static: their waves finish together and would hit the counter in one burst
+	const unsigned long long dynRounds = rounds >= 8 ? std::max<unsigned long long>(1, rounds / dynDiv) : 0;
+	qq.static_n = rounds >= 8 ? (uint32_t) ((rounds - dynRounds) * perRound) : n;
+	qq.dyn_slot = (uint32_t) (kNumBins * kBinShards + 2 + (MODE == 0 ? 0 : 1));
 	// the early loop exits trade the latency of a few straggling rays for throughput; with only a few
 	// batches per wave the stragglers are the critical path, so small launches run the plain loops
 	if (n < 8u * kTraceGridBlocks * kTraceBlock || coherent)
