@@ -86,6 +86,48 @@ __global__ void k_ld_tables(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_
 	}
 }
 
+// The same tables with the permutations shuffled in LDS ([entry][lane], row stride 65 halfwords) and written out
+// in coalesced 128-byte rows: the serial chain of a shuffle is ~2 dependent memory accesses per step, which LDS
+// serves an order of magnitude faster than the L2.  One wave per workgroup; used while spp * 65 * 2 B fits in 64 KB.
+__global__ __launch_bounds__(64) void k_ld_tables_lds(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_slots,
+                                                      uint32_t *scr, uint16_t *perm) {
+	extern __shared__ uint16_t s_p[];
+	const uint32_t lane = threadIdx.x, slot0 = blockIdx.x * 64u, slot = slot0 + lane;
+	const bool active = slot < n_slots;
+	const uint32_t spp = cfg.spp;
+	const int depth = cfg.ld_depth;
+	const bool ld = cfg.sampler_kind == 1;
+	uint64_t st = active ? keyedInit(cfg.seed, pixel_keys[slot], 0) : 0ull;
+	uint32_t *s = scr + (size_t) slot * 3 * depth;
+	for (int arr = 0; arr < 2 * depth; ++arr) {
+		if (active) {
+			const int i = arr >> 1;
+			if (ld) {
+				if ((arr & 1) == 0) {
+					s[i * 3 + 0] = (uint32_t) (keyedNext(st) & 0xFFFFFFFFull);
+				} else {
+					const uint64_t q = keyedNext(st);
+					s[i * 3 + 1] = (uint32_t) (q & 0xFFFFFFFFull);
+					s[i * 3 + 2] = (uint32_t) (q >> 32);
+				}
+			}
+			for (uint32_t k = 0; k < spp; ++k) s_p[k * 65u + lane] = (uint16_t) k;
+			for (uint32_t it = spp - 1; it > 0; --it) {
+				const uint32_t other = (uint32_t) keyedNextSize(st, it);
+				const uint16_t a = s_p[it * 65u + lane], b = s_p[other * 65u + lane];
+				s_p[it * 65u + lane] = b; s_p[other * 65u + lane] = a;
+			}
+		}
+		__syncthreads();
+		const uint32_t rows = (n_slots - slot0 < 64u) ? n_slots - slot0 : 64u;
+		for (uint32_t r = 0; r < rows; ++r) {
+			uint16_t *dst = perm + ((size_t) (slot0 + r) * 2 * depth + arr) * spp;
+			for (uint32_t k = lane; k < spp; k += 64u) dst[k] = s_p[k * 65u + r];
+		}
+		__syncthreads();
+	}
+}
+
 // ===========================================================================
 // Sampler::next1D / next2D (independent.cpp:72-81, ldsampler.cpp:172-186)
 // ===========================================================================
@@ -1856,7 +1898,12 @@ void launch_iota(hipStream_t s, uint32_t *p, uint32_t n) {
 
 void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_keys, uint32_t n_slots,
                       uint32_t *scr, uint16_t *perm) {
-	if (n_slots) hipLaunchKernelGGL(k_ld_tables, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, cfg, pixel_keys, n_slots, scr, perm);
+	if (!n_slots) return;
+	const size_t lds = (size_t) cfg.spp * 65 * sizeof(uint16_t);
+	if (lds <= 64 * 1024 - 256)
+		hipLaunchKernelGGL(k_ld_tables_lds, dim3(blocks_for(n_slots, 64)), dim3(64), lds, s, cfg, pixel_keys, n_slots, scr, perm);
+	else
+		hipLaunchKernelGGL(k_ld_tables, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, cfg, pixel_keys, n_slots, scr, perm);
 }
 
 void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg,
