@@ -86,9 +86,10 @@ __global__ void k_ld_tables(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_
 	}
 }
 
-// The same tables with the permutations shuffled in LDS ([entry][lane], row stride 65 halfwords) and written out
+// The same tables with the permutations shuffled in LDS ([entry][lane ^ entry]: the XOR swizzle keeps both the
+// per-lane shuffle accesses and the transposed write-out free of bank conflicts without padding) and written out
 // in coalesced 128-byte rows: the serial chain of a shuffle is ~2 dependent memory accesses per step, which LDS
-// serves an order of magnitude faster than the L2.  One wave per workgroup; used while spp * 65 * 2 B fits in 64 KB.
+// serves an order of magnitude faster than the L2.  One wave per workgroup; used while spp * 128 B fits in 64 KB.
 __global__ __launch_bounds__(64) void k_ld_tables_lds(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_slots,
                                                       uint32_t *scr, uint16_t *perm) {
 	extern __shared__ uint16_t s_p[];
@@ -111,18 +112,19 @@ __global__ __launch_bounds__(64) void k_ld_tables_lds(DConfig cfg, const uint32_
 					s[i * 3 + 2] = (uint32_t) (q >> 32);
 				}
 			}
-			for (uint32_t k = 0; k < spp; ++k) s_p[k * 65u + lane] = (uint16_t) k;
+			for (uint32_t k = 0; k < spp; ++k) s_p[k * 64u + (lane ^ (k & 63u))] = (uint16_t) k;
 			for (uint32_t it = spp - 1; it > 0; --it) {
 				const uint32_t other = (uint32_t) keyedNextSize(st, it);
-				const uint16_t a = s_p[it * 65u + lane], b = s_p[other * 65u + lane];
-				s_p[it * 65u + lane] = b; s_p[other * 65u + lane] = a;
+				const uint32_t ia = it * 64u + (lane ^ (it & 63u)), ib = other * 64u + (lane ^ (other & 63u));
+				const uint16_t a = s_p[ia], b = s_p[ib];
+				s_p[ia] = b; s_p[ib] = a;
 			}
 		}
 		__syncthreads();
 		const uint32_t rows = (n_slots - slot0 < 64u) ? n_slots - slot0 : 64u;
 		for (uint32_t r = 0; r < rows; ++r) {
 			uint16_t *dst = perm + ((size_t) (slot0 + r) * 2 * depth + arr) * spp;
-			for (uint32_t k = lane; k < spp; k += 64u) dst[k] = s_p[k * 65u + r];
+			for (uint32_t k = lane; k < spp; k += 64u) dst[k] = s_p[k * 64u + (r ^ (k & 63u))];
 		}
 		__syncthreads();
 	}
@@ -1899,8 +1901,8 @@ void launch_iota(hipStream_t s, uint32_t *p, uint32_t n) {
 void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_keys, uint32_t n_slots,
                       uint32_t *scr, uint16_t *perm) {
 	if (!n_slots) return;
-	const size_t lds = (size_t) cfg.spp * 65 * sizeof(uint16_t);
-	if (lds <= 64 * 1024 - 256)
+	const size_t lds = (size_t) cfg.spp * 64 * sizeof(uint16_t);
+	if (lds <= 64 * 1024)
 		hipLaunchKernelGGL(k_ld_tables_lds, dim3(blocks_for(n_slots, 64)), dim3(64), lds, s, cfg, pixel_keys, n_slots, scr, perm);
 	else
 		hipLaunchKernelGGL(k_ld_tables, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, cfg, pixel_keys, n_slots, scr, perm);

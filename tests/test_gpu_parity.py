@@ -282,6 +282,13 @@ def test_edge_cases(gpu_lib, mts, orc):
     assert np.array_equal(it3.film().view(np.uint32), o3.view(np.uint32))
     with pytest.raises(mts.MtsGpuError):
         it3.preprocess(sc1, cam3, sampler="ldsampler", sampleCount=65537)                 # would not fit the tables
+    # 512 samples: the largest tables the LDS kernel holds (64 KB); 1024: the first size of the plain kernel
+    for spp in (512, 1024):
+        cam4 = mts.PerspectiveCamera.for_description(sd1, 12, 10)
+        it3.preprocess(sc1, cam4, sampler="ldsampler", sampleCount=spp, seed=9)
+        it3.clear_film(); assert it3.render()
+        o4, _ = orc.render(osc1.scene, orc.make_camera(sd1, 12, 10), orc.render_params(3, sampler=mts.abi.SAMPLER_LD_KEYED, spp=spp, seed=9))
+        assert np.array_equal(it3.film().view(np.uint32), o4.view(np.uint32)), spp
 
 
 # --------------------------------------------------------------------------------------------
