@@ -121,6 +121,7 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	auto &o = c->pathAllocs;
 	int rc = 0;
 	rc |= devAlloc(c, &c->paths.base, cap * kPathSlots, o);
+	rc |= devAlloc(c, &c->paths.shq_o, cap, o); rc |= devAlloc(c, &c->paths.shq_d, cap, o); rc |= devAlloc(c, &c->paths.shq_nee, cap, o);
 	// every shard (workgroups with blockIdx % kBinShards == s) sees at most 1/kBinShards of the 256-ray
 	// batches plus one per workgroup, and all of them may land in one bin
 	const size_t segCap = cap / kBinShards + (size_t) kTraceBlock * (kTraceGridBlocks / kBinShards + 2);

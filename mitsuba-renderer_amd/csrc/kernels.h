@@ -52,11 +52,11 @@ struct DScene {
 };
 
 // Per-path state, indexed by path id (paths never move; queues hold ids).
-// One 256-byte record per path = two 128-byte lines, so that the id-indexed gathers of the
-// shading and traversal kernels cost one or two L1 misses instead of one per field:
-//   line 0: ray_o, ray_d, hit, thr, Li, bsdf, misc, spos   (everything a bounce reads)
-//   line 1: nee, sh_o, sh_d                                  (the pending shadow ray)
-constexpr int kPathSlots = 16;        // float4 slots per record
+// One 128-byte record per path = one cache line, so that the id-indexed gathers of the shading and
+// traversal kernels cost one L1 miss instead of one per field:
+//   ray_o, ray_d, hit, thr, Li, bsdf, misc, spos   (everything a bounce reads)
+// The pending shadow ray does not live here: it is stored in shadow-queue order (shq_*).
+constexpr int kPathSlots = 8;         // float4 slots per record: one 128-byte line
 struct DPaths {
 	float4 *base;
 	__host__ __device__ float4 &slot(size_t id, int k) const { return base[id * kPathSlots + k]; }
@@ -68,9 +68,10 @@ struct DPaths {
 	__host__ __device__ float4 &bsdf(size_t id) const { return slot(id, 5); }    // bsdfVal/pdf rgb, w = bsdfPdf
 	__host__ __device__ uint4  &misc(size_t id) const { return reinterpret_cast<uint4 &>(slot(id, 6)); } // rng lo, rng hi, sample idx, pixel key
 	__host__ __device__ float4 &spos(size_t id) const { return slot(id, 7); }    // raster position x, y
-	__host__ __device__ float4 &nee(size_t id) const { return slot(id, 8); }     // pending direct-light contribution rgb
-	__host__ __device__ float4 &sh_o(size_t id) const { return slot(id, 9); }    // shadow ray origin p1
-	__host__ __device__ float4 &sh_d(size_t id) const { return slot(id, 10); }   // shadow ray direction p2 - p1
+	// shadow rays live in queue order, not in the record: written coalesced by k_shade at the slot the stream
+	// compaction assigns, read coalesced by k_trace<shadow>
+	float4 *shq_o, *shq_d;        // origin p1, direction p2 - p1
+	float4 *shq_nee;              // pending direct-light contribution rgb, w = path id (uint bits)
 };
 
 // flags in Li.w

@@ -470,10 +470,11 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 			} else if (MODE == 1) {
 				// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
 				if (done && !found) {
-					float4 L = ps.Li(id);
-					const float4 c = ps.nee(id);
+					const float4 c = ps.shq_nee[id];            // id = position in the shadow queue; c.w = path id
+					const uint32_t pid = __float_as_uint(c.w);
+					float4 L = ps.Li(pid);
 					L.x += c.x; L.y += c.y; L.z += c.z;
-					ps.Li(id) = L;
+					ps.Li(pid) = L;
 				}
 			} else {
 				if (done)
@@ -491,11 +492,11 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 			sup_base += taken; sup_left -= taken;
 			MG_WSLOT(w_batch);
 			if (take) {
-				id = queue[my];
+				id = (MODE == 1) ? my : queue[my];       // shadow rays are addressed by their queue position
 				float4 a, b;
 				float rmint, rmaxt;
 				if (MODE == 1) {
-					a = ps.sh_o(id); b = ps.sh_d(id);
+					a = ps.shq_o[my]; b = ps.shq_d[my];
 					rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
 				} else {
 					a = ps.ray_o(id); b = ps.ray_d(id);
@@ -1573,6 +1574,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 		id = q.bins[BT][(size_t) seg * q.bin_seg_cap + (gtid - view.prefix[seg])];
 	}
 	bool continues = false, wantShadow = false;
+	V3 neeV(0, 0, 0), shO(0, 0, 0), shD(0, 0, 0);      // pending direct-light term and its shadow ray
 
 	if (active) {
 		const float4 ro = ps.ray_o(id), rd = ps.ray_d(id);
@@ -1702,12 +1704,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 						const float weight = direct ? mi_weight(lRec.pdf * cfg.frac_lum, bsdfPdf * cfg.frac_bsdf) * cfg.weight_lum
 						                            : mi_weight(lRec.pdf, bsdfPdf);          // direct.cpp:143-145
 						// added to Li by k_trace<shadow> iff the segment is unoccluded
-						ps.nee(id) = make_float4(thr.x * lRec.value.x * bsdfVal.x * weight,
-						                         thr.y * lRec.value.y * bsdfVal.y * weight,
-						                         thr.z * lRec.value.z * bsdfVal.z * weight, 0.0f);
-						const V3 sd = lRec.p - its.p;       // Ray(p1, p2 - p1) (scene.h:241-246)
-						ps.sh_o(id) = make_float4(its.p.x, its.p.y, its.p.z, 0.0f);
-						ps.sh_d(id) = make_float4(sd.x, sd.y, sd.z, 0.0f);
+						// (kept in registers until the shadow-queue slot of this path is known, see the end of the kernel)
+						neeV = V3(thr.x * lRec.value.x * bsdfVal.x * weight,
+						          thr.y * lRec.value.y * bsdfVal.y * weight,
+						          thr.z * lRec.value.z * bsdfVal.z * weight);
+						shO = its.p;
+						shD = lRec.p - its.p;               // Ray(p1, p2 - p1) (scene.h:241-246)
 						wantShadow = true;
 					}
 				}
@@ -1762,7 +1764,13 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 	for (uint32_t w = 0; w < wave; ++w) { offN += s_cnt[0][w]; offS += s_cnt[1][w]; }
 	const unsigned long long below = (1ull << lane) - 1ull;
 	if (continues) q.next[offN + (uint32_t) __popcll(mN & below)] = id;
-	if (wantShadow) q.shadow[offS + (uint32_t) __popcll(mS & below)] = id;
+	if (wantShadow) {
+		// the shadow ray lives in queue order (coalesced for both kernels); the path id rides in nee.w
+		const uint32_t pos = offS + (uint32_t) __popcll(mS & below);
+		ps.shq_o[pos] = make_float4(shO.x, shO.y, shO.z, 0.0f);
+		ps.shq_d[pos] = make_float4(shD.x, shD.y, shD.z, 0.0f);
+		ps.shq_nee[pos] = make_float4(neeV.x, neeV.y, neeV.z, __uint_as_float(id));
+	}
 }
 
 // ===========================================================================
