@@ -640,3 +640,37 @@ def test_point_light_direct_illumination_is_analytic(mts, orc):
     centre = img[16, 16, 0]
     assert abs(centre - 0.5 / np.pi * 10.0 / 4.0) < 2e-3            # straight below the light: d = 2, cos = 1
     assert img[0, 0, 0] < centre
+
+
+def test_furnace_analytic_radiance(mts, orc):
+    """closed-form radiance in a constant environment (the whole Li estimator: MIS weights, throughput, Russian
+    roulette, background pdf): a convex lambertian body shows rho * Le, a dielectric or mirror body returns
+    (reflectance) * Le whatever the path length, an area-lit lambertian floor below a large sphere light ... """
+    def sphere_scene(bsdf_fn, env=2.0):
+        sd = mts.scenes.SceneDescription("furnace")
+        sd.add_sphere((0.0, 0.0, 0.0), 1.0, bsdf=bsdf_fn(sd))
+        sd.add_lum(mts.abi.LUM_CONSTANT, [env, env, env])
+        sd.camera = dict(origin=(0.0, 0.0, 6.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=8.0)   # all pixels on the sphere
+        return sd
+    cases = [
+        ("lambertian", lambda sd: sd.add_bsdf(mts.abi.BSDF_LAMBERTIAN, [0.5, 0.7, 0.2]), (1.0, 1.4, 0.4), 0.012),
+        ("dielectric", lambda sd: sd.dielectric(1.5, 1.0), (2.0, 2.0, 2.0), 0.004),
+        ("mirror", lambda sd: sd.mirror(0.9), (1.8, 1.8, 1.8), 2e-5),
+        ("difftrans", lambda sd: sd.difftrans(0.6), None, None),
+    ]
+    for name, fn, expect, tol in cases:
+        sd = sphere_scene(fn)
+        fs = orc.FlatScene(sd)
+        cam = orc.make_camera(sd, 24, 24)
+        for sampler in (mts.abi.SAMPLER_INDEPENDENT_KEYED, mts.abi.SAMPLER_LD_KEYED):
+            prm = orc.render_params(-1, rr_depth=10, sampler=sampler, spp=256, seed=3)
+            film, _ = orc.render(fs.scene, cam, prm)
+            img = orc.develop(film)
+            assert (film[..., 3] == film[..., 4]).all()                         # every camera ray hits the sphere
+            m = img.reshape(-1, 3).mean(axis=0)
+            if expect is None:
+                # light diffuses through the sphere's wall twice per crossing: strictly between 0 and Le, no NaN
+                assert np.isfinite(img).all() and 0.05 < m[0] < 2.0
+                continue
+            for c in range(3):
+                assert abs(m[c] / expect[c] - 1) < tol, (name, sampler, m, expect)
