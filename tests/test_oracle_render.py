@@ -645,7 +645,8 @@ def test_point_light_direct_illumination_is_analytic(mts, orc):
 def test_furnace_analytic_radiance(mts, orc):
     """closed-form radiance in a constant environment (the whole Li estimator: MIS weights, throughput, Russian
     roulette, background pdf): a convex lambertian body shows rho * Le, a dielectric or mirror body returns
-    (reflectance) * Le whatever the path length, an area-lit lambertian floor below a large sphere light ... """
+    (reflectance) * Le whatever the path length; and the direct light of a spherical area luminaire (solid-angle
+    sampling of src/shapes/sphere.cpp + MIS) on a lambertian floor: Lo = rho * L * (R / d)^2 straight below it"""
     def sphere_scene(bsdf_fn, env=2.0):
         sd = mts.scenes.SceneDescription("furnace")
         sd.add_sphere((0.0, 0.0, 0.0), 1.0, bsdf=bsdf_fn(sd))
@@ -674,3 +675,16 @@ def test_furnace_analytic_radiance(mts, orc):
                 continue
             for c in range(3):
                 assert abs(m[c] / expect[c] - 1) < tol, (name, sampler, m, expect)
+
+    # --- spherical area light above a lambertian floor, maxDepth 2 (direct light only) ---
+    sd = mts.scenes.SceneDescription("spherelight")
+    pos, tri = mts.scenes._quad((-6, 0, -6), (12, 0, 0), (0, 0, 12), (0, 1, 0))
+    sd.add_mesh(pos, tri, bsdf=sd.lambertian(0.5), face_normals=True)
+    lum = sd.add_lum(mts.abi.LUM_AREA, [10.0, 10.0, 10.0])
+    sd.add_sphere((0.0, 2.0, 0.0), 0.5, bsdf=sd.lambertian(0.0), lum=lum)
+    sd.camera = dict(origin=(2.5, 1.5, 0.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=1.0)
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 9, 9)
+    film, _ = orc.render(fs.scene, cam, orc.render_params(2, sampler=mts.abi.SAMPLER_LD_KEYED, spp=1024, seed=2))
+    centre = orc.develop(film)[4, 4, 0]
+    assert abs(centre / (0.5 * 10.0 * (0.5 / 2.0) ** 2) - 1) < 0.01, centre
