@@ -688,3 +688,15 @@ def test_furnace_analytic_radiance(mts, orc):
     film, _ = orc.render(fs.scene, cam, orc.render_params(2, sampler=mts.abi.SAMPLER_LD_KEYED, spp=1024, seed=2))
     centre = orc.develop(film)[4, 4, 0]
     assert abs(centre / (0.5 * 10.0 * (0.5 / 2.0) ** 2) - 1) < 0.01, centre
+
+    # --- a uniform environment MAP must act like the constant luminaire (checks the density normalisation of
+    #     src/luminaires/envmap.cpp:123-193 against the closed form) ---
+    sd = mts.scenes.SceneDescription("furnace_envmap")
+    sd.add_sphere((0.0, 0.0, 0.0), 1.0, bsdf=sd.add_bsdf(mts.abi.BSDF_LAMBERTIAN, [0.5, 0.7, 0.2]))
+    sd.envmap(np.full((16, 32, 3), 2.0, dtype=np.float32), 1.0)
+    sd.camera = dict(origin=(0.0, 0.0, 6.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=8.0)
+    fs = orc.FlatScene(sd)
+    film, _ = orc.render(fs.scene, orc.make_camera(sd, 24, 24), orc.render_params(-1, sampler=mts.abi.SAMPLER_LD_KEYED, spp=256, seed=3))
+    m = orc.develop(film).reshape(-1, 3).mean(axis=0)
+    for c, e in enumerate((1.0, 1.4, 0.4)):
+        assert abs(m[c] / e - 1) < 0.015, m
