@@ -190,6 +190,53 @@ def test_cancel_and_error_paths(gpu_lib, mts, orc):
         fresh.render()                                  # no scene uploaded
 
 
+def test_api_state_transitions(gpu_lib, mts, orc):
+    """one context reused across scenes, film sizes, samplers, integrators and filters gives the same films as fresh
+    contexts (no stale device state); C-ABI misuse returns error codes instead of crashing"""
+    import ctypes as C
+    L = mts.lib()
+    sdA, sdB = mts.scenes.cornell_c1(), mts.scenes.cornell_c5(sphere_subdiv=2)
+    scA, scB = mts.Scene(sdA), mts.Scene(sdB)
+    oA, oB = orc.FlatScene(sdA), orc.FlatScene(sdB)
+    it = mts.MIPathTracer(maxDepth=5)
+    plan = [(sdA, scA, oA, 40, 24, "ldsampler", 8), (sdB, scB, oB, 17, 33, "independent", 5), (sdA, scA, oA, 64, 64, "stratified", 9),
+            (sdB, scB, oB, 40, 24, "halton", 6)]
+    for sd, sc, osc, w, h, sampler, spp in plan:
+        cam = mts.PerspectiveCamera.for_description(sd, w, h)
+        it.preprocess(sc, cam, sampler=sampler, sampleCount=spp, seed=21)
+        it.clear_film()
+        assert it.render()
+        kind = {"independent": 0, "ldsampler": 1, "halton": 2, "hammersley": 3, "stratified": 4}[sampler]
+        o, _ = orc.render(osc.scene, orc.make_camera(sd, w, h), orc.render_params(5, sampler=kind, spp=spp, seed=21))
+        assert np.array_equal(it.film().view(np.uint32), o.view(np.uint32)), (w, h, sampler)
+    # rendering twice without clearing accumulates (Film::putImageBlock semantics)
+    f1 = it.film().copy(); assert it.render()
+    f2 = it.film()                                                      # (f1 + a) + b, not f1 + (a + b): equal up to rounding
+    assert np.allclose(f2, f1 + f1, rtol=1e-5, atol=1e-6) and not np.array_equal(f2, f1)
+    # misuse of the C ABI
+    assert L.mtsgpu_upload_scene(None, None) < 0 and L.mtsgpu_set_camera(it._ctx, None) < 0
+    assert L.mtsgpu_read_film(it._ctx, None) < 0 and L.mtsgpu_trace_rays(it._ctx, None, 5, 0, None) < 0
+    assert L.mtsgpu_set_tiles(it._ctx, 0, 0, 1) < 0 and L.mtsgpu_set_tiles(it._ctx, 32, 3, 2) < 0
+    assert L.mtsgpu_set_sampler(it._ctx, 99, 4, 3, 0) < 0 and L.mtsgpu_set_sampler(it._ctx, 1, 0, 3, 0) < 0
+    assert L.mtsgpu_set_rfilter(it._ctx, -1.0, 2.0, (C.c_float * 256)()) < 0
+    bad = mts.abi.Camera(); bad.width = -4; bad.height = 10
+    assert L.mtsgpu_set_camera(it._ctx, C.byref(bad)) < 0
+    assert b"" != L.mtsgpu_last_error(it._ctx)
+    L.mtsgpu_destroy(None)                                             # a no-op
+    # a corrupted scene is refused before anything reaches the GPU
+    arr = scA.arrays()
+    broken = mts.abi.Scene.from_buffer_copy(scA.sc)
+    nodes = arr["kd_nodes"].copy(); nodes[0, 0] = (nodes[0, 0] & 3) | (0x3FFFFFF << 2)      # child offset far outside the array
+    broken.kd_nodes = mts.abi.ptr(nodes, mts.abi.u32p)
+    assert L.mtsgpu_upload_scene(it._ctx, C.byref(broken)) == -1
+    idx = arr["kd_indices"].copy(); idx[0] = 0x7FFFFFFF
+    broken = mts.abi.Scene.from_buffer_copy(scA.sc); broken.kd_indices = mts.abi.ptr(idx, mts.abi.u32p)
+    assert L.mtsgpu_upload_scene(it._ctx, C.byref(broken)) == -1
+    # the context still works afterwards
+    it.preprocess(scA, mts.PerspectiveCamera.for_description(sdA, 16, 16), sampler="independent", sampleCount=2)
+    it.clear_film(); assert it.render()
+
+
 def test_orthographic_camera(gpu_lib, mts, orc):
     """`orthographic` camera plugin (src/cameras/orthographic.cpp:104-118): parallel rays, mint = 0, maxt = far - near"""
     sd = mts.scenes.cornell_c5(sphere_subdiv=2)
