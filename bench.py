@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--grid", type=int, default=320, help="wall grid resolution (320 -> 1 024 000 triangles)")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-kd", action="store_true", help="kd-tree binning phase on the host instead of the GPU (same tree)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,7 +94,7 @@ def main():
     kp = None
     if os.environ.get("MTSGPU_KD_TRAV"):          # experiment knob: Scene property kdTraversalCost (scene.cpp:54-88)
         kp = pkg.abi.KdParams(); kp.traversal_cost = float(os.environ["MTSGPU_KD_TRAV"])
-    scene = pkg.Scene(sd, kp)
+    scene = pkg.Scene(sd, kp, gpu_binning=not args.host_kd)
     flatten_s = time.time() - t0
     W = H = args.res
     spp_total = args.spp * world

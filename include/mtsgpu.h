@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MTSGPU_ABI_VERSION 2
+#define MTSGPU_ABI_VERSION 3
 
 enum {
 	MTSGPU_OK = 0,
@@ -299,6 +299,9 @@ typedef struct mtsgpu_kd_params {
 	float traversal_cost, query_cost, empty_space_bonus;
 	int32_t stop_prims, max_bad_refines, exact_prim_threshold, max_depth, min_max_bins;
 	int32_t clip, retract, n_threads;
+	/* 1: the min-max binning phase (> exact_prim_threshold primitives per node) runs on the current HIP device; the
+	 * tree is the same bit for bit.  An error if there is no device; 0 = host */
+	int32_t gpu_binning;
 } mtsgpu_kd_params;
 
 typedef struct mtsgpu_flat_scene mtsgpu_flat_scene; /* owns the arrays of a mtsgpu_scene */

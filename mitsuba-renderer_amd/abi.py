@@ -5,7 +5,7 @@ against the sizes the C compiler reports (mtsgpu_abi_sizeof)."""
 import ctypes as C
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET, BSDF_MIRROR, BSDF_PHONG, BSDF_ROUGHGLASS, BSDF_DIFFTRANS = 0, 1, 2, 3, 4, 5, 6, 7
 BSDF_TWOSIDED = 0x100
 BSDF_NPARAMS = 16
@@ -88,7 +88,7 @@ class KdParams(C.Structure):
         ("traversal_cost", C.c_float), ("query_cost", C.c_float), ("empty_space_bonus", C.c_float),
         ("stop_prims", C.c_int32), ("max_bad_refines", C.c_int32), ("exact_prim_threshold", C.c_int32),
         ("max_depth", C.c_int32), ("min_max_bins", C.c_int32),
-        ("clip", C.c_int32), ("retract", C.c_int32), ("n_threads", C.c_int32),
+        ("clip", C.c_int32), ("retract", C.c_int32), ("n_threads", C.c_int32), ("gpu_binning", C.c_int32),
     ]
 
 

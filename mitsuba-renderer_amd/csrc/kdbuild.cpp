@@ -15,12 +15,16 @@
 // Edge events that compare equal are additionally ordered by primitive index so that
 // the result does not depend on the sort implementation.
 #include "host.h"
+#include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
 #include <thread>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace mg {
 namespace {
@@ -171,7 +175,24 @@ struct Context {
 	uint32_t allocNodes(uint32_t n) { const uint32_t r = (uint32_t) nodes.size(); nodes.resize(nodes.size() + n); return r; }
 };
 
-struct Job { uint32_t depth; Box nodeBox; std::vector<uint32_t> prims; uint32_t badRefines; Context ctx; uint32_t root; };
+struct Job { uint32_t depth; Box nodeBox; std::vector<uint32_t> prims; uint32_t badRefines; Context ctx; uint32_t root; double ms = 0; };
+
+// (int64_t) of a bin coordinate as the x86 conversion the reference compiles to defines it: values outside the
+// int64 range (a node that is flat along the axis divides by zero) give INT64_MIN; host and device agree on this
+__host__ __device__ inline int64_t binIndex(float v) {
+	return (v >= -9223372036854775808.0f && v < 9223372036854775808.0f) ? (int64_t) v : (int64_t) 0x8000000000000000ull;
+}
+
+// Record of the min-max binning phase when it ran on the device: per node what minimizeCost chose, the unions of the
+// boxes sent to either side and, for nodes the phase ends at, their primitive list
+struct PlanNode {
+	uint32_t count = 0;
+	Split best;
+	Box leftRaw, rightRaw;
+	std::vector<uint32_t> prims;
+	int child[2] = { -1, -1 };
+};
+struct Plan { std::vector<PlanNode> nodes; };
 
 class Builder {
 public:
@@ -228,7 +249,7 @@ public:
 	}
 
 	// buildTree: exact greedy sweep (gkdtree.h:1898-2345)
-	float sweep(Context &c, std::vector<uint8_t> &cls, uint32_t depth, uint32_t node, const Box &nodeBox,
+	float sweep(Context &c, uint8_t *cls, uint32_t depth, uint32_t node, const Box &nodeBox,
 	            std::vector<Event> &events, uint32_t primCount, uint32_t badRefines) const {
 		const Event *eventStart = events.data(), *eventEnd = events.data() + events.size();
 		const float leafCost = primCount * m_p.queryCost;
@@ -366,7 +387,7 @@ public:
 	}
 
 	// transitionToNLogN + createEventList (gkdtree.h:1668-1704, :1490-1530)
-	float runExact(Context &c, std::vector<uint8_t> &cls, uint32_t depth, uint32_t node, const Box &nodeBox,
+	float runExact(Context &c, uint8_t *cls, uint32_t depth, uint32_t node, const Box &nodeBox,
 	               const std::vector<uint32_t> &prims, uint32_t badRefines) const {
 		std::vector<Event> events;
 		events.reserve(6 * prims.size());
@@ -387,8 +408,8 @@ public:
 	}
 
 	// MinMaxBins::minimizeCost (gkdtree.h:2405-2510)
-	Split minimize(const Box &tight, const float *binSize, const float *invBinSize, const std::vector<uint32_t> &minBins,
-	               const std::vector<uint32_t> &maxBins, uint32_t primCount) const {
+	Split minimize(const Box &tight, const float *binSize, const float *invBinSize, const uint32_t *minBins,
+	               const uint32_t *maxBins, uint32_t primCount) const {
 		Split cand;
 		int binIdx = 0, leftBin = 0;
 		const int nb = m_p.minMaxBins;
@@ -436,66 +457,37 @@ public:
 		return cand;
 	}
 
-	// buildTreeMinMax (gkdtree.h:1735-1867).  Nodes that drop to the exact method become jobs.
-	float binned(Context &c, uint32_t depth, uint32_t node, const Box &nodeBox, const Box &tight,
-	             std::vector<uint32_t> &prims, uint32_t badRefines) {
-		const uint32_t primCount = (uint32_t) prims.size();
+	// --- decisions of buildTreeMinMax shared by the host loop and the device binning phase ---
+	enum Early { kMakeLeaf, kDefer, kBin };
+	Early early(uint32_t primCount, uint32_t depth) const {
+		if (primCount <= m_p.stopPrims || depth >= m_p.maxDepth) return kMakeLeaf;
+		if (primCount <= m_p.exactPrimThreshold) return kDefer;
+		return kBin;
+	}
+	// what follows MinMaxBins::minimizeCost (gkdtree.h:1779-1800): 0 split, 1 leaf, 2 hand over to the exact method
+	int afterMinimize(const Split &best, uint32_t primCount, uint32_t &badRefines) const {
 		const float leafCost = primCount * m_p.queryCost;
-		if (primCount <= m_p.stopPrims || depth >= m_p.maxDepth) {
-			leafFromIndices(c, node, prims.data(), primCount);
-			return leafCost;
-		}
-		if (primCount <= m_p.exactPrimThreshold)
-			return defer(c, depth, node, nodeBox, prims, badRefines);
-
-		const int nb = m_p.minMaxBins;
-		float binSize[3], invBinSize[3];
-		const float recip = 1.0f / (float) nb;
-		for (int a = 0; a < 3; ++a) { binSize[a] = (tight.mx[a] - tight.mn[a]) * recip; invBinSize[a] = 1 / binSize[a]; }
-		std::vector<uint32_t> minBins(3 * (size_t) nb, 0u), maxBins(3 * (size_t) nb, 0u);
-		const int64_t maxBin = nb - 1;
-		for (uint32_t i = 0; i < primCount; ++i) {
-			Box b; m_g.box(prims[i], b);
-			for (int a = 0; a < 3; ++a) {
-				const int64_t minIdx = (int64_t) ((b.mn[a] - tight.mn[a]) * invBinSize[a]);
-				const int64_t maxIdx = (int64_t) ((b.mx[a] - tight.mn[a]) * invBinSize[a]);
-				maxBins[a * nb + std::max((int64_t) 0, std::min(maxIdx, maxBin))]++;
-				minBins[a * nb + std::max((int64_t) 0, std::min(minIdx, maxBin))]++;
-			}
-		}
-		Split best = minimize(tight, binSize, invBinSize, minBins, maxBins, primCount);
-		if (best.cost == kInf)
-			return defer(c, depth, node, nodeBox, prims, badRefines);
+		if (best.cost == kInf) return 2;
 		if (best.cost >= leafCost) {
-			if ((best.cost > 4 * leafCost && primCount < 16) || badRefines >= m_p.maxBadRefines) {
-				leafFromIndices(c, node, prims.data(), primCount);
-				return leafCost;
-			}
+			if ((best.cost > 4 * leafCost && primCount < 16) || badRefines >= m_p.maxBadRefines) return 1;
 			++badRefines;
 		}
-
-		// MinMaxBins::partition (gkdtree.h:2517-2596)
-		const float splitPos = best.pos;
+		return 0;
+	}
+	void binSetup(const Box &tight, float *binSize, float *invBinSize) const {
+		const float recip = 1.0f / (float) m_p.minMaxBins;
+		for (int a = 0; a < 3; ++a) { binSize[a] = (tight.mx[a] - tight.mn[a]) * recip; invBinSize[a] = 1 / binSize[a]; }
+	}
+	// tail of MinMaxBins::partition (gkdtree.h:2560-2596): tight child boxes, split moved onto the nearer of them
+	void finishSplit(const Box &tight, Split &best, Box &leftBounds, Box &rightBounds, uint32_t numLeft, uint32_t numRight) const {
 		const int axis = best.axis;
-		Box leftBounds, rightBounds; leftBounds.reset(); rightBounds.reset();
-		std::vector<uint32_t> leftPrims, rightPrims;
-		leftPrims.reserve(best.numLeft); rightPrims.reserve(best.numRight);
-		for (uint32_t i = 0; i < primCount; ++i) {
-			const uint32_t p = prims[i];
-			Box b; m_g.box(p, b);
-			if (b.mx[axis] <= splitPos) { leftBounds.expand(b); leftPrims.push_back(p); }
-			else if (b.mn[axis] > splitPos) { rightBounds.expand(b); rightPrims.push_back(p); }
-			else { leftBounds.expand(b); rightBounds.expand(b); leftPrims.push_back(p); rightPrims.push_back(p); }
-		}
-		if (leftPrims.size() != best.numLeft || rightPrims.size() != best.numRight)
-			throw std::runtime_error("kd-tree build: min-max binning and partition disagree");
-		std::vector<uint32_t>().swap(prims);
+		const float splitPos = best.pos;
 		leftBounds.clip(tight); rightBounds.clip(tight);
 		leftBounds.mx[axis] = std::min(leftBounds.mx[axis], splitPos);
 		rightBounds.mn[axis] = std::max(rightBounds.mn[axis], splitPos);
 		if (leftBounds.mx[axis] != rightBounds.mn[axis]) {
 			const SAH tch(tight);
-			const float nL = (float) leftPrims.size(), nR = (float) rightPrims.size();
+			const float nL = (float) numLeft, nR = (float) numRight;
 			float p1l, p1r, p2l, p2r;
 			tch(axis, leftBounds.mx[axis] - tight.mn[axis], tight.mx[axis] - leftBounds.mx[axis], p1l, p1r);
 			tch(axis, rightBounds.mn[axis] - tight.mn[axis], tight.mx[axis] - rightBounds.mn[axis], p2l, p2r);
@@ -506,6 +498,70 @@ public:
 			leftBounds.mx[axis] = std::min(leftBounds.mx[axis], best.pos);
 			rightBounds.mn[axis] = std::max(rightBounds.mn[axis], best.pos);
 		}
+	}
+
+	// buildTreeMinMax (gkdtree.h:1735-1867).  Nodes that drop to the exact method become jobs.
+	// With a plan (device binning phase, kdbuild_gpu below) the histogram / partition loops are replaced by its records.
+	float binned(Context &c, uint32_t depth, uint32_t node, const Box &nodeBox, const Box &tight,
+	             std::vector<uint32_t> &prims, uint32_t badRefines, Plan *plan = nullptr, int planNode = -1) {
+		PlanNode *pn = plan ? &plan->nodes[planNode] : nullptr;
+		if (pn && pn->child[0] < 0)
+			prims.swap(pn->prims);                         // terminal record: its primitive list was read back
+		const uint32_t primCount = (pn && pn->child[0] >= 0) ? pn->count : (uint32_t) prims.size();
+		const float leafCost = primCount * m_p.queryCost;
+		switch (early(primCount, depth)) {
+			case kMakeLeaf: leafFromIndices(c, node, prims.data(), primCount); return leafCost;
+			case kDefer: return defer(c, depth, node, nodeBox, prims, badRefines);
+			default: break;
+		}
+
+		Split best;
+		Box leftBounds, rightBounds; leftBounds.reset(); rightBounds.reset();
+		std::vector<uint32_t> leftPrims, rightPrims;
+		if (!pn) {
+			const int nb = m_p.minMaxBins;
+			float binSize[3], invBinSize[3];
+			binSetup(tight, binSize, invBinSize);
+			std::vector<uint32_t> minBins(3 * (size_t) nb, 0u), maxBins(3 * (size_t) nb, 0u);
+			const int64_t maxBin = nb - 1;
+			for (uint32_t i = 0; i < primCount; ++i) {
+				Box b; m_g.box(prims[i], b);
+				for (int a = 0; a < 3; ++a) {
+					const int64_t minIdx = binIndex((b.mn[a] - tight.mn[a]) * invBinSize[a]);
+					const int64_t maxIdx = binIndex((b.mx[a] - tight.mn[a]) * invBinSize[a]);
+					maxBins[a * nb + std::max((int64_t) 0, std::min(maxIdx, maxBin))]++;
+					minBins[a * nb + std::max((int64_t) 0, std::min(minIdx, maxBin))]++;
+				}
+			}
+			best = minimize(tight, binSize, invBinSize, minBins.data(), maxBins.data(), primCount);
+		} else {
+			best = pn->best;
+		}
+		switch (afterMinimize(best, primCount, badRefines)) {
+			case 2: return defer(c, depth, node, nodeBox, prims, badRefines);
+			case 1: leafFromIndices(c, node, prims.data(), primCount); return leafCost;
+			default: break;
+		}
+
+		// MinMaxBins::partition (gkdtree.h:2517-2596)
+		if (!pn) {
+			const float splitPos = best.pos;
+			const int axis = best.axis;
+			leftPrims.reserve(best.numLeft); rightPrims.reserve(best.numRight);
+			for (uint32_t i = 0; i < primCount; ++i) {
+				const uint32_t p = prims[i];
+				Box b; m_g.box(p, b);
+				if (b.mx[axis] <= splitPos) { leftBounds.expand(b); leftPrims.push_back(p); }
+				else if (b.mn[axis] > splitPos) { rightBounds.expand(b); rightPrims.push_back(p); }
+				else { leftBounds.expand(b); rightBounds.expand(b); leftPrims.push_back(p); rightPrims.push_back(p); }
+			}
+			if (leftPrims.size() != best.numLeft || rightPrims.size() != best.numRight)
+				throw std::runtime_error("kd-tree build: min-max binning and partition disagree");
+			std::vector<uint32_t>().swap(prims);
+		} else {
+			leftBounds = pn->leftRaw; rightBounds = pn->rightRaw;
+		}
+		finishSplit(tight, best, leftBounds, rightBounds, best.numLeft, best.numRight);
 
 		const uint32_t children = c.allocNodes(2);
 		const uint32_t nodePosBefore = (uint32_t) c.nodes.size(), indexPosBefore = (uint32_t) c.indices.size();
@@ -516,10 +572,10 @@ public:
 
 		Box childBox = nodeBox;
 		childBox.mx[best.axis] = best.pos;
-		const float leftCost = binned(c, depth + 1, children, childBox, leftBounds, leftPrims, badRefines);
+		const float leftCost = binned(c, depth + 1, children, childBox, leftBounds, leftPrims, badRefines, plan, pn ? pn->child[0] : -1);
 		childBox.mn[best.axis] = best.pos;
 		childBox.mx[best.axis] = nodeBox.mx[best.axis];
-		const float rightCost = binned(c, depth + 1, children + 1, childBox, rightBounds, rightPrims, badRefines);
+		const float rightCost = binned(c, depth + 1, children + 1, childBox, rightBounds, rightPrims, badRefines, plan, pn ? pn->child[1] : -1);
 
 		const SAH tch(nodeBox);
 		float pl, pr;
@@ -539,8 +595,10 @@ public:
 	// Hand a subtree to the job pool (parallel build) or build it right here (<= threshold scenes)
 	float defer(Context &c, uint32_t depth, uint32_t node, const Box &nodeBox, std::vector<uint32_t> &prims, uint32_t badRefines) {
 		if (!m_parallel) {
-			std::vector<uint8_t> cls(m_nPrims, 0);
-			return runExact(c, cls, depth, node, nodeBox, prims, badRefines);
+			// scratch classification per primitive id: every entry is written (kBoth) before the sweep reads it, so it
+			// is left uninitialised -- zero-filling nPrims bytes per worker page-faults 2 GB at 10 M primitives
+			std::unique_ptr<uint8_t[]> cls(new uint8_t[m_nPrims]);
+			return runExact(c, cls.get(), depth, node, nodeBox, prims, badRefines);
 		}
 		m_jobs.emplace_back(new Job());
 		Job &j = *m_jobs.back();
@@ -553,14 +611,17 @@ public:
 	void runJobs(int nThreads) {
 		std::atomic<size_t> next(0);
 		auto worker = [&]() {
-			std::vector<uint8_t> cls(m_nPrims, 0);
+			std::unique_ptr<uint8_t[]> clsBuf(new uint8_t[m_nPrims]);
+			uint8_t *cls = clsBuf.get();
 			for (;;) {
 				const size_t k = next.fetch_add(1);
 				if (k >= m_jobs.size())
 					break;
 				Job &j = *m_jobs[k];
 				j.root = j.ctx.allocNodes(1);
+				const auto tj0 = std::chrono::steady_clock::now();
 				runExact(j.ctx, cls, j.depth, j.root, j.nodeBox, j.prims, j.badRefines);
+				j.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count();
 				std::vector<uint32_t>().swap(j.prims);
 			}
 		};
@@ -577,6 +638,313 @@ public:
 	bool m_parallel = false;
 	std::vector<std::unique_ptr<Job>> m_jobs;
 };
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device binning phase.  buildTreeMinMax walks every primitive of a node twice (histogram, partition) on ONE host
+// thread, and at >= 10 M triangles that serial walk is most of the build on a many-core host.  Both walks are integer /
+// compare work over 24-byte boxes, so they run here level by level: all nodes of one level share three launches
+// (histogram, count + child bounds, stable scatter); the 768 counters of each node come back to the host, which runs
+// the reference's minimizeCost / split bookkeeping unchanged.  The result is a Plan that binned() replays, so the tree
+// is the one the host loop builds, bit for bit (tests/test_gpu_parity.py::test_gpu_binning_builds_the_same_tree).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kKdBlock = 256;
+constexpr uint32_t kKdChunk = 2048;          // entries of one node handled by one workgroup
+struct DevNode { float tmn[3], inv[3]; int32_t axis; float split; };
+struct DevChunk { uint32_t start, count, node, pad; };
+struct DevChunkOut { uint32_t nLeft, nRight; float lmn[3], lmx[3], rmn[3], rmx[3]; uint32_t pad[2]; };
+
+#define KDHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string("kd-tree build (device binning): ") + hipGetErrorString(e_)); } while (0)
+
+__global__ void k_kd_iota(uint32_t *p, uint32_t n) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) p[i] = i;
+}
+
+// MinMaxBins::bin (gkdtree.h:2379-2403): hist[node][0..3nb) = minBins, [3nb..6nb) = maxBins
+__global__ __launch_bounds__(kKdBlock) void k_kd_bin(const float *__restrict__ boxes, const uint32_t *__restrict__ cur,
+		const DevChunk *__restrict__ chunks, const DevNode *__restrict__ nodes, uint32_t *__restrict__ hist, int nb) {
+	extern __shared__ uint32_t s_h[];
+	const DevChunk ch = chunks[blockIdx.x];
+	const DevNode nd = nodes[ch.node];
+	for (int i = threadIdx.x; i < 6 * nb; i += kKdBlock) s_h[i] = 0u;
+	__syncthreads();
+	const int64_t maxBin = nb - 1;
+	for (uint32_t e = threadIdx.x; e < ch.count; e += kKdBlock) {
+		const float *b = boxes + 6 * (size_t) cur[ch.start + e];
+		for (int a = 0; a < 3; ++a) {
+			const int64_t minIdx = binIndex((b[a] - nd.tmn[a]) * nd.inv[a]);
+			const int64_t maxIdx = binIndex((b[3 + a] - nd.tmn[a]) * nd.inv[a]);
+			atomicAdd(&s_h[3 * nb + a * nb + (int) max((int64_t) 0, min(maxIdx, maxBin))], 1u);
+			atomicAdd(&s_h[a * nb + (int) max((int64_t) 0, min(minIdx, maxBin))], 1u);
+		}
+	}
+	__syncthreads();
+	uint32_t *out = hist + (size_t) ch.node * 6 * nb;
+	for (int i = threadIdx.x; i < 6 * nb; i += kKdBlock)
+		if (s_h[i]) atomicAdd(&out[i], s_h[i]);
+}
+
+// key of a bound for an order-independent reduction that still returns what the sequential std::min / std::max
+// chain returns: ties (+0 / -0) go to the earliest entry, whose bits are read back afterwards
+__device__ inline uint32_t monoKey(float v) {
+	const uint32_t u = __float_as_uint(v + 0.0f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// MinMaxBins::partition, first half: how many entries of the chunk go left / right, and the boxes they span
+__global__ __launch_bounds__(kKdBlock) void k_kd_count(const float *__restrict__ boxes, const uint32_t *__restrict__ cur,
+		const DevChunk *__restrict__ chunks, const DevNode *__restrict__ nodes, DevChunkOut *__restrict__ out) {
+	__shared__ unsigned long long s_key[12];
+	__shared__ uint32_t s_cnt[2];
+	const DevChunk ch = chunks[blockIdx.x];
+	const DevNode nd = nodes[ch.node];
+	if (threadIdx.x < 12) s_key[threadIdx.x] = (threadIdx.x % 6 < 3) ? ~0ull : 0ull;     // mins start high, maxes low
+	if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0u;
+	__syncthreads();
+	unsigned long long key[12];
+	for (int k = 0; k < 12; ++k) key[k] = (k % 6 < 3) ? ~0ull : 0ull;
+	uint32_t nL = 0, nR = 0;
+	for (uint32_t e = threadIdx.x; e < ch.count; e += kKdBlock) {
+		const float *b = boxes + 6 * (size_t) cur[ch.start + e];
+		const bool leftOnly = b[3 + nd.axis] <= nd.split;
+		const bool goesLeft = leftOnly || !(b[nd.axis] > nd.split), goesRight = !leftOnly;
+		nL += goesLeft; nR += goesRight;
+		for (int k = 0; k < 6; ++k) {
+			const unsigned long long hi = (unsigned long long) monoKey(b[k]) << 32;
+			const unsigned long long kmin = hi | e, kmax = hi | (0xFFFFFFFFu - e);
+			if (k < 3) {
+				if (goesLeft && kmin < key[k]) key[k] = kmin;
+				if (goesRight && kmin < key[6 + k]) key[6 + k] = kmin;
+			} else {
+				if (goesLeft && kmax > key[k]) key[k] = kmax;
+				if (goesRight && kmax > key[6 + k]) key[6 + k] = kmax;
+			}
+		}
+	}
+	for (int k = 0; k < 12; ++k) {
+		if (k % 6 < 3) atomicMin(&s_key[k], key[k]); else atomicMax(&s_key[k], key[k]);
+	}
+	atomicAdd(&s_cnt[0], nL); atomicAdd(&s_cnt[1], nR);
+	__syncthreads();
+	DevChunkOut &o = out[blockIdx.x];
+	if (threadIdx.x < 12) {
+		const int k = threadIdx.x, comp = k % 6;
+		const unsigned long long kk = s_key[k];
+		const bool empty = (comp < 3) ? (kk == ~0ull) : (kk == 0ull);
+		float v = (comp < 3) ? INFINITY : -INFINITY;             // Box::reset()
+		if (!empty) {
+			const uint32_t e = (comp < 3) ? (uint32_t) kk : 0xFFFFFFFFu - (uint32_t) kk;
+			v = boxes[6 * (size_t) cur[ch.start + e] + comp];
+		}
+		float *dst = (k < 6) ? (comp < 3 ? o.lmn : o.lmx) : (comp < 3 ? o.rmn : o.rmx);
+		dst[comp % 3] = v;
+	}
+	if (threadIdx.x == 0) { o.nLeft = s_cnt[0]; o.nRight = s_cnt[1]; }
+}
+
+// MinMaxBins::partition, second half: stable scatter (the lists keep the parent's order, as push_back gives it)
+__global__ __launch_bounds__(kKdBlock) void k_kd_scatter(const float *__restrict__ boxes, const uint32_t *__restrict__ cur,
+		const DevChunk *__restrict__ chunks, const DevNode *__restrict__ nodes, const uint2 *__restrict__ dst, uint32_t *__restrict__ next) {
+	__shared__ uint32_t s_w[2][kKdBlock / 64];
+	const DevChunk ch = chunks[blockIdx.x];
+	const DevNode nd = nodes[ch.node];
+	uint32_t baseL = dst[blockIdx.x].x, baseR = dst[blockIdx.x].y;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	for (uint32_t r = 0; r < ch.count; r += kKdBlock) {
+		const uint32_t e = r + threadIdx.x;
+		bool goesLeft = false, goesRight = false;
+		uint32_t p = 0;
+		if (e < ch.count) {
+			p = cur[ch.start + e];
+			const float *b = boxes + 6 * (size_t) p;
+			const bool leftOnly = b[3 + nd.axis] <= nd.split;
+			goesLeft = leftOnly || !(b[nd.axis] > nd.split); goesRight = !leftOnly;
+		}
+		const unsigned long long mL = __ballot(goesLeft), mR = __ballot(goesRight);
+		const unsigned long long below = (1ull << lane) - 1ull;
+		if (lane == 0) { s_w[0][wave] = (uint32_t) __popcll(mL); s_w[1][wave] = (uint32_t) __popcll(mR); }
+		__syncthreads();
+		uint32_t offL = 0, offR = 0, totL = 0, totR = 0;
+		for (uint32_t w = 0; w < kKdBlock / 64; ++w) {
+			if (w < wave) { offL += s_w[0][w]; offR += s_w[1][w]; }
+			totL += s_w[0][w]; totR += s_w[1][w];
+		}
+		if (goesLeft) next[baseL + offL + (uint32_t) __popcll(mL & below)] = p;
+		if (goesRight) next[baseR + offR + (uint32_t) __popcll(mR & below)] = p;
+		baseL += totL; baseR += totR;
+		__syncthreads();
+	}
+}
+
+template <typename T> struct DevBuf {
+	T *p = nullptr; size_t cap = 0;
+	~DevBuf() { if (p) (void) hipFree(p); }
+	void reserve(size_t n) {
+		if (n <= cap) return;
+		if (p) { (void) hipFree(p); p = nullptr; cap = 0; }
+		KDHIP(hipMalloc((void **) &p, n * sizeof(T)));
+		cap = n;
+	}
+};
+
+// Runs the binning phase of the whole tree on the current HIP device and records it as a Plan
+void planOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_t nPrims, const Box &scene, int nThreads, Plan &plan) {
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+		throw std::runtime_error("kd-tree build: gpu_binning was requested but there is no HIP device");
+	const int nb = p.minMaxBins;
+	if ((size_t) 6 * nb * sizeof(uint32_t) > 60 * 1024)
+		throw std::runtime_error("kd-tree build: gpu_binning supports at most 2560 bins");
+	hipStream_t st;
+	KDHIP(hipStreamCreate(&st));
+	struct StreamGuard { hipStream_t s; ~StreamGuard() { (void) hipStreamDestroy(s); } } guard{ st };
+
+	// the boxes of all primitives, once (host threads), then resident
+	std::vector<float> boxes(6 * (size_t) nPrims);
+	{
+		auto fill = [&](uint32_t lo, uint32_t hi) {
+			for (uint32_t i = lo; i < hi; ++i) { Box t; g.box(i, t); std::memcpy(&boxes[6 * (size_t) i], t.mn, 12); std::memcpy(&boxes[6 * (size_t) i + 3], t.mx, 12); }
+		};
+		const int nt = std::max(1, std::min(nThreads, 16));
+		std::vector<std::thread> pool;
+		for (int t = 1; t < nt; ++t) pool.emplace_back(fill, (uint32_t) ((uint64_t) nPrims * t / nt), (uint32_t) ((uint64_t) nPrims * (t + 1) / nt));
+		fill(0, (uint32_t) ((uint64_t) nPrims / nt));
+		for (auto &t : pool) t.join();
+	}
+	DevBuf<float> dBoxes; dBoxes.reserve(boxes.size());
+	KDHIP(hipMemcpyAsync(dBoxes.p, boxes.data(), boxes.size() * sizeof(float), hipMemcpyHostToDevice, st));
+	DevBuf<uint32_t> dCur, dNext, dHist;
+	dCur.reserve((size_t) nPrims + nPrims / 4 + 1024);
+	k_kd_iota<<<(nPrims + 255) / 256, 256, 0, st>>>(dCur.p, nPrims);
+	DevBuf<DevNode> dNodes; DevBuf<DevChunk> dChunks; DevBuf<DevChunkOut> dOut; DevBuf<uint2> dDst;
+
+	struct Active { int plan; uint32_t off, count, depth, badRefines; Box tight; };
+	std::vector<Active> level, nextLevel;
+	plan.nodes.clear();
+	plan.nodes.emplace_back();
+	plan.nodes[0].count = nPrims;
+	auto readBack = [&](int pn, const uint32_t *src, uint32_t off, uint32_t count) {
+		plan.nodes[pn].prims.resize(count);
+		if (count) KDHIP(hipMemcpyAsync(plan.nodes[pn].prims.data(), src + off, (size_t) count * 4, hipMemcpyDeviceToHost, st));
+	};
+	if (b.early(nPrims, 1) == Builder::kBin) level.push_back(Active{ 0, 0, nPrims, 1, 0, scene });
+	else readBack(0, dCur.p, 0, nPrims);
+
+	std::vector<DevNode> hNodes; std::vector<DevChunk> hChunks; std::vector<uint32_t> hHist;
+	std::vector<DevChunkOut> hOut; std::vector<uint2> hDst;
+	auto makeChunks = [&](const std::vector<uint32_t> &which) {
+		hChunks.clear();
+		for (uint32_t k : which)
+			for (uint32_t o = 0; o < level[k].count; o += kKdChunk)
+				hChunks.push_back(DevChunk{ level[k].off + o, std::min(kKdChunk, level[k].count - o), k, 0 });
+		dChunks.reserve(hChunks.size());
+		KDHIP(hipMemcpyAsync(dChunks.p, hChunks.data(), hChunks.size() * sizeof(DevChunk), hipMemcpyHostToDevice, st));
+	};
+
+	while (!level.empty()) {
+		const uint32_t nAct = (uint32_t) level.size();
+		// 1. histograms of every node of the level
+		hNodes.assign(nAct, DevNode());
+		std::vector<float> binSize(3 * (size_t) nAct), invBinSize(3 * (size_t) nAct);
+		std::vector<uint32_t> all(nAct);
+		for (uint32_t k = 0; k < nAct; ++k) {
+			all[k] = k;
+			b.binSetup(level[k].tight, &binSize[3 * k], &invBinSize[3 * k]);
+			for (int a = 0; a < 3; ++a) { hNodes[k].tmn[a] = level[k].tight.mn[a]; hNodes[k].inv[a] = invBinSize[3 * k + a]; }
+		}
+		makeChunks(all);
+		dNodes.reserve(nAct);
+		KDHIP(hipMemcpyAsync(dNodes.p, hNodes.data(), nAct * sizeof(DevNode), hipMemcpyHostToDevice, st));
+		dHist.reserve((size_t) nAct * 6 * nb);
+		KDHIP(hipMemsetAsync(dHist.p, 0, (size_t) nAct * 6 * nb * 4, st));
+		k_kd_bin<<<(uint32_t) hChunks.size(), kKdBlock, 6 * nb * sizeof(uint32_t), st>>>(dBoxes.p, dCur.p, dChunks.p, dNodes.p, dHist.p, nb);
+		KDHIP(hipGetLastError());
+		hHist.resize((size_t) nAct * 6 * nb);
+		KDHIP(hipMemcpyAsync(hHist.data(), dHist.p, hHist.size() * 4, hipMemcpyDeviceToHost, st));
+		KDHIP(hipStreamSynchronize(st));
+
+		// 2. minimizeCost per node (host, 3 x 127 candidates each); nodes that stop here hand their list back
+		std::vector<uint32_t> splitting;
+		size_t nextSize = 0;
+		std::vector<uint32_t> childOff(2 * (size_t) nAct, 0u);
+		for (uint32_t k = 0; k < nAct; ++k) {
+			Active &a = level[k];
+			const uint32_t *h = &hHist[(size_t) k * 6 * nb];
+			PlanNode &pn = plan.nodes[a.plan];
+			pn.best = b.minimize(a.tight, &binSize[3 * k], &invBinSize[3 * k], h, h + 3 * nb, a.count);
+			if (b.afterMinimize(pn.best, a.count, a.badRefines) != 0) {
+				readBack(a.plan, dCur.p, a.off, a.count);
+				continue;
+			}
+			hNodes[k].axis = pn.best.axis; hNodes[k].split = pn.best.pos;
+			childOff[2 * k] = (uint32_t) nextSize; childOff[2 * k + 1] = (uint32_t) nextSize + pn.best.numLeft;
+			nextSize += (size_t) pn.best.numLeft + pn.best.numRight;
+			if (nextSize > 0xFFFFFFFFull) throw std::runtime_error("kd-tree build: a level of the binning phase exceeds 2^32 entries");
+			splitting.push_back(k);
+		}
+		if (splitting.empty()) { KDHIP(hipStreamSynchronize(st)); break; }
+
+		// 3. count + child bounds per chunk, offsets by a host scan over the chunks, stable scatter
+		makeChunks(splitting);
+		KDHIP(hipMemcpyAsync(dNodes.p, hNodes.data(), nAct * sizeof(DevNode), hipMemcpyHostToDevice, st));
+		dOut.reserve(hChunks.size());
+		k_kd_count<<<(uint32_t) hChunks.size(), kKdBlock, 0, st>>>(dBoxes.p, dCur.p, dChunks.p, dNodes.p, dOut.p);
+		KDHIP(hipGetLastError());
+		hOut.resize(hChunks.size());
+		KDHIP(hipMemcpyAsync(hOut.data(), dOut.p, hOut.size() * sizeof(DevChunkOut), hipMemcpyDeviceToHost, st));
+		KDHIP(hipStreamSynchronize(st));
+		hDst.resize(hChunks.size());
+		std::vector<uint32_t> gotL(nAct, 0u), gotR(nAct, 0u);
+		for (uint32_t k : splitting) { PlanNode &pn = plan.nodes[level[k].plan]; pn.leftRaw.reset(); pn.rightRaw.reset(); }
+		for (size_t cidx = 0; cidx < hChunks.size(); ++cidx) {
+			const uint32_t k = hChunks[cidx].node;
+			PlanNode &pn = plan.nodes[level[k].plan];
+			const DevChunkOut &o = hOut[cidx];
+			hDst[cidx] = make_uint2(childOff[2 * k] + gotL[k], childOff[2 * k + 1] + gotR[k]);
+			gotL[k] += o.nLeft; gotR[k] += o.nRight;
+			// the chunks of a node arrive in list order, so this is the sequential expand() chain of the host loop
+			Box l, r;
+			std::memcpy(l.mn, o.lmn, 12); std::memcpy(l.mx, o.lmx, 12); std::memcpy(r.mn, o.rmn, 12); std::memcpy(r.mx, o.rmx, 12);
+			pn.leftRaw.expand(l); pn.rightRaw.expand(r);
+		}
+		for (uint32_t k : splitting) {
+			const PlanNode &pn = plan.nodes[level[k].plan];
+			if (gotL[k] != pn.best.numLeft || gotR[k] != pn.best.numRight)
+				throw std::runtime_error("kd-tree build: min-max binning and partition disagree");
+		}
+		dDst.reserve(hDst.size());
+		KDHIP(hipMemcpyAsync(dDst.p, hDst.data(), hDst.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+		dNext.reserve(nextSize + 1024);
+		k_kd_scatter<<<(uint32_t) hChunks.size(), kKdBlock, 0, st>>>(dBoxes.p, dCur.p, dChunks.p, dNodes.p, dDst.p, dNext.p);
+		KDHIP(hipGetLastError());
+
+		// 4. children: tight boxes as the host loop computes them; those that leave the phase read their list back
+		nextLevel.clear();
+		for (uint32_t k : splitting) {
+			const Active a = level[k];
+			Split best = plan.nodes[a.plan].best;
+			Box lb = plan.nodes[a.plan].leftRaw, rb = plan.nodes[a.plan].rightRaw;
+			b.finishSplit(a.tight, best, lb, rb, best.numLeft, best.numRight);
+			const uint32_t counts[2] = { best.numLeft, best.numRight };
+			const Box *boxes2[2] = { &lb, &rb };
+			for (int side = 0; side < 2; ++side) {
+				const int child = (int) plan.nodes.size();
+				plan.nodes.emplace_back();
+				plan.nodes[child].count = counts[side];
+				plan.nodes[a.plan].child[side] = child;
+				if (b.early(counts[side], a.depth + 1) == Builder::kBin)
+					nextLevel.push_back(Active{ child, childOff[2 * k + side], counts[side], a.depth + 1, a.badRefines, *boxes2[side] });
+				else
+					readBack(child, dNext.p, childOff[2 * k + side], counts[side]);
+			}
+		}
+		KDHIP(hipStreamSynchronize(st));              // read-backs done before the buffers swap roles
+		std::swap(dCur.p, dNext.p); std::swap(dCur.cap, dNext.cap);
+		level.swap(nextLevel);
+	}
+	KDHIP(hipStreamSynchronize(st));
+}
 
 int log2i(uint32_t v) { int r = 0; while (v >>= 1) r++; return r; }
 
@@ -614,8 +982,29 @@ void buildKdTree(const float *vtx, const uint32_t *tri, uint32_t nTris, const fl
 
 	Context root;
 	const uint32_t prelimRoot = root.allocNodes(1);
-	b.binned(root, 1, prelimRoot, scene, scene, prims, 0);
+	const bool timing = std::getenv("MTSGPU_KDTIMING") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
+	const bool onDevice = kp && kp->gpu_binning > 0 && b.m_parallel;
+	if (onDevice) {
+		Plan plan;
+		std::vector<uint32_t>().swap(prims);
+		planOnDevice(b, p, g, nTris, scene, nThreads, plan);
+		b.binned(root, 1, prelimRoot, scene, scene, prims, 0, &plan, 0);
+	} else {
+		b.binned(root, 1, prelimRoot, scene, scene, prims, 0);
+	}
+	const auto t1 = std::chrono::steady_clock::now();
 	b.runJobs(nThreads);
+	const auto t2 = std::chrono::steady_clock::now();
+	if (timing) {
+		double mx = 0, sum = 0;
+		for (auto &j : b.m_jobs) { mx = std::max(mx, j->ms); sum += j->ms; }
+		std::fprintf(stderr, "[kdbuild] jobs: longest %.1f ms, mean %.1f ms\n", mx, b.m_jobs.empty() ? 0.0 : sum / b.m_jobs.size());
+	}
+	if (timing)
+		std::fprintf(stderr, "[kdbuild] %u prims: binning phase (%s) %.1f ms (%zu jobs), exact phase %.1f ms on %d threads\n", nTris, onDevice ? "device" : "host",
+		             std::chrono::duration<double, std::milli>(t1 - t0).count(), b.m_jobs.size(),
+		             std::chrono::duration<double, std::milli>(t2 - t1).count(), nThreads);
 
 	// final layout (gkdtree.h:1042-1138): depth first, left child first, siblings adjacent
 	uint32_t inner = root.innerCount, leaves = root.leafCount, nIdx = root.primIndexCount;

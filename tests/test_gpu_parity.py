@@ -190,6 +190,34 @@ def test_cancel_and_error_paths(gpu_lib, mts, orc):
         fresh.render()                                  # no scene uploaded
 
 
+@pytest.mark.parametrize("case", ["c3_1M", "c5_threshold_300", "spheres_threshold_40", "bunny_threshold_2000", "bins_32"])
+def test_gpu_binning_builds_the_same_tree(gpu_lib, mts, orc, case):
+    """the device binning phase (k_kd_bin / k_kd_count / k_kd_scatter + the host's minimizeCost) yields the tree of the
+    host builder bit for bit -- nodes, index lists, statistics, bounding box -- and therefore the oracle's tree"""
+    kp = lambda: mts.abi.KdParams()
+    a, b = kp(), kp()
+    if case == "c3_1M":
+        sd = mts.scenes.cornell_c3()
+    elif case == "c5_threshold_300":
+        sd = mts.scenes.cornell_c5(sphere_subdiv=3); a.exact_prim_threshold = b.exact_prim_threshold = 300
+    elif case == "spheres_threshold_40":
+        sd = mts.scenes.spheres(); a.exact_prim_threshold = b.exact_prim_threshold = 40
+    elif case == "bunny_threshold_2000":
+        sd = mts.scenes.bunny(_bunny_serialized(), _loader()); a.exact_prim_threshold = b.exact_prim_threshold = 2000
+    else:
+        sd = mts.scenes.cornell_c3(grid=60, sphere_subdiv=3); a.exact_prim_threshold = b.exact_prim_threshold = 1000
+        a.min_max_bins = b.min_max_bins = 32
+    host = mts.Scene(sd, kd_params=a)
+    dev = mts.Scene(sd, kd_params=b, gpu_binning=True)
+    ha, da = host.arrays(), dev.arrays()
+    for k in ("kd_nodes", "kd_indices", "aabb_min", "aabb_max", "triaccel"):
+        assert np.array_equal(ha[k].view(np.uint32), da[k].view(np.uint32)), k
+    assert host.kdstats() == dev.kdstats()
+    if case != "c3_1M":                                                 # the oracle's own builder, same parameters
+        oa = orc.FlatScene(sd, kd_params=a).arrays()
+        assert np.array_equal(oa["kd_nodes"], da["kd_nodes"]) and np.array_equal(oa["kd_indices"], da["kd_indices"])
+
+
 def test_api_state_transitions(gpu_lib, mts, orc):
     """one context reused across scenes, film sizes, samplers, integrators and filters gives the same films as fresh
     contexts (no stale device state); C-ABI misuse returns error codes instead of crashing"""
