@@ -37,6 +37,11 @@ def test_no_gpu_means_a_loud_error_not_a_fallback(mts):
     with pytest.raises(mts.MtsGpuError) as e:
         mts.MIPathTracer(maxDepth=4)
     assert "no HIP device" in str(e.value) or "CPU fallback" in str(e.value)
+    # the device binning phase of the kd-tree build does not quietly run on the host either
+    kp = mts.abi.KdParams(); kp.exact_prim_threshold = 300
+    with pytest.raises(mts.MtsGpuError) as e:
+        mts.Scene(mts.scenes.cornell_c5(sphere_subdiv=2), kd_params=kp, gpu_binning=True)
+    assert "no HIP device" in str(e.value)
 
 
 @pytest.mark.parametrize("maker", [
