@@ -217,8 +217,10 @@ int  mtsgpu_set_camera(mtsgpu_ctx *ctx, const mtsgpu_camera *cam);
 /* MonteCarloIntegrator properties (src/librender/integrator.cpp:272-292) */
 int  mtsgpu_set_integrator(mtsgpu_ctx *ctx, int max_depth, int rr_depth, int strict_normals);
 /* Switches to the `direct` integrator plugin (MIDirectIntegrator, src/integrators/direct/direct.cpp:33-56):
- * luminaireSamples / bsdfSamples in {0, 1} (larger counts need Sampler::next2DArray); mtsgpu_set_integrator()
- * switches back to `path`. */
+ * luminaireSamples, bsdfSamples >= 0 with a positive sum.  Counts above one draw from Sampler::next2DArray
+ * (direct.cpp:58-63,122-127,156-161), which the independent, ldsampler and stratified samplers provide; with halton /
+ * hammersley the render call fails as the reference does (halton.cpp:102-104).  sampleCount x count <= 65536.
+ * mtsgpu_set_integrator() switches back to `path`. */
 int  mtsgpu_set_direct_integrator(mtsgpu_ctx *ctx, int luminaire_samples, int bsdf_samples);
 /* Sampler (src/samplers/{independent,ldsampler}.cpp): kind, sampleCount (LD: rounded up to pow2), LD depth, seed */
 int  mtsgpu_set_sampler(mtsgpu_ctx *ctx, int kind, uint32_t spp, int ld_depth, uint64_t seed);

@@ -325,7 +325,8 @@ class MIPathTracer:
 
 
 class MIDirectIntegrator(MIPathTracer):
-    """The `direct` integrator (src/integrators/direct/direct.cpp): luminaireSamples, bsdfSamples in {0, 1}"""
+    """The `direct` integrator (src/integrators/direct/direct.cpp); more than one sample per strategy needs a sampler
+    with sample arrays (independent, ldsampler, stratified), as in the reference"""
 
     def __init__(self, luminaireSamples=1, bsdfSamples=1, device=0):
         MIPathTracer.__init__(self, device=device)

@@ -54,6 +54,10 @@ struct mtsgpu_ctx {
 	uint32_t *queueA = nullptr, *queueB = nullptr;
 	uint32_t *pixelList = nullptr; size_t pixelListCap = 0;
 	uint32_t *ldScr = nullptr; uint16_t *ldPerm = nullptr; size_t ldScrCap = 0, ldPermCap = 0;
+	// Sampler::request2DArray arrays of the direct integrator (per pass, like the tables above)
+	unsigned long long *ldState = nullptr; size_t ldStateCap = 0;
+	uint32_t *arrScr = nullptr; uint16_t *arrPerm = nullptr; float2 *arrPts = nullptr; size_t arrScrCap = 0, arrPermCap = 0, arrPtsCap = 0;
+	float4 *primSave = nullptr; size_t primSaveCap = 0;
 	uint16_t *primes = nullptr;        // primeTable (util.cpp:64-122) on the device
 	uint32_t *explicitSamples = nullptr; size_t explicitCap = 0;
 	uint32_t *hostCounters = nullptr;       // pinned
@@ -174,8 +178,43 @@ DConfig makeConfig(const mtsgpu_ctx *c, bool slotPerPath) {
 	cfg.strat_res = 1; while ((uint32_t) cfg.strat_res * (uint32_t) cfg.strat_res < cfg.spp) ++cfg.strat_res;
 	cfg.slot_per_path = slotPerPath ? 1 : 0;
 	cfg.ld_scr = c->ldScr; cfg.ld_perm = c->ldPerm; cfg.primes = c->primes;
+	// MIDirectIntegrator::configureSampler (direct.cpp:58-63): the luminaire array first
+	if (c->integrator == 1) {
+		if (c->nLumSamples > 1) cfg.arr_size[cfg.arr_n++] = (uint32_t) c->nLumSamples;
+		if (c->nBsdfSamples > 1) cfg.arr_size[cfg.arr_n++] = (uint32_t) c->nBsdfSamples;
+		for (int a = 0; a < cfg.arr_n; ++a) { cfg.arr_off[a] = cfg.arr_total; cfg.arr_total += cfg.spp * cfg.arr_size[a]; }
+	}
+	cfg.arr_scr = c->arrScr; cfg.arr_perm = c->arrPerm; cfg.arr_pts = c->arrPts;
 	cfg.filt_size_x = c->filtSizeX; cfg.filt_size_y = c->filtSizeY; cfg.filt_border = c->filtBorder; cfg.filt_values = c->filtValues;
 	return cfg;
+}
+
+// buffers of the sample arrays for nSlots sampler slots (and of the saved camera hits for nPaths paths)
+int ensureSampleArrays(mtsgpu_ctx *c, size_t nSlots, size_t nPaths) {
+	if (c->integrator != 1 || (c->nLumSamples <= 1 && c->nBsdfSamples <= 1))
+		return 0;
+	if (c->samplerKind == MTSGPU_SAMPLER_HALTON || c->samplerKind == MTSGPU_SAMPLER_HAMMERSLEY)
+		return fail(c, MTSGPU_EINVAL, "request2DArray() is not supported by QMC samplers! (halton.cpp:102-104, hammersley.cpp:112-114)");
+	const uint32_t spp = effectiveSpp(c);
+	size_t total = 0; int nArr = 0;
+	for (int n : { c->nLumSamples, c->nBsdfSamples })
+		if (n > 1) {
+			if ((uint64_t) spp * (uint64_t) n > 65536ull)
+				return fail(c, MTSGPU_EINVAL, "sampleCount x samples per strategy = %llu exceeds 65536 points per pixel", (unsigned long long) spp * n);
+			total += (size_t) spp * n; ++nArr;
+		}
+	int rc = 0;
+	if (c->nBsdfSamples > 1) { rc = ensureBuf(c, &c->primSave, &c->primSaveCap, 3 * nPaths); if (rc) return rc; }
+	c->paths.prim = c->primSave;
+	if (!samplerHasTables(c)) return 0;
+	rc = ensureBuf(c, &c->ldState, &c->ldStateCap, nSlots); if (rc) return rc;
+	if (c->samplerKind == MTSGPU_SAMPLER_LD_KEYED) {
+		rc = ensureBuf(c, &c->arrScr, &c->arrScrCap, nSlots * nArr * 2); if (rc) return rc;
+		rc = ensureBuf(c, &c->arrPerm, &c->arrPermCap, nSlots * total); if (rc) return rc;
+	} else {
+		rc = ensureBuf(c, &c->arrPts, &c->arrPtsCap, nSlots * total); if (rc) return rc;
+	}
+	return 0;
 }
 
 hipEvent_t *nextEventPair(mtsgpu_ctx *c, std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used) {
@@ -187,8 +226,95 @@ hipEvent_t *nextEventPair(mtsgpu_ctx *c, std::vector<std::pair<hipEvent_t, hipEv
 	return &pool[used++].first;
 }
 
+int readCounters(mtsgpu_ctx *c) {
+	HIPCHK(c, hipMemcpyAsync(c->hostCounters, c->q.counters, kNumCounters * kCounterStride * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return 0;
+}
+
+// MIDirectIntegrator with more than one sample per strategy (direct.cpp:129-150,163-195): after the camera rays are
+// traced and sorted by material, the two sampling loops run as rounds over those queues -- round j of the first loop
+// shades with luminaire sample j and traces its shadow rays, round j of the second loop shades with BSDF sample j,
+// traces the sampled rays and adds what they hit.  Li therefore receives its terms in the order of the reference
+// (emission, luminaire samples 0.., BSDF samples 0..), which float addition needs for identical results.
+int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatile const int *cancel) {
+	hipStream_t s = c->stream;
+	DConfig cfg = cfg0;
+	const size_t counterBytes = kNumCounters * kCounterStride * sizeof(uint32_t);
+	auto timedTrace = [&](int mode, bool bin, const uint32_t *queue, uint32_t n, bool coherent) -> int {
+		hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
+		if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
+		launch_trace(s, mode, c->countTraversal, bin, c->dsc, c->paths, c->q, queue, n, coherent);
+		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
+		HIPCHK(c, hipGetLastError());
+		c->stats.trace_launches++;
+		return 0;
+	};
+	HIPCHK(c, hipMemsetAsync(c->q.counters, 0, counterBytes, s));
+	c->q.next = c->queueB;
+	int rc = timedTrace(0, true, c->queueA, nPaths, true); if (rc) return rc;
+	c->stats.rays_closest += nPaths;
+	rc = readCounters(c); if (rc) return rc;
+	BinView views[kNumBins];
+	for (int b = 0; b < kNumBins; ++b) {
+		uint32_t acc = 0;
+		for (int k = 0; k < kBinShards; ++k) {
+			views[b].prefix[k] = acc;
+			const uint32_t cnt = c->hostCounters[(b * kBinShards + k) * kCounterStride];
+			if (cnt > c->q.bin_seg_cap) return fail(c, MTSGPU_EHIP, "internal: bin segment overflow");
+			acc += cnt;
+		}
+		views[b].prefix[kBinShards] = acc;
+	}
+	auto shadeRound = [&](int mode, int index, bool withTerminal) -> int {
+		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
+		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, counterBytes, s));     // the bins stay as they are; views[] holds their sizes
+		if (sev) HIPCHK(c, hipEventRecord(sev[0], s));
+		cfg.dr_mode = mode; cfg.dr_index = index;
+		for (int b = 0; b < (withTerminal ? kNumBins : kNumBsdfTypes); ++b)
+			launch_shade(s, b, c->dsc, c->paths, cfg, c->q, views[b]);
+		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
+		HIPCHK(c, hipGetLastError());
+		return readCounters(c);
+	};
+	// direct.cpp:122-150
+	for (int j = 0; j < std::max(1, c->nLumSamples); ++j) {
+		if (cancel && *cancel) return fail(c, MTSGPU_ECANCEL, "render cancelled");
+		rc = shadeRound(1, j, j == 0); if (rc) return rc;
+		const uint32_t nShadow = c->hostCounters[(kNumBins * kBinShards + 1) * kCounterStride];
+		if (nShadow) {
+			rc = timedTrace(1, false, c->q.shadow, nShadow, true); if (rc) return rc;
+			c->stats.rays_shadow += nShadow;
+		}
+	}
+	// direct.cpp:152-195
+	for (int j = 0; j < std::max(1, c->nBsdfSamples); ++j) {
+		if (cancel && *cancel) return fail(c, MTSGPU_ECANCEL, "render cancelled");
+		rc = shadeRound(2, j, false); if (rc) return rc;
+		const uint32_t nNext = c->hostCounters[kNumBins * kBinShards * kCounterStride];
+		if (!nNext) continue;
+		rc = timedTrace(0, false, c->queueB, nNext, false); if (rc) return rc;
+		c->stats.rays_closest += nNext;
+		// what the sampled rays hit: the material-independent tail of the shading kernel over the ray queue
+		DQueues tailQ = c->q;
+		tailQ.bins[kNumBsdfTypes] = c->queueB;
+		BinView tail;
+		tail.prefix[0] = 0;
+		for (int k = 1; k <= kBinShards; ++k) tail.prefix[k] = nNext;
+		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
+		if (sev) HIPCHK(c, hipEventRecord(sev[0], s));
+		cfg.dr_mode = 3; cfg.dr_index = j;
+		launch_shade(s, kNumBsdfTypes, c->dsc, c->paths, cfg, tailQ, tail);
+		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
+		HIPCHK(c, hipGetLastError());
+	}
+	return 0;
+}
+
 // One wavefront pass: all bounces of the paths already generated into queueA[0..nPaths)
 int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile const int *cancel) {
+	if (cfg.integrator == 1 && (cfg.n_lum > 1 || cfg.n_bsdf > 1))
+		return runDirectRounds(c, cfg, nPaths, cancel);
 	uint32_t nQ = nPaths;
 	uint32_t *cur = c->queueA, *nxt = c->queueB;
 	bool first = true;       // camera rays and their shadow rays are coherent: plain 64-ray batches win there
@@ -350,6 +476,11 @@ void mtsgpu_destroy(mtsgpu_ctx *c) {
 	if (c->pixelList) (void) hipFree(c->pixelList);
 	if (c->ldScr) (void) hipFree(c->ldScr);
 	if (c->ldPerm) (void) hipFree(c->ldPerm);
+	if (c->ldState) (void) hipFree(c->ldState);
+	if (c->arrScr) (void) hipFree(c->arrScr);
+	if (c->arrPerm) (void) hipFree(c->arrPerm);
+	if (c->arrPts) (void) hipFree(c->arrPts);
+	if (c->primSave) (void) hipFree(c->primSave);
 	if (c->primes) (void) hipFree(c->primes);
 	if (c->explicitSamples) (void) hipFree(c->explicitSamples);
 	if (c->filtValues) (void) hipFree(c->filtValues);
@@ -608,8 +739,8 @@ int mtsgpu_set_direct_integrator(mtsgpu_ctx *c, int luminaire_samples, int bsdf_
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
 	if (luminaire_samples < 0 || bsdf_samples < 0 || luminaire_samples + bsdf_samples <= 0)
 		return fail(c, MTSGPU_EINVAL, "luminaireSamples + bsdfSamples must be > 0 (direct.cpp:41)");
-	if (luminaire_samples > 1 || bsdf_samples > 1)
-		return fail(c, MTSGPU_EINVAL, "more than one sample per strategy draws from Sampler::next2DArray, which this path does not implement");
+	if (luminaire_samples > 65536 || bsdf_samples > 65536)
+		return fail(c, MTSGPU_EINVAL, "at most 65536 samples per strategy");
 	c->integrator = 1; c->nLumSamples = luminaire_samples; c->nBsdfSamples = bsdf_samples;
 	return 0;
 }
@@ -761,6 +892,7 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 		rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, slotsPerPass * 3 * c->ldDepth); if (rc) return rc;
 		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, slotsPerPass * 2 * c->ldDepth * spp); if (rc) return rc;
 	}
+	rc = ensureSampleArrays(c, slotsPerPass, slotsPerPass * spp); if (rc) return rc;
 	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 8 * sizeof(unsigned long long), c->stream));
 	DConfig cfg = makeConfig(c, false);
 	cfg.pix_w = RW; cfg.pix_off = off;
@@ -790,8 +922,10 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 			nSlots = (uint32_t) std::min(slotsPerPass, pixels.size() - base);
 		}
 		const uint32_t nPaths = nSlots * spp;
-		if (samplerHasTables(c))
-			launch_ld_tables(c->stream, cfg, c->pixelList + base, nSlots, c->ldScr, c->ldPerm);
+		if (samplerHasTables(c)) {
+			launch_ld_tables(c->stream, cfg, c->pixelList + base, nSlots, c->ldScr, c->ldPerm, cfg.arr_n ? c->ldState : nullptr);
+			launch_sample_arrays(c->stream, cfg, nSlots, c->ldState);
+		}
 		launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList + base, nSlots, nullptr, nPaths, c->queueA);
 		HIPCHK(c, hipGetLastError());
 		rc = runBounces(c, cfg, nPaths, cancel);
@@ -882,7 +1016,7 @@ int mtsgpu_ld_tables(mtsgpu_ctx *c, uint32_t pixel_key, float *out1d, float *out
 	HIPCHK(c, hipMemcpyAsync(c->pixelList, &pixel_key, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	DConfig cfg{};
 	cfg.spp = spp; cfg.ld_depth = depth; cfg.seed = c->seed; cfg.sampler_kind = 1;
-	launch_ld_tables(c->stream, cfg, c->pixelList, 1, c->ldScr, c->ldPerm);
+	launch_ld_tables(c->stream, cfg, c->pixelList, 1, c->ldScr, c->ldPerm, nullptr);
 	HIPCHK(c, hipGetLastError());
 	std::vector<uint32_t> scr((size_t) 3 * depth);
 	std::vector<uint16_t> perm((size_t) 2 * depth * spp);
@@ -923,9 +1057,12 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 		rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, (size_t) n * 3 * c->ldDepth); if (rc) return rc;
 		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, (size_t) n * 2 * c->ldDepth * spp); if (rc) return rc;
 	}
+	rc = ensureSampleArrays(c, n, n); if (rc) return rc;
 	const DConfig cfg = makeConfig(c, true);
-	if (samplerHasTables(c))
-		launch_ld_tables(c->stream, cfg, c->pixelList, n, c->ldScr, c->ldPerm);
+	if (samplerHasTables(c)) {
+		launch_ld_tables(c->stream, cfg, c->pixelList, n, c->ldScr, c->ldPerm, cfg.arr_n ? c->ldState : nullptr);
+		launch_sample_arrays(c->stream, cfg, n, c->ldState);
+	}
 	launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList, n, c->explicitSamples, n, c->queueA);
 	HIPCHK(c, hipGetLastError());
 	rc = runBounces(c, cfg, n, nullptr); if (rc) return rc;

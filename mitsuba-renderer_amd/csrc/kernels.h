@@ -72,6 +72,9 @@ struct DPaths {
 	// compaction assigns, read coalesced by k_trace<shadow>
 	float4 *shq_o, *shq_d;        // origin p1, direction p2 - p1
 	float4 *shq_nee;              // pending direct-light contribution rgb, w = path id (uint bits)
+	// MIDirectIntegrator with several BSDF samples: the camera ray and its hit, [id][3] (ray_o, ray_d, hit), kept
+	// while the record carries the ray of the current BSDF sample
+	float4 *prim;
 };
 
 // flags in Li.w
@@ -93,6 +96,17 @@ struct DConfig {
 	// integrator plugin: 0 = path (MIPathTracer), 1 = direct (MIDirectIntegrator, direct.cpp:51-56)
 	int32_t integrator, n_lum, n_bsdf;
 	float frac_lum, frac_bsdf, weight_lum, weight_bsdf;
+	// luminaireSamples / bsdfSamples > 1: the loops of direct.cpp:129-150,163-195 run as rounds over the paths of the
+	// camera hits -- 0 one pass (both counts <= 1), 1 luminaire sample dr_index, 2 BSDF sample dr_index,
+	// 3 what follows the ray of a BSDF sample (direct.cpp:172-194)
+	int32_t dr_mode, dr_index;
+	// Sampler::request2DArray (sampler.cpp:71-74): arr_n arrays of arr_size[a] points per camera sample; element
+	// (sample j, k) of array a is entry arr_off[a] + j * arr_size[a] + k of the pixel's arr_total points
+	int32_t arr_n;
+	uint32_t arr_size[2], arr_off[2], arr_total;
+	const uint32_t *arr_scr;      // ldsampler: [slot][arr_n][2] scrambles
+	const uint16_t *arr_perm;     // ldsampler: [slot][arr_total] shuffled point indices
+	const float2 *arr_pts;        // stratified: [slot][arr_total] latin hypercube points
 	int32_t sampler_kind;
 	uint32_t spp; int32_t ld_depth;
 	int32_t strat_res;            // StratifiedSampler::m_resolution (spp = strat_res^2)
@@ -123,8 +137,12 @@ struct DQueues {
 };
 
 // --- launchers (kernels.hip) -------------------------------------------------
+// state_out (may be NULL): where the generate() stream of each slot stands after its tables
 void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_keys, uint32_t n_slots,
-                      uint32_t *scr, uint16_t *perm);
+                      uint32_t *scr, uint16_t *perm, unsigned long long *state_out);
+// the requested sample arrays of the table-based samplers (ldsampler.cpp:152-153, stratified.cpp:136-138), continuing
+// that stream; writes cfg.arr_scr / arr_perm / arr_pts
+void launch_sample_arrays(hipStream_t s, const DConfig &cfg, uint32_t n_slots, const unsigned long long *state_in);
 void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg,
                      const uint32_t *pixel_list, uint32_t n_slots, const uint32_t *explicit_samples,
                      uint32_t n_paths, uint32_t *queue);

@@ -50,7 +50,7 @@ __global__ void k_iota(uint32_t *p, uint32_t n) {
 // The tables hold the permutation; values are f(perm[j]) at lookup time.
 // ===========================================================================
 __global__ void k_ld_tables(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_slots,
-                            uint32_t *scr, uint16_t *perm) {
+                            uint32_t *scr, uint16_t *perm, unsigned long long *state_out) {
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (slot >= n_slots)
 		return;
@@ -84,6 +84,45 @@ __global__ void k_ld_tables(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_
 			p[it] = b; p[other] = a;
 		}
 	}
+	if (state_out) state_out[slot] = st;
+}
+
+// Sampler::request2DArray arrays of one pixel (one lane per sampler slot, continuing its generate() stream):
+// LowDiscrepancySampler::generate2D over all spp * size points (ldsampler.cpp:129-141,152-153) -- one 64-bit scramble
+// and a shuffle of the point indices -- or latinHypercube(random, dest, spp * size, 2) (util.cpp:529-540,
+// stratified.cpp:136-138)
+__global__ void k_sample_arrays(DConfig cfg, uint32_t n_slots, const unsigned long long *state_in,
+                                uint32_t *scr, uint16_t *perm, float2 *pts) {
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= n_slots)
+		return;
+	uint64_t st = state_in[slot];
+	for (int a = 0; a < cfg.arr_n; ++a) {
+		const uint32_t n = cfg.spp * cfg.arr_size[a];
+		if (cfg.sampler_kind == 1) {
+			const uint64_t q = keyedNext(st);
+			scr[((size_t) slot * cfg.arr_n + a) * 2 + 0] = (uint32_t) (q & 0xFFFFFFFFull);
+			scr[((size_t) slot * cfg.arr_n + a) * 2 + 1] = (uint32_t) (q >> 32);
+			uint16_t *p = perm + (size_t) slot * cfg.arr_total + cfg.arr_off[a];
+			for (uint32_t k = 0; k < n; ++k) p[k] = (uint16_t) k;
+			for (uint32_t it = n - 1; it > 0; --it) {
+				const uint32_t other = (uint32_t) keyedNextSize(st, it);
+				const uint16_t x = p[it], y = p[other];
+				p[it] = y; p[other] = x;
+			}
+		} else {
+			float *d = reinterpret_cast<float *>(pts + (size_t) slot * cfg.arr_total + cfg.arr_off[a]);
+			const float delta = 1 / (float) n;
+			for (uint32_t i = 0; i < n; ++i)
+				for (uint32_t j = 0; j < 2; ++j)
+					d[2 * i + j] = ((float) i + ulongToFloat(keyedNext(st))) * delta;
+			for (uint32_t i = 0; i < 2; ++i)
+				for (uint32_t j = 0; j < n; ++j) {
+					const uint32_t other = (uint32_t) keyedNextSize(st, n);
+					const float t = d[2 * j + i]; d[2 * j + i] = d[2 * other + i]; d[2 * other + i] = t;
+				}
+		}
+	}
 }
 
 // The same tables with the permutations shuffled in LDS ([entry][lane ^ entry]: the XOR swizzle keeps both the
@@ -91,7 +130,7 @@ __global__ void k_ld_tables(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_
 // in coalesced 128-byte rows: the serial chain of a shuffle is ~2 dependent memory accesses per step, which LDS
 // serves an order of magnitude faster than the L2.  One wave per workgroup; used while spp * 128 B fits in 64 KB.
 __global__ __launch_bounds__(64) void k_ld_tables_lds(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_slots,
-                                                      uint32_t *scr, uint16_t *perm) {
+                                                      uint32_t *scr, uint16_t *perm, unsigned long long *state_out) {
 	extern __shared__ uint16_t s_p[];
 	const uint32_t lane = threadIdx.x, slot0 = blockIdx.x * 64u, slot = slot0 + lane;
 	const bool active = slot < n_slots;
@@ -128,6 +167,7 @@ __global__ __launch_bounds__(64) void k_ld_tables_lds(DConfig cfg, const uint32_
 		}
 		__syncthreads();
 	}
+	if (active && state_out) state_out[slot] = st;
 }
 
 // ===========================================================================
@@ -205,6 +245,27 @@ __device__ __forceinline__ void sampler_next2d(const DConfig &cfg, PathSampler &
 	// x first, then y (independent.cpp:76-81)
 	x = ulongToFloat(keyedNext(s.stream));
 	y = ulongToFloat(keyedNext(s.stream));
+}
+
+// Sampler::next2DArray (sampler.cpp:76-87): point k of the array `a` of camera sample s.j.  The keyed independent
+// sampler fills its arrays from the pixel's generate() stream (independent.cpp:63-66), which is counter-based, so the
+// point is computed in place; the other two read the tables of k_sample_arrays
+__device__ __forceinline__ void sampler_array2d(const DConfig &cfg, const PathSampler &s, uint32_t pixelKey, int a, uint32_t k,
+                                                float &x, float &y) {
+	const size_t e = (size_t) cfg.arr_off[a] + (size_t) s.j * cfg.arr_size[a] + k;
+	if (cfg.sampler_kind == 0) {
+		const uint64_t st0 = keyedInit(cfg.seed, pixelKey, 0);
+		x = ulongToFloat(sm64mix(st0 + 0x9E3779B97F4A7C15ULL * (uint64_t) (2 * e + 1)));
+		y = ulongToFloat(sm64mix(st0 + 0x9E3779B97F4A7C15ULL * (uint64_t) (2 * e + 2)));
+	} else if (cfg.sampler_kind == 1) {
+		const uint32_t idx = cfg.arr_perm[(size_t) s.slot * cfg.arr_total + e];
+		const uint32_t *scr = cfg.arr_scr + ((size_t) s.slot * cfg.arr_n + a) * 2;
+		x = u32ToUnit(vdcBits(idx, scr[0]));
+		y = u32ToUnit(sobol2Bits(idx, scr[1]));
+	} else {
+		const float2 v = cfg.arr_pts[(size_t) s.slot * cfg.arr_total + e];
+		x = v.x; y = v.y;
+	}
 }
 
 // ===========================================================================
@@ -1577,9 +1638,21 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 	V3 neeV(0, 0, 0), shO(0, 0, 0), shD(0, 0, 0);      // pending direct-light term and its shadow ray
 
 	if (active) {
-		const float4 ro = ps.ray_o(id), rd = ps.ray_d(id);
+		// rounds of MIDirectIntegrator (DConfig::dr_mode): later BSDF samples start again from the camera hit
+		const int mode = cfg.dr_mode;
+		const bool skipToNee = mode == 1 && cfg.dr_index > 0, skipToBsdf = mode == 2;
+		float4 ro, rd; uint4 h;
+		if (skipToBsdf && cfg.dr_index > 0) {
+			ro = ps.prim[3 * (size_t) id]; rd = ps.prim[3 * (size_t) id + 1];
+			h = reinterpret_cast<const uint4 &>(ps.prim[3 * (size_t) id + 2]);
+		} else {
+			ro = ps.ray_o(id); rd = ps.ray_d(id); h = ps.hit(id);
+			if (skipToBsdf && cfg.n_bsdf > 1) {
+				ps.prim[3 * (size_t) id] = ro; ps.prim[3 * (size_t) id + 1] = rd;
+				ps.prim[3 * (size_t) id + 2] = reinterpret_cast<const float4 &>(h);
+			}
+		}
 		const V3 rayO(ro.x, ro.y, ro.z), rayD(rd.x, rd.y, rd.z);
-		const uint4 h = ps.hit(id);
 		const bool valid = h.w != kNoPrim;
 		float4 T4 = ps.thr(id), L4 = ps.Li(id);
 		V3 thr(T4.x, T4.y, T4.z), Li(L4.x, L4.y, L4.z);
@@ -1602,7 +1675,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 		const int shapeLum = valid ? sc.shape_lum[its.shape] : -1;
 
 		do {
-			if (flags & F_FIRST) {
+			if (skipToNee || skipToBsdf) {
+				// nothing before the sampling loops runs again
+			} else if (flags & F_FIRST) {
 				// rRec.rayIntersect (records.inl:89-105): alpha = 1 on a hit
 				flags &= ~F_FIRST;
 				if (valid) flags |= F_ALPHA;
@@ -1660,6 +1735,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 
 			// ---- head of the iteration (path.cpp:62-98) ----
 			if (!valid) {
+				if (skipToNee || skipToBsdf) break;
 				if ((flags & F_EMITTED) && sc.background_lum >= 0) {
 					const float *LP = sc.lum_params + kLumStride * (size_t) sc.background_lum;
 					const V3 le = (sc.lum_type[sc.background_lum] == 5u) ? env_le(sc, LP, normalize(rayD)) : V3(LP[0], LP[1], LP[2]);
@@ -1672,7 +1748,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 			const int bsdfIdx = sc.shape_bsdf[its.shape];
 			const float *BP = sc.bsdf_params + 16 * (size_t) bsdfIdx;
 			const bool twoSided = (sc.bsdf_type[bsdfIdx] & 0x100u) != 0;
-			if (shapeLum >= 0 && (flags & F_EMITTED)) {
+			if (shapeLum >= 0 && (flags & F_EMITTED) && !(skipToNee || skipToBsdf)) {
 				// Li += pathThroughput * its.Le(-ray.d) (path.cpp:80-81, area.cpp:62-66)
 				const float *LP = sc.lum_params + kLumStride * (size_t) shapeLum;
 				const V3 le = (dot(-rayD, its.geoN) <= 0) ? V3(0.0f, 0.0f, 0.0f) : V3(LP[0], LP[1], LP[2]);
@@ -1688,9 +1764,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 			const bool strict = cfg.strict_normals && !direct;
 
 			// ---- luminaire sampling (path.cpp:100-126) ----
-			{
+			if (!skipToBsdf) {
 				float s0, s1;
-				sampler_next2d(cfg, smp, s0, s1);
+				if (direct && cfg.n_lum > 1) sampler_array2d(cfg, smp, misc_zw.y, 0, (uint32_t) cfg.dr_index, s0, s1);   // direct.cpp:122-123
+				else sampler_next2d(cfg, smp, s0, s1);
 				LRec lRec;
 				if ((!direct || cfg.n_lum > 0) && sample_luminaire(sc, its.p, s0, s1, lRec)) {
 					const V3 wo = -lRec.d;
@@ -1715,9 +1792,13 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 				}
 			}
 
+			if (mode == 1)
+				break;                                      // a luminaire round ends here
+
 			// ---- BSDF sampling (path.cpp:128-146) ----
 			float s0, s1;
-			sampler_next2d(cfg, smp, s0, s1);
+			if (direct && cfg.n_bsdf > 1) sampler_array2d(cfg, smp, misc_zw.y, cfg.n_lum > 1 ? 1 : 0, (uint32_t) cfg.dr_index, s0, s1);   // direct.cpp:156-157
+			else sampler_next2d(cfg, smp, s0, s1);
 			if (direct && cfg.n_bsdf <= 0)
 				break;                                      // the sample is drawn even when it is not used (direct.cpp:156-161)
 			V3 woL; float bsdfPdf; uint32_t sampledType;
@@ -1907,13 +1988,19 @@ void launch_iota(hipStream_t s, uint32_t *p, uint32_t n) {
 }
 
 void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_keys, uint32_t n_slots,
-                      uint32_t *scr, uint16_t *perm) {
+                      uint32_t *scr, uint16_t *perm, unsigned long long *state_out) {
 	if (!n_slots) return;
 	const size_t lds = (size_t) cfg.spp * 64 * sizeof(uint16_t);
 	if (lds <= 64 * 1024)
-		hipLaunchKernelGGL(k_ld_tables_lds, dim3(blocks_for(n_slots, 64)), dim3(64), lds, s, cfg, pixel_keys, n_slots, scr, perm);
+		hipLaunchKernelGGL(k_ld_tables_lds, dim3(blocks_for(n_slots, 64)), dim3(64), lds, s, cfg, pixel_keys, n_slots, scr, perm, state_out);
 	else
-		hipLaunchKernelGGL(k_ld_tables, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, cfg, pixel_keys, n_slots, scr, perm);
+		hipLaunchKernelGGL(k_ld_tables, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, cfg, pixel_keys, n_slots, scr, perm, state_out);
+}
+
+void launch_sample_arrays(hipStream_t s, const DConfig &cfg, uint32_t n_slots, const unsigned long long *state_in) {
+	if (!n_slots || cfg.arr_n == 0) return;
+	hipLaunchKernelGGL(k_sample_arrays, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, cfg, n_slots, state_in,
+	                   const_cast<uint32_t *>(cfg.arr_scr), const_cast<uint16_t *>(cfg.arr_perm), const_cast<float2 *>(cfg.arr_pts));
 }
 
 void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg,

@@ -114,7 +114,7 @@ typedef struct orc_render_params {
 	uint32_t spp; int ld_depth; uint64_t seed;
 	int n_threads;                             /* OpenMP threads (0 = all) */
 	int integrator;                            /* 0 = path (MIPathTracer), 1 = direct (MIDirectIntegrator) */
-	int luminaire_samples, bsdf_samples;       /* direct.cpp:36-41; 0 or 1 each (no next2DArray)       */
+	int luminaire_samples, bsdf_samples;       /* direct.cpp:36-41; > 1: Sampler::next2DArray           */
 } orc_render_params;
 
 /* SampleIntegrator::renderBlock over a pixel rectangle [x0,x1) x [y0,y1) with the

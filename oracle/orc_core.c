@@ -210,8 +210,8 @@ static void keyed_shuffle_u32(uint64_t *st, uint32_t *a, size_t n) {
 
 /* Index form used by the renderer: scrambles [depth][3] (1D, 2D.x, 2D.y) and
  * permutations [depth][2][spp] */
-void orc_ld_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth,
-                                  uint32_t *scr, uint32_t *perm) {
+uint64_t orc_ld_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth,
+                                      uint32_t *scr, uint32_t *perm) {
 	uint64_t st = orc_keyed_init(seed, pixel_key, 0);
 	for (int i = 0; i < depth; ++i) {
 		uint32_t *p1 = perm + ((size_t) i * 2 + 0) * spp, *p2 = perm + ((size_t) i * 2 + 1) * spp;
@@ -224,11 +224,12 @@ void orc_ld_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t sp
 		for (uint32_t k = 0; k < spp; ++k) p2[k] = k;
 		keyed_shuffle_u32(&st, p2, spp);
 	}
+	return st;          /* the stream goes on with the requested sample arrays (ldsampler.cpp:149-153) */
 }
 
 /* StratifiedSampler::generate (src/samplers/stratified.cpp:121-141) with the keyed stream: the stratum permutations
  * [depth][2][spp] (1D, 2D) */
-void orc_strat_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth, uint32_t *perm) {
+uint64_t orc_strat_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth, uint32_t *perm) {
 	uint64_t st = orc_keyed_init(seed, pixel_key, 0);
 	for (int i = 0; i < depth; ++i) {
 		uint32_t *p1 = perm + ((size_t) i * 2 + 0) * spp, *p2 = perm + ((size_t) i * 2 + 1) * spp;
@@ -236,6 +237,48 @@ void orc_strat_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t
 		keyed_shuffle_u32(&st, p1, spp);
 		for (uint32_t k = 0; k < spp; ++k) p2[k] = k;
 		keyed_shuffle_u32(&st, p2, spp);
+	}
+	return st;
+}
+
+/* Sampler::request2DArray / next2DArray (src/librender/sampler.cpp:71-87): one array of `size` points per camera
+ * sample, all spp * size points of a pixel filled by generate().  The keyed samplers draw them from the pixel's
+ * generate() stream (seed, pixel, 0), which *st continues.
+ * kind 0: IndependentSampler::generate (independent.cpp:63-66): x then y per point */
+void orc_independent_generate_array(uint64_t *st, size_t n, float *out) {
+	for (size_t j = 0; j < n; ++j) {
+		out[2*j+0] = orc_ulong_to_float(orc_keyed_next(st));
+		out[2*j+1] = orc_ulong_to_float(orc_keyed_next(st));
+	}
+}
+
+/* LowDiscrepancySampler::generate2D (ldsampler.cpp:129-141): one (0,2)-sequence of n points, scrambled by the two
+ * halves of one 64-bit draw, then shuffled as points */
+void orc_ld_generate_array(uint64_t *st, size_t n, float *out) {
+	uint64_t q = orc_keyed_next(st);
+	uint32_t lo = (uint32_t) (q & 0xFFFFFFFFULL), hi = (uint32_t) (q >> 32);
+	uint32_t *perm = (uint32_t *) malloc(sizeof(uint32_t) * (n ? n : 1));
+	for (size_t k = 0; k < n; ++k) perm[k] = (uint32_t) k;
+	keyed_shuffle_u32(st, perm, n);
+	for (size_t k = 0; k < n; ++k) {
+		out[2*k+0] = orc_u32_to_unit(orc_vdc_bits(perm[k], lo));
+		out[2*k+1] = orc_u32_to_unit(orc_sobol2_bits(perm[k], hi));
+	}
+	free(perm);
+}
+
+/* latinHypercube(random, dest, nSamples, nDim = 2) (src/libcore/util.cpp:529-540), as StratifiedSampler::generate
+ * fills its 2D arrays (stratified.cpp:136-138) */
+void orc_latin_hypercube_array(uint64_t *st, size_t n, float *out) {
+	float delta = 1 / (float) n;
+	for (size_t i = 0; i < n; ++i)
+		for (size_t j = 0; j < 2; ++j)
+			out[2*i+j] = (i + orc_ulong_to_float(orc_keyed_next(st))) * delta;
+	for (size_t i = 0; i < 2; ++i) {
+		for (size_t j = 0; j < n; ++j) {
+			size_t other = (size_t) keyed_next_size(st, (uint64_t) n);
+			float tmp = out[2*j+i]; out[2*j+i] = out[2*other+i]; out[2*other+i] = tmp;
+		}
 	}
 }
 

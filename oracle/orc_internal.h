@@ -52,9 +52,12 @@ static inline void v3_normalize(float r[3], const float a[3]) {
 
 float    orc_ulong_to_float(uint64_t v);
 uint64_t orc_size_bitmask(uint64_t n);
-void     orc_ld_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth,
+uint64_t orc_ld_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth,
                                       uint32_t *scr, uint32_t *perm);
-void     orc_strat_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth, uint32_t *perm);
+uint64_t orc_strat_generate_keyed_tables(uint64_t seed, uint32_t pixel_key, uint32_t spp, int depth, uint32_t *perm);
+void     orc_independent_generate_array(uint64_t *st, size_t n, float *out);
+void     orc_ld_generate_array(uint64_t *st, size_t n, float *out);
+void     orc_latin_hypercube_array(uint64_t *st, size_t n, float *out);
 
 /* kd-tree builder (orc_kdtree.c) */
 typedef struct orc_kdtree {

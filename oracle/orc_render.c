@@ -1366,7 +1366,20 @@ typedef struct {
 	int depth, d1, d2; uint32_t spp, index;
 	const uint32_t *scr, *perm;      /* keyed tables */
 	const float *t1d, *t2d;          /* MT tables */
+	/* Sampler::m_sampleArrays2D / m_req2D / m_sampleDepth2DArray (sampler.h) */
+	const float *arr[2]; uint32_t arr_size[2]; int n_arr, adepth;
 } sampler_t;
+
+/* Sampler::next2DArray (src/librender/sampler.cpp:76-87) */
+static const float *sampler_next2d_array(sampler_t *s, uint32_t size) {
+	if (s->adepth >= s->n_arr || s->arr_size[s->adepth] != size) {
+		fprintf(stderr, "oracle: a size-%u 2D array was not requested\n", size);
+		abort();
+	}
+	const float *a = s->arr[s->adepth] + 2 * (size_t) s->index * size;
+	s->adepth++;
+	return a;
+}
 
 /* primeTable (src/libcore/util.cpp:64-122): the first 1000 primes */
 static int orc_prime(int i) {
@@ -1680,8 +1693,8 @@ static void path_li(const mtsgpu_scene *sc, const orc_render_params *prm, const 
 	res->depth = depth;
 }
 
-/* MIDirectIntegrator::Li (src/integrators/direct/direct.cpp:64-198) for a camera ray (rRec.depth == 1) with
- * luminaireSamples, bsdfSamples in {0, 1}: larger counts draw from Sampler::next2DArray, which is not restated. */
+/* MIDirectIntegrator::Li (src/integrators/direct/direct.cpp:64-198) for a camera ray (rRec.depth == 1); sample counts
+ * above one draw their points from Sampler::next2DArray (direct.cpp:122-127,156-161) */
 static void direct_li(const mtsgpu_scene *sc, const orc_render_params *prm, const ray_t *r, sampler_t *smp,
                       li_result *res, mtsgpu_stats *st) {
 	its_t its, bsdfIts;
@@ -1722,9 +1735,11 @@ static void direct_li(const mtsgpu_scene *sc, const orc_render_params *prm, cons
 		/* ---- luminaire sampling (direct.cpp:122-150): the sample is drawn even when no luminaire sample is taken ---- */
 		lrec_t lRec; memset(&lRec, 0, sizeof(lRec));
 		float sample[2];
-		sampler_next2d(smp, sample);
+		const float *sampleArray = sample;
+		if (numLuminaireSamples > 1) sampleArray = sampler_next2d_array(smp, (uint32_t) numLuminaireSamples);
+		else sampler_next2d(smp, sample);
 		for (int k = 0; k < numLuminaireSamples; ++k) {
-			if (scene_sample_luminaire(sc, its.p, &lRec, sample, st)) {
+			if (scene_sample_luminaire(sc, its.p, &lRec, sampleArray + 2 * k, st)) {
 				const float wo[3] = { -lRec.d[0], -lRec.d[1], -lRec.d[2] };
 				float woL[3] = { v3_dot(wo, its.shS), v3_dot(wo, its.shT), v3_dot(wo, its.shN) };
 				float bsdfVal[3];
@@ -1742,11 +1757,13 @@ static void direct_li(const mtsgpu_scene *sc, const orc_render_params *prm, cons
 		}
 
 		/* ---- BSDF sampling (direct.cpp:152-195) ---- */
-		sampler_next2d(smp, sample);
+		sampleArray = sample;
+		if (numBSDFSamples > 1) sampleArray = sampler_next2d_array(smp, (uint32_t) numBSDFSamples);
+		else sampler_next2d(smp, sample);
 		for (int k = 0; k < numBSDFSamples; ++k) {
 			float woL[3], bsdfPdf, bsdfVal[3];
 			uint32_t sampledType;
-			orc_bsdf_sample(btype, BP, its.wi, sample, woL, &bsdfPdf, &sampledType, bsdfVal);
+			orc_bsdf_sample(btype, BP, its.wi, sampleArray + 2 * k, woL, &bsdfPdf, &sampledType, bsdfVal);
 			if (!spec_is_zero(bsdfVal)) {
 				float ac = fabsf(woL[2]);
 				bsdfVal[0] *= ac; bsdfVal[1] *= ac; bsdfVal[2] *= ac;
@@ -1860,10 +1877,42 @@ static int put_sample(float *film, int W, int H, const tabfilter_t *filter, floa
 /* ========================================================================== */
 static uint32_t round_to_pow2(uint32_t v) { uint32_t r = 1; while (r < v) r <<= 1; return r; }
 
-/* Sampler::generate() of the two table-based samplers */
-static void sampler_generate_tables(const orc_render_params *prm, uint32_t pixelKey, uint32_t spp, int depth, uint32_t *scr, uint32_t *perm) {
-	if (prm->sampler_kind == MTSGPU_SAMPLER_STRATIFIED_KEYED) orc_strat_generate_keyed_tables(prm->seed, pixelKey, spp, depth, perm);
-	else orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);
+/* the arrays MIDirectIntegrator::configureSampler requests (direct.cpp:58-63): luminaire samples first */
+typedef struct { int n; uint32_t size[2]; float *data[2]; } sample_arrays;
+
+static int arrays_init(sample_arrays *A, const orc_render_params *prm, uint32_t spp) {
+	memset(A, 0, sizeof(*A));
+	if (prm->integrator != 1) return 0;
+	if (prm->luminaire_samples > 1) A->size[A->n++] = (uint32_t) prm->luminaire_samples;
+	if (prm->bsdf_samples > 1) A->size[A->n++] = (uint32_t) prm->bsdf_samples;
+	for (int i = 0; i < A->n; ++i) A->data[i] = (float *) malloc(sizeof(float) * 2 * (size_t) spp * A->size[i]);
+	return A->n;
+}
+static void arrays_free(sample_arrays *A) { for (int i = 0; i < A->n; ++i) free(A->data[i]); }
+static void sampler_bind_arrays(sampler_t *s, const sample_arrays *A) {
+	s->n_arr = A->n; s->adepth = 0;
+	for (int i = 0; i < A->n; ++i) { s->arr[i] = A->data[i]; s->arr_size[i] = A->size[i]; }
+}
+
+/* Sampler::generate() of the keyed samplers for one pixel: the per-pixel tables of the table-based ones, then the
+ * requested sample arrays (independent.cpp:59-70, ldsampler.cpp:143-158, stratified.cpp:121-141) */
+static void sampler_generate_tables(const orc_render_params *prm, uint32_t pixelKey, uint32_t spp, int depth, uint32_t *scr, uint32_t *perm,
+                                    sample_arrays *A) {
+	uint64_t st;
+	if (prm->sampler_kind == MTSGPU_SAMPLER_STRATIFIED_KEYED) st = orc_strat_generate_keyed_tables(prm->seed, pixelKey, spp, depth, perm);
+	else if (prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED) st = orc_ld_generate_keyed_tables(prm->seed, pixelKey, spp, depth, scr, perm);
+	else st = orc_keyed_init(prm->seed, pixelKey, 0);
+	if (!A || A->n == 0) return;
+	if (prm->sampler_kind == MTSGPU_SAMPLER_HALTON || prm->sampler_kind == MTSGPU_SAMPLER_HAMMERSLEY) {
+		fprintf(stderr, "oracle: request2DArray() is not supported by QMC samplers! (halton.cpp:102-104)\n");
+		abort();
+	}
+	for (int i = 0; i < A->n; ++i) {
+		const size_t n = (size_t) spp * A->size[i];
+		if (prm->sampler_kind == MTSGPU_SAMPLER_STRATIFIED_KEYED) orc_latin_hypercube_array(&st, n, A->data[i]);
+		else if (prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED) orc_ld_generate_array(&st, n, A->data[i]);
+		else orc_independent_generate_array(&st, n, A->data[i]);
+	}
 }
 
 static int isqrt_u32(uint32_t v) { uint32_t i = 1; while (i * i < v) ++i; return (int) i; }
@@ -1905,6 +1954,7 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 	{
 		uint32_t *scr = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 3 * (size_t) depth) : NULL;
 		uint32_t *perm = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 2 * (size_t) depth * spp) : NULL;
+		sample_arrays arrays; const int hasArrays = arrays_init(&arrays, prm, spp);
 		mtsgpu_stats st; memset(&st, 0, sizeof(st));
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1) collapse(2)
@@ -1912,10 +1962,11 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 		for (int y = y0; y < y1; ++y) {
 			for (int x = x0; x < x1; ++x) {
 				const uint32_t pixelKey = (uint32_t) y * (uint32_t) W + (uint32_t) x;
-				if (isLD)
-					sampler_generate_tables(prm, pixelKey, spp, depth, scr, perm);   /* sampler->generate() */
+				if (isLD || hasArrays)
+					sampler_generate_tables(prm, pixelKey, spp, depth, scr, perm, &arrays);   /* sampler->generate() */
 				for (uint32_t j = 0; j < spp; ++j) {
 					sampler_t smp; memset(&smp, 0, sizeof(smp));
+					sampler_bind_arrays(&smp, &arrays);
 					smp.kind = sampler_kind_of(prm);
 					smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 					smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm; smp.resolution = isqrt_u32(spp);
@@ -1932,7 +1983,7 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 			}
 		}
 		nClosest += st.rays_closest; nShadow += st.rays_shadow;
-		free(scr); free(perm);
+		free(scr); free(perm); arrays_free(&arrays);
 	}
 	if (stats) {
 		stats->camera_samples += (uint64_t) (x1 - x0) * (uint64_t) (y1 - y0) * spp;
@@ -1949,14 +2000,16 @@ void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_
 	uint32_t *scr = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 3 * (size_t) depth) : NULL;
 	uint32_t *perm = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 2 * (size_t) depth * spp) : NULL;
 	uint32_t lastKey = 0xFFFFFFFFu;
+	sample_arrays arrays; const int hasArrays = arrays_init(&arrays, prm, spp);
 	for (uint32_t i = 0; i < n; ++i) {
 		const uint32_t x = pix_samples[3*(size_t)i], y = pix_samples[3*(size_t)i+1], j = pix_samples[3*(size_t)i+2];
 		const uint32_t pixelKey = y * (uint32_t) cam->width + x;
-		if (isLD && pixelKey != lastKey) {
-			sampler_generate_tables(prm, pixelKey, spp, depth, scr, perm);
+		if ((isLD || hasArrays) && pixelKey != lastKey) {
+			sampler_generate_tables(prm, pixelKey, spp, depth, scr, perm, &arrays);
 			lastKey = pixelKey;
 		}
 		sampler_t smp; memset(&smp, 0, sizeof(smp));
+		sampler_bind_arrays(&smp, &arrays);
 		smp.kind = sampler_kind_of(prm);
 		smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 		smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm; smp.resolution = isqrt_u32(spp);
@@ -1972,7 +2025,7 @@ void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_
 		o[0] = res.Li[0]; o[1] = res.Li[1]; o[2] = res.Li[2]; o[3] = res.alpha;
 		o[4] = sample[0]; o[5] = sample[1]; o[6] = (float) res.depth; o[7] = 0.0f;
 	}
-	free(scr); free(perm);
+	free(scr); free(perm); arrays_free(&arrays);
 }
 
 /* The reference's own sequential sampling: one Random (default seed 5489, the
@@ -2126,6 +2179,7 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 		uint32_t *scr = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 3 * (size_t) depth) : NULL;
 		uint32_t *perm = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 2 * (size_t) depth * spp) : NULL;
 		tsample_t *smp = (tsample_t *) malloc(sizeof(tsample_t) * (size_t) bs * bs * spp);
+		sample_arrays arrays; const int hasArrays = arrays_init(&arrays, prm, spp);
 		mtsgpu_stats st; memset(&st, 0, sizeof(st));
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
@@ -2138,9 +2192,10 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 			for (int py = 0; py < h; ++py) for (int px = 0; px < w; ++px) {
 				/* sampler key = index of the pixel inside the rendered rectangle */
 				const uint32_t pixelKey = (uint32_t) (y0 + py - off) * (uint32_t) RW + (uint32_t) (x0 + px - off);
-				if (isLD) sampler_generate_tables(prm, pixelKey, spp, depth, scr, perm);
+				if (isLD || hasArrays) sampler_generate_tables(prm, pixelKey, spp, depth, scr, perm, &arrays);
 				for (uint32_t j = 0; j < spp; ++j) {
 					sampler_t s; memset(&s, 0, sizeof(s));
+					sampler_bind_arrays(&s, &arrays);
 					s.kind = sampler_kind_of(prm);
 					s.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
 					s.depth = depth; s.spp = spp; s.index = j; s.scr = scr; s.perm = perm; s.resolution = isqrt_u32(spp);
@@ -2196,7 +2251,7 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 			blocks[t] = blk;
 		}
 		nClosest += st.rays_closest; nShadow += st.rays_shadow;
-		free(scr); free(perm); free(smp);
+		free(scr); free(perm); free(smp); arrays_free(&arrays);
 	}
 	/* 3. Film::putImageBlock in colour order */
 	for (int colour = 0; colour < 4; ++colour)

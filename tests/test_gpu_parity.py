@@ -123,15 +123,22 @@ def test_film_matches_oracle(gpu_lib, mts, orc, name, sampler, spp):
     assert np.array_equal(film.view(np.uint32), ofilm.view(np.uint32)), "film not bit-identical (RMSE %g)" % rmse
 
 
-@pytest.mark.parametrize("name,nl,nb", [("c5_small", 1, 1), ("spheres", 1, 1), ("envlit", 1, 1), ("next_rows", 1, 0), ("c5_small", 0, 1)])
-def test_direct_integrator_matches_oracle(gpu_lib, mts, orc, name, nl, nb):
+@pytest.mark.parametrize("name,nl,nb,sampler", [
+    ("c5_small", 1, 1, "ldsampler"), ("spheres", 1, 1, "ldsampler"), ("envlit", 1, 1, "ldsampler"), ("next_rows", 1, 0, "ldsampler"),
+    ("c5_small", 0, 1, "ldsampler"),
+    # more than one sample per strategy: Sampler::next2DArray (sampler.cpp:76-87) of the three samplers that have it
+    ("c5_small", 4, 1, "ldsampler"), ("c5_small", 1, 4, "ldsampler"), ("c5_small", 3, 2, "ldsampler"), ("c5_small", 4, 0, "independent"),
+    ("c5_small", 0, 3, "stratified"), ("spheres", 2, 2, "independent"), ("envlit", 3, 3, "stratified"), ("next_rows", 5, 2, "ldsampler"),
+    ("c3_small", 2, 5, "independent"), ("c1", 8, 8, "stratified")])
+def test_direct_integrator_matches_oracle(gpu_lib, mts, orc, name, nl, nb, sampler):
     """the `direct` integrator plugin (src/integrators/direct/direct.cpp): per-sample Li and the film"""
     sd = SCENES[name](mts.scenes)
     scene = mts.Scene(sd); oscene = orc.FlatScene(sd)
     cam = mts.PerspectiveCamera.for_description(sd, 40, 32); ocam = orc.make_camera(sd, 40, 32)
     it = mts.MIDirectIntegrator(luminaireSamples=nl, bsdfSamples=nb)
-    it.preprocess(scene, cam, sampler="ldsampler", sampleCount=16, seed=11)
-    op = orc.render_params(-1, sampler=mts.abi.SAMPLER_LD_KEYED, spp=16, seed=11, integrator="direct",
+    it.preprocess(scene, cam, sampler=sampler, sampleCount=16, seed=11)
+    kind = {"independent": mts.abi.SAMPLER_INDEPENDENT_KEYED, "ldsampler": mts.abi.SAMPLER_LD_KEYED, "stratified": mts.abi.SAMPLER_STRATIFIED_KEYED}[sampler]
+    op = orc.render_params(-1, sampler=kind, spp=16, seed=11, integrator="direct",
                            luminaire_samples=nl, bsdf_samples=nb)
     rng = np.random.RandomState(3)
     ps = np.stack([rng.randint(0, 40, 3000), rng.randint(0, 32, 3000), rng.randint(0, 16, 3000)], axis=1).astype(np.uint32)
@@ -147,9 +154,12 @@ def test_direct_integrator_matches_oracle(gpu_lib, mts, orc, name, nl, nb):
     # Scene::sampleLuminaire tests visibility before the BSDF is evaluated; the wavefront only queues a shadow ray
     # when the term it guards is non-zero: fewer shadow rays, same sums
     assert st["rays_closest"] == ost.rays_closest and st["rays_shadow"] <= ost.rays_shadow and (st["rays_shadow"] > 0) == (nl > 0)
-    # unsupported sample counts are refused, not approximated
-    with pytest.raises(mts.MtsGpuError):
-        mts.MIDirectIntegrator(luminaireSamples=4).configure()
+    # the QMC samplers have no sample arrays (halton.cpp:102-104): refused like the reference refuses it
+    if nl > 1:
+        it.preprocess(scene, cam, sampler="halton", sampleCount=16, seed=11)
+        with pytest.raises(mts.MtsGpuError) as e:
+            it.render()
+        assert "not supported by QMC samplers" in str(e.value)
 
 
 def test_tile_sharding_is_exact(gpu_lib, mts, orc):

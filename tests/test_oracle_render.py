@@ -483,6 +483,67 @@ def test_direct_integrator(mts, orc):
     assert err(both) < err(bs)
 
 
+def test_sample_arrays_of_the_three_samplers(orc):
+    """Sampler::request2DArray / next2DArray (sampler.cpp:71-87) as generate() fills the arrays: plain draws
+    (independent.cpp:63-66), one shuffled (0,2)-sequence (ldsampler.cpp:129-141,152-153), latinHypercube
+    (util.cpp:529-540, stratified.cpp:136-138)"""
+    import ctypes as C
+    L = orc.lib()
+    for f in (L.orc_independent_generate_array, L.orc_ld_generate_array, L.orc_latin_hypercube_array):
+        f.argtypes = [C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_float)]; f.restype = None
+    L.orc_ulong_to_float.argtypes = [C.c_uint64]; L.orc_ulong_to_float.restype = C.c_float
+    def gen(f, n, key=(7, 11, 0)):
+        st = C.c_uint64(L.orc_keyed_init(*key)); out = np.zeros((n, 2), dtype=np.float32)
+        f(C.byref(st), n, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out, st.value
+    # independent: 2n consecutive draws of the stream, x first
+    a, end = gen(L.orc_independent_generate_array, 50)
+    st = C.c_uint64(L.orc_keyed_init(7, 11, 0))
+    exp = np.array([L.orc_ulong_to_float(L.orc_keyed_next(C.byref(st))) for _ in range(100)], dtype=np.float32).reshape(50, 2)
+    assert np.array_equal(a, exp) and end == st.value
+    # ldsampler: 64 points of a scrambled (0,2)-sequence -- one point in every elementary interval of area 1/64
+    a, _ = gen(L.orc_ld_generate_array, 64)
+    for bx in range(7):
+        cells = (np.floor(a[:, 0] * (1 << bx)).astype(int) << (6 - bx)) | np.floor(a[:, 1] * (1 << (6 - bx))).astype(int)
+        assert sorted(cells) == list(range(64)), bx
+    b, _ = gen(L.orc_ld_generate_array, 64, key=(7, 12, 0))
+    assert not np.array_equal(a, b)
+    # stratified: each coordinate visits each of the n strata exactly once, and the two are shuffled independently
+    for n in (16, 60, 256):
+        a, _ = gen(L.orc_latin_hypercube_array, n)
+        sx, sy = np.floor(a[:, 0] * n).astype(int), np.floor(a[:, 1] * n).astype(int)
+        assert sorted(sx) == list(range(n)) and sorted(sy) == list(range(n))
+        assert not np.array_equal(sx, np.arange(n)) and not np.array_equal(sx, sy)
+        assert (a >= 0).all() and (a < 1).all()
+
+
+def test_direct_integrator_with_several_samples(mts, orc):
+    """luminaireSamples / bsdfSamples > 1 (direct.cpp:129-150,163-195): the same expectation as one sample each, less
+    variance per camera sample; the weights 1/N and the sample-count fractions of the MIS terms are in place"""
+    sd = mts.scenes.cornell_c1()
+    fs = orc.FlatScene(sd)
+    cam = orc.make_camera(sd, 32, 32)
+    ref, _ = orc.render(fs.scene, cam, orc.render_params(-1, integrator="direct", sampler=mts.abi.SAMPLER_LD_KEYED, spp=1024, seed=5))
+    refimg = orc.develop(ref)
+    # pixels inside one wall: elsewhere geometric aliasing at 16 camera samples hides the noise of the estimator
+    lum = refimg.mean(axis=2); pad = np.pad(lum, 1, mode="edge")
+    loc = np.stack([pad[i:i + 32, j:j + 32] for i in range(3) for j in range(3)])
+    flat = (loc.max(0) - loc.min(0)) < 0.08 * np.maximum(lum, 1e-3)
+    assert flat.sum() > 40
+    err = {}
+    for sampler in (mts.abi.SAMPLER_INDEPENDENT_KEYED, mts.abi.SAMPLER_LD_KEYED, mts.abi.SAMPLER_STRATIFIED_KEYED):
+        for nl, nb in ((1, 1), (4, 4), (8, 0), (0, 8), (6, 2)):
+            f, st = orc.render(fs.scene, cam, orc.render_params(-1, integrator="direct", sampler=sampler, spp=16, seed=9,
+                                                                 luminaire_samples=nl, bsdf_samples=nb))
+            img = orc.develop(f)
+            assert abs(img.mean() / refimg.mean() - 1) < 0.05, (sampler, nl, nb, img.mean(), refimg.mean())
+            err[(sampler, nl, nb)] = float(np.mean((img - refimg)[flat] ** 2))
+            n = 32 * 32 * 16
+            assert st.rays_shadow <= n * max(nl, 0) and st.rays_closest <= n * (1 + nb)
+            if nl == 0: assert st.rays_shadow == 0
+        assert err[(sampler, 4, 4)] < 0.5 * err[(sampler, 1, 1)], (sampler, err)
+
+
 def test_atan2_is_faithful(orc):
     L = orc.lib()
     rng = np.random.RandomState(2)
