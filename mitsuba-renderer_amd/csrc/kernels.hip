@@ -1620,7 +1620,9 @@ __device__ __forceinline__ float mi_weight(float pdfA, float pdfB) {     // path
 // iteration (emitter hit by the BSDF sample, Russian roulette, throughput
 // update; path.cpp:171-208) runs first because it needs the new hit.
 // ===========================================================================
-template <int BT>
+// ROUNDS: the instantiation the rounds of MIDirectIntegrator use (DConfig::dr_mode != 0); the path tracer and the
+// one-sample direct integrator run the one without that code
+template <int BT, bool ROUNDS>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, BinView view) {
 	__shared__ uint32_t s_cnt[2][kShadeBlock / 64];
 	__shared__ uint32_t s_base[2];
@@ -1639,8 +1641,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 
 	if (active) {
 		// rounds of MIDirectIntegrator (DConfig::dr_mode): later BSDF samples start again from the camera hit
-		const int mode = cfg.dr_mode;
-		const bool skipToNee = mode == 1 && cfg.dr_index > 0, skipToBsdf = mode == 2;
+		const int mode = ROUNDS ? cfg.dr_mode : 0;
+		const bool skipToNee = ROUNDS && mode == 1 && cfg.dr_index > 0, skipToBsdf = ROUNDS && mode == 2;
 		float4 ro, rd; uint4 h;
 		if (skipToBsdf && cfg.dr_index > 0) {
 			ro = ps.prim[3 * (size_t) id]; rd = ps.prim[3 * (size_t) id + 1];
@@ -1766,7 +1768,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 			// ---- luminaire sampling (path.cpp:100-126) ----
 			if (!skipToBsdf) {
 				float s0, s1;
-				if (direct && cfg.n_lum > 1) sampler_array2d(cfg, smp, misc_zw.y, 0, (uint32_t) cfg.dr_index, s0, s1);   // direct.cpp:122-123
+				if (ROUNDS && direct && cfg.n_lum > 1) sampler_array2d(cfg, smp, misc_zw.y, 0, (uint32_t) cfg.dr_index, s0, s1);   // direct.cpp:122-123
 				else sampler_next2d(cfg, smp, s0, s1);
 				LRec lRec;
 				if ((!direct || cfg.n_lum > 0) && sample_luminaire(sc, its.p, s0, s1, lRec)) {
@@ -1797,7 +1799,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 
 			// ---- BSDF sampling (path.cpp:128-146) ----
 			float s0, s1;
-			if (direct && cfg.n_bsdf > 1) sampler_array2d(cfg, smp, misc_zw.y, cfg.n_lum > 1 ? 1 : 0, (uint32_t) cfg.dr_index, s0, s1);   // direct.cpp:156-157
+			if (ROUNDS && direct && cfg.n_bsdf > 1) sampler_array2d(cfg, smp, misc_zw.y, cfg.n_lum > 1 ? 1 : 0, (uint32_t) cfg.dr_index, s0, s1);   // direct.cpp:156-157
 			else sampler_next2d(cfg, smp, s0, s1);
 			if (direct && cfg.n_bsdf <= 0)
 				break;                                      // the sample is drawn even when it is not used (direct.cpp:156-161)
@@ -2051,17 +2053,20 @@ void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, co
 	const uint32_t n = view.prefix[kBinShards];
 	if (!n) return;
 	const dim3 g(blocks_for(n, kShadeBlock)), b(kShadeBlock);
+	#define MG_SHADE(BT) do { if (cfg.dr_mode != 0) hipLaunchKernelGGL((k_shade<BT, true>), g, b, 0, s, sc, ps, cfg, q, view); \
+	                          else hipLaunchKernelGGL((k_shade<BT, false>), g, b, 0, s, sc, ps, cfg, q, view); } while (0)
 	switch (bin) {
-		case 0: hipLaunchKernelGGL(k_shade<0>, g, b, 0, s, sc, ps, cfg, q, view); break;
-		case 1: hipLaunchKernelGGL(k_shade<1>, g, b, 0, s, sc, ps, cfg, q, view); break;
-		case 2: hipLaunchKernelGGL(k_shade<2>, g, b, 0, s, sc, ps, cfg, q, view); break;
-		case 3: hipLaunchKernelGGL(k_shade<3>, g, b, 0, s, sc, ps, cfg, q, view); break;
-		case 4: hipLaunchKernelGGL(k_shade<4>, g, b, 0, s, sc, ps, cfg, q, view); break;
-		case 5: hipLaunchKernelGGL(k_shade<5>, g, b, 0, s, sc, ps, cfg, q, view); break;
-		case 6: hipLaunchKernelGGL(k_shade<6>, g, b, 0, s, sc, ps, cfg, q, view); break;
-		case 7: hipLaunchKernelGGL(k_shade<7>, g, b, 0, s, sc, ps, cfg, q, view); break;
-		default: hipLaunchKernelGGL(k_shade<kNumBsdfTypes>, g, b, 0, s, sc, ps, cfg, q, view); break;
+		case 0: MG_SHADE(0); break;
+		case 1: MG_SHADE(1); break;
+		case 2: MG_SHADE(2); break;
+		case 3: MG_SHADE(3); break;
+		case 4: MG_SHADE(4); break;
+		case 5: MG_SHADE(5); break;
+		case 6: MG_SHADE(6); break;
+		case 7: MG_SHADE(7); break;
+		default: MG_SHADE(kNumBsdfTypes); break;
 	}
+	#undef MG_SHADE
 }
 
 void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,
