@@ -162,6 +162,32 @@ def test_direct_integrator_matches_oracle(gpu_lib, mts, orc, name, nl, nb, sampl
         assert "not supported by QMC samplers" in str(e.value)
 
 
+def test_direct_integrator_sample_arrays_with_tiles_and_filter(gpu_lib, mts, orc):
+    """sample arrays through the bordered-ImageBlock path (gaussian filter, highQualityEdges, several passes, tile
+    shards): the per-pixel tables follow the pixel keys of the rendered rectangle"""
+    sd = mts.scenes.cornell_c5(sphere_subdiv=2)
+    scene = mts.Scene(sd); oscene = orc.FlatScene(sd)
+    cam = mts.PerspectiveCamera.for_description(sd, 70, 50); ocam = orc.make_camera(sd, 70, 50)
+    it = mts.MIDirectIntegrator(luminaireSamples=3, bsdfSamples=2)
+    it.set_rfilter("gaussian"); of = orc.tabulate_filter("gaussian")
+    for sampler, kind in (("ldsampler", mts.abi.SAMPLER_LD_KEYED), ("stratified", mts.abi.SAMPLER_STRATIFIED_KEYED)):
+        it.preprocess(scene, cam, sampler=sampler, sampleCount=4, seed=2)
+        op = orc.render_params(-1, sampler=kind, spp=4, seed=2, integrator="direct", luminaire_samples=3, bsdf_samples=2)
+        it.set_film_edges(True); it.clear_film(); assert it.render()
+        ofilm, _ = orc.render_tiles(oscene.scene, ocam, op, of, hq_edges=True)
+        assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32)), sampler
+        it.set_options(max_paths=32 * 32 * 4); it.clear_film(); assert it.render()       # one tile per pass
+        assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32)), sampler
+        it.set_options(max_paths=0); it.set_film_edges(False)
+        acc = np.zeros((50, 70, 5), dtype=np.float32)
+        for part in range(2):
+            it.clear_film(); it.set_tiles(32, part, 2); assert it.render()
+            acc += it.film()
+        it.set_tiles(32, 0, 1)
+        o2, _ = orc.render_tiles(oscene.scene, ocam, op, of)
+        assert np.allclose(acc, o2, rtol=2e-6, atol=1e-7)
+
+
 def test_tile_sharding_is_exact(gpu_lib, mts, orc):
     """ImageBlock sharding: the union of the parts equals the unsharded film bit for bit"""
     sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "c1", W=80, H=72, sampler="ldsampler", spp=8)
