@@ -134,6 +134,7 @@ struct DQueues {
 	uint32_t leaf_min;                 // ... and its primitive loop when fewer lanes than this have leaf entries left (>= 1)
 	uint32_t static_n, dyn_slot;       // k_trace: statically dealt queue prefix; counter (line index) of the dynamic head
 	uint32_t refill_min;               // k_trace refills its idle lanes once this many are idle (1..64)
+	uint32_t batch;                    // k_trace: rays per wave and batch (64; fewer when the launch cannot fill the chip)
 };
 
 // --- launchers (kernels.hip) -------------------------------------------------

@@ -444,7 +444,7 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 	const uint32_t tid = threadIdx.x;
 	const uint32_t gtid = blockIdx.x * kTraceBlock + tid;     // spill slot of this lane
 	const uint32_t lane = lane_id();
-	const uint32_t stride = gridDim.x * kTraceBlock;
+	const uint32_t stride = gridDim.x * (kTraceBlock / 64u) * q.batch;      // queue entries per round of the grid
 	const uint32_t shard = blockIdx.x % kBinShards;     // contention on a bin counter is spread over kBinShards words
 
 	uint32_t c_inner = 0, c_leaf = 0, c_idx = 0, c_tri = 0;
@@ -457,7 +457,11 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 	// evens out the finishing times of the waves (measured: the mean wave used to live 0.90-0.94 of the kernel).
 	// A lane whose ray has finished stays idle until at least q.refill_min lanes of the wave are idle; then the
 	// finished rays are retired together (one hit store + one binning step) and the idle lanes take new rays.
-	const uint32_t first = blockIdx.x * kTraceBlock + (tid & ~63u);
+	// A launch with fewer rays than the chip has lanes runs B < 64 rays per wave (lanes >= B stay idle): a wave lasts
+	// as long as its slowest ray, and with the wave slots to spare narrower batches shorten that critical path.
+	const uint32_t B = q.batch;
+	const uint64_t limitMask = (B >= 64u) ? ~0ull : ((1ull << B) - 1ull);
+	const uint32_t first = (blockIdx.x * (kTraceBlock / 64u) + (tid >> 6)) * B;
 	const uint32_t static_n = q.static_n;   // whole rounds of the grid (or the whole queue of a small launch)
 	uint32_t next_static = first;           // queue index of this wave's next static batch (uniform)
 	uint32_t sup_base = 0, sup_left = 0;    // the chunk being handed out: queue[sup_base .. sup_base + sup_left)
@@ -481,17 +485,17 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 	while (true) {
 		const uint64_t liveMask = __builtin_amdgcn_ballot_w64(has);
 		const uint32_t nlive = (uint32_t) __popcll(liveMask);
-		const bool wantRays = nlive == 0u || 64u - nlive >= refill_min;
+		const bool wantRays = nlive == 0u || B - nlive >= refill_min;
 		if (wantRays && sup_left == 0u) {
 			// next chunk: a batch of the static share, or one claimed from the shared tail of the queue
 			if (next_static < static_n) {
-				sup_base = next_static; sup_left = (static_n - next_static < 64u) ? static_n - next_static : 64u; next_static += stride;
+				sup_base = next_static; sup_left = (static_n - next_static < B) ? static_n - next_static : B; next_static += stride;
 			} else if (!dyn_done) {
 				uint32_t b = 0;
 				if (lane == 0) b = atomicAdd(&q.counters[q.dyn_slot * kCounterStride], 1u);
 				b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
-				const unsigned long long base = (unsigned long long) static_n + 64ull * b;
-				if (base < n) { sup_base = (uint32_t) base; sup_left = (n - sup_base < 64u) ? n - sup_base : 64u; }
+				const unsigned long long base = (unsigned long long) static_n + (unsigned long long) B * b;
+				if (base < n) { sup_base = (uint32_t) base; sup_left = (n - sup_base < B) ? n - sup_base : B; }
 				else dyn_done = true;
 			}
 		}
@@ -546,9 +550,9 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 				break;          // nlive == 0 and nothing left: the wave is finished
 
 			// ---- refill: idle lane number r takes ray r of the current chunk ----
-			const uint32_t r = (uint32_t) __popcll(~liveMask & ((1ull << lane) - 1ull));
-			const bool take = !has && r < remaining;
-			const uint32_t taken = (64u - nlive < remaining) ? 64u - nlive : remaining;
+			const uint32_t r = (uint32_t) __popcll(~liveMask & limitMask & ((1ull << lane) - 1ull));
+			const bool take = !has && lane < B && r < remaining;
+			const uint32_t taken = (B - nlive < remaining) ? B - nlive : remaining;
 			const uint32_t my = sup_base + r;
 			sup_base += taken; sup_left -= taken;
 			MG_WSLOT(w_batch);
@@ -2015,11 +2019,19 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 template <int MODE, bool COUNT, bool BIN>
 static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent) {
 	// persistent grid: enough workgroups to fill every CU, never more than there are rays
-	const unsigned blocks = std::min<unsigned>(blocks_for(n, kTraceBlock), 256u * trace_blocks_per_cu(MODE));
+	const unsigned maxBlocks = 256u * trace_blocks_per_cu(MODE), wavesPerBlock = kTraceBlock / 64;
 	DQueues qq = q;
+	// rays per wave: 64, or the smallest power of two (>= 8) with which the launch still fits into one round of the
+	// persistent grid -- a launch that cannot fill the lanes of the chip trades idle lanes for shorter waves
+	static const int batchEnv = getenv("MTSGPU_BATCH") ? atoi(getenv("MTSGPU_BATCH")) : 0;
+	unsigned batch = 64;
+	if (!coherent) while (batch > 8u && (unsigned long long) (batch / 2) * wavesPerBlock * maxBlocks >= n) batch /= 2;
+	if (batchEnv >= 1 && batchEnv <= 64) batch = (unsigned) batchEnv;
+	qq.batch = batch;
+	const unsigned blocks = std::min<unsigned>(blocks_for(n, batch * wavesPerBlock), maxBlocks);
 	// static share of the queue: whole rounds of the grid; the last quarter of the rounds and the remainder are
 	// claimed dynamically (one atomic per 64-ray batch, far below the ~88 / us a single counter sustains)
-	const unsigned long long perRound = (unsigned long long) blocks * kTraceBlock;
+	const unsigned long long perRound = (unsigned long long) blocks * wavesPerBlock * batch;
 	const unsigned long long rounds = n / perRound;
 	static const int dynDiv = getenv("MTSGPU_DYNDIV") ? std::max(1, atoi(getenv("MTSGPU_DYNDIV"))) : 4;
 	// small launches stay fully static: their waves finish together and would hit the counter in one burst
@@ -2032,6 +2044,7 @@ static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, co
 		qq.desc_min = qq.leaf_min = 1;
 	if (coherent && !getenv("MTSGPU_REFILL"))
 		qq.refill_min = 64;       // neighbouring camera samples finish together: refilling would only mix batches
+	qq.refill_min = std::min(qq.refill_min, batch);
 	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, sc, ps, qq, queue, n);
 }
 
