@@ -494,5 +494,62 @@ def bunny(serialized_path, loader, material="roughglass"):
     return sd
 
 
+def fuzz(seed, n_meshes=14):
+    """Random triangle soups, spheres, materials and luminaires inside the Cornell box: shared-vertex meshes with
+    smooth normals, degenerate and duplicated triangles, axis-aligned slabs, every BSDF type with random parameters,
+    area / point / spot / constant luminaires.  Meant for parity runs (tests/test_gpu_parity.py::test_fuzz_scenes)."""
+    rng = np.random.RandomState(seed)
+    sd = SceneDescription("fuzz_%d" % seed)
+    u = lambda lo, hi, n=None: rng.uniform(lo, hi, n)
+    mats = [sd.lambertian(*u(0.1, 0.9, 3)), sd.dielectric(u(1.2, 1.8), 1.0), sd.roughmetal(u(0.05, 0.4)),
+            sd.microfacet(u(0.05, 0.4), u(0.2, 0.8), u(0.2, 0.8)), sd.mirror(u(0.5, 0.95)), sd.phong(u(5, 60), u(0.2, 0.6), u(0.1, 0.4)),
+            sd.roughglass(u(0.05, 0.3), distribution=["beckmann", "phong", "ggx"][rng.randint(3)]), sd.difftrans(u(0.2, 0.8))]
+    mats += [sd.twosided(mats[0]), sd.twosided(mats[3]), sd.twosided(mats[5])]
+    white = sd.lambertian(0.73)
+    for name, p0, e1, e2, nrm in _box_faces():
+        pos, tri = _quad(p0, e1, e2, nrm)
+        sd.add_mesh(pos, tri, bsdf=white if rng.rand() < 0.6 else mats[rng.randint(len(mats))], face_normals=True, name=name)
+    for m in range(n_meshes):
+        kind = rng.randint(5)
+        c = np.array([u(-0.8, 0.8), u(0.2, 1.7), u(-0.8, 0.8)])
+        bs = mats[rng.randint(len(mats))]
+        if kind == 0:                                    # random soup, unshared vertices, some degenerate triangles
+            nt = rng.randint(4, 60)
+            pos = (c + u(-0.25, 0.25, (nt * 3, 3))).astype(np.float32)
+            tri = np.arange(nt * 3, dtype=np.uint32).reshape(nt, 3)
+            pos[3 * (nt // 2) + 1] = pos[3 * (nt // 2)]  # two equal vertices
+            pos[3 * (nt // 3) + 2] = pos[3 * (nt // 3)] * 0.5 + pos[3 * (nt // 3) + 1] * 0.5      # collinear
+            sd.add_mesh(pos, tri, bsdf=bs, face_normals=bool(rng.randint(2)), name="soup%d" % m)
+        elif kind == 1:                                  # icosphere with smooth normals
+            pos, tri = icosphere(rng.randint(0, 3), u(0.08, 0.3), tuple(c))
+            sd.add_mesh(pos, tri, bsdf=bs, face_normals=False, name="ico%d" % m)
+        elif kind == 2:                                  # axis-aligned slab: coplanar, duplicated triangles
+            pos, tri = _quad(tuple(c), (u(0.1, 0.5), 0, 0), (0, 0, u(0.1, 0.5)), (0, 1, 0))
+            tri = np.concatenate([tri, tri])             # every triangle twice
+            sd.add_mesh(pos, tri, bsdf=bs, face_normals=True, name="slab%d" % m)
+        elif kind == 3:                                  # analytic sphere
+            sd.add_sphere(tuple(c), u(0.05, 0.3), bsdf=bs)
+        else:                                            # wavy grid with shared vertices (smooth normals)
+            n = rng.randint(3, 12)
+            gx, gz = np.meshgrid(np.linspace(-0.3, 0.3, n), np.linspace(-0.3, 0.3, n), indexing="ij")
+            gy = 0.05 * np.sin(7 * gx + seed) * np.cos(5 * gz)
+            pos = (c + np.stack([gx, gy, gz], axis=-1).reshape(-1, 3)).astype(np.float32)
+            idx = np.arange(n * n).reshape(n, n)
+            a, b, cc, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+            tri = np.concatenate([np.stack([a, b, cc], 1), np.stack([a, cc, d], 1)]).astype(np.uint32)
+            sd.add_mesh(pos, tri, bsdf=bs, face_normals=False, name="grid%d" % m)
+    _add_light(sd, intensity=float(u(5, 20)))
+    extra = rng.randint(4)
+    if extra == 0: sd.point_light((u(-0.5, 0.5), u(0.5, 1.5), u(-0.5, 0.5)), (2.0, 2.0, 1.5))
+    elif extra == 1: sd.spot_light((0.0, 1.8, 0.5), (u(-0.5, 0.5), 0.0, u(-0.5, 0.5)), (8.0, 8.0, 8.0), cutoff_deg=float(u(15, 40)))
+    elif extra == 2: sd.add_lum(abi.LUM_CONSTANT, [0.3, 0.35, 0.5])
+    else:                                                # a second area luminaire: an emitting sphere
+        lum = sd.add_lum(abi.LUM_AREA, [6.0, 5.0, 4.0])
+        sd.add_sphere((u(-0.6, 0.6), u(1.2, 1.7), u(-0.6, 0.6)), 0.08, bsdf=sd.lambertian(0.0), lum=lum)
+    sd.max_depth = int(rng.randint(3, 12))
+    sd.rr_depth = int(rng.randint(2, 6))
+    return sd
+
+
 def by_name(name, **kw):
     return {"c1": cornell_c1, "c3": cornell_c3, "c5": cornell_c5, "next": next_rows, "spheres": spheres, "envlit": envlit}[name](**kw)

@@ -188,6 +188,40 @@ def test_direct_integrator_sample_arrays_with_tiles_and_filter(gpu_lib, mts, orc
         assert np.allclose(acc, o2, rtol=2e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_fuzz_scenes(gpu_lib, mts, orc, seed):
+    """random scenes (soups with degenerate / duplicated triangles, spheres, every BSDF, mixed luminaires): both host
+    builders agree on the tree, the traversal answers and per-sample radiance agree bit for bit"""
+    sd = mts.scenes.fuzz(seed)
+    kp = mts.abi.KdParams()
+    if seed % 3 == 0: kp.exact_prim_threshold = 64                      # min-max binning phase too (on the device for seed % 6 == 0)
+    scene = mts.Scene(sd, kd_params=kp, gpu_binning=(seed % 6 == 0)); oscene = orc.FlatScene(sd, kd_params=kp)
+    a, b = scene.arrays(), oscene.arrays()
+    for k in ("kd_nodes", "kd_indices", "triaccel", "vtx_nrm", "lum_tri_cdf"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    W, H = 48, 36
+    cam = mts.PerspectiveCamera.for_description(sd, W, H); ocam = orc.make_camera(sd, W, H)
+    sampler = ["independent", "ldsampler", "stratified", "halton"][seed % 4]
+    kind = {"independent": 0, "ldsampler": 1, "halton": 2, "stratified": 4}[sampler]
+    it = mts.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth, strictNormals=bool(seed & 1))
+    it.preprocess(scene, cam, sampler=sampler, sampleCount=16, seed=seed)
+    op = orc.render_params(sd.max_depth, rr_depth=sd.rr_depth, strict_normals=int(seed & 1), sampler=kind, spp=16, seed=seed)
+    rng = np.random.RandomState(seed)
+    n = 6000
+    ps = np.stack([rng.randint(0, W, n), rng.randint(0, H, n), rng.randint(0, 16, n)], axis=1).astype(np.uint32)
+    got, exp = it.li_samples(ps), orc.li_samples(oscene.scene, ocam, op, ps)
+    bad = (got.view(np.uint32) != exp.view(np.uint32)).any(axis=1)
+    assert not bad.any(), "%d of %d samples differ; first: %s got %s exp %s" % (bad.sum(), n, ps[bad][:1], got[bad][:1], exp[bad][:1])
+    assert np.isfinite(exp[:, :3]).all() and exp[:, :3].max() > 0
+    # rays through the whole box: closest hits and occlusion
+    o = rng.uniform(-0.95, 0.95, (20000, 3)).astype(np.float32); o[:, 1] = rng.uniform(0.05, 1.95, 20000)
+    d = rng.normal(size=(20000, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, np.full((20000, 1), 1e-4, np.float32), d, np.full((20000, 1), np.inf, np.float32)], axis=1).astype(np.float32)
+    for shadow in (False, True):
+        g = it.trace_rays(rays, shadow=shadow); e = orc.trace_rays(oscene.scene, rays, shadow=shadow)
+        assert np.array_equal(np.asarray(g).view(np.uint32), np.asarray(e).view(np.uint32)), shadow
+
+
 def test_tile_sharding_is_exact(gpu_lib, mts, orc):
     """ImageBlock sharding: the union of the parts equals the unsharded film bit for bit"""
     sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "c1", W=80, H=72, sampler="ldsampler", spp=8)

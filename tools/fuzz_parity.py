@@ -1,0 +1,42 @@
+"""Parity sweep over random scenes (mitsuba-renderer_amd/scenes.py::fuzz): HIP path vs the oracle, bit for bit.
+usage: python tools/fuzz_parity.py [first_seed] [count]     (test infrastructure: uses oracle/)"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _pkgload
+mts = _pkgload.load()
+from oracle import orc
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+W, H = 40, 30
+bad_total = 0
+for seed in range(first, first + count):
+    sd = mts.scenes.fuzz(seed, n_meshes=6 + seed % 25)
+    kp = mts.abi.KdParams()
+    if seed % 3 == 0: kp.exact_prim_threshold = 32 + seed % 100
+    scene = mts.Scene(sd, kd_params=kp, gpu_binning=(seed % 2 == 0)); oscene = orc.FlatScene(sd, kd_params=kp)
+    a, b = scene.arrays(), oscene.arrays()
+    same = all(np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)) for k in ("kd_nodes", "kd_indices", "triaccel", "vtx_nrm"))
+    cam = mts.PerspectiveCamera.for_description(sd, W, H); ocam = orc.make_camera(sd, W, H)
+    sampler = ["independent", "ldsampler", "stratified", "halton", "hammersley"][seed % 5]
+    kind = {"independent": 0, "ldsampler": 1, "halton": 2, "hammersley": 3, "stratified": 4}[sampler]
+    direct = seed % 7 == 0
+    nl, nb = (1 + seed % 4, seed % 3) if direct and kind in (0, 1, 4) else (1, 1)
+    it = mts.MIDirectIntegrator(luminaireSamples=nl, bsdfSamples=nb) if direct else \
+        mts.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth, strictNormals=bool(seed & 1))
+    it.preprocess(scene, cam, sampler=sampler, sampleCount=9 if kind == 4 else 8, seed=seed)
+    op = orc.render_params(sd.max_depth, rr_depth=sd.rr_depth, strict_normals=int(seed & 1), sampler=kind, spp=9 if kind == 4 else 8, seed=seed,
+                           integrator="direct" if direct else "path", luminaire_samples=nl, bsdf_samples=nb)
+    assert it.render()
+    film = it.film()
+    ofilm, _ = orc.render(oscene.scene, ocam, op)
+    nbad = int((film.view(np.uint32) != ofilm.view(np.uint32)).any(axis=2).sum())
+    bad_total += nbad + (0 if same else 1)
+    print("seed %d: %d tris, %s%s, tree %s, %d of %d pixels differ" % (seed, sd.n_tris, sampler, " direct(%d,%d)" % (nl, nb) if direct else "",
+                                                                       "same" if same else "DIFFERENT", nbad, W * H), flush=True)
+print("TOTAL mismatches:", bad_total)
