@@ -628,6 +628,9 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 					const float split = __uint_as_float(nd.y);
 					const int axis = (int) (nd.x & 3u);
 					const uint32_t left = nd.x >> 2;            // device nodes hold the absolute index of the left child
+					// both children in one 16-byte load (sibling pairs are 16-byte aligned in the device order), issued
+					// before the case logic below instead of after it: the step is a chain of dependent fetches
+					const uint4 pair = reinterpret_cast<const uint4 *>(sc.nodes)[left >> 1];
 					if (COUNT) c_inner++;
 					MG_WSLOT(w_inner);
 					const float pen = sel3(enx, eny, enz, axis), pex = sel3(exx, exy, exz, axis);
@@ -652,12 +655,12 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 						const float distToSplit = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
 						ex_ref = (cur << 1) | farRight;
 						ex_t = distToSplit;
-						exx = ox + distToSplit * dx; exy = oy + distToSplit * dy; exz = oz + distToSplit * dz;
-						if (axis == 0) exx = split; else if (axis == 1) exy = split; else exz = split;
+						const float px = ox + distToSplit * dx, py = oy + distToSplit * dy, pz = oz + distToSplit * dz;
+						exx = (axis == 0) ? split : px; exy = (axis == 1) ? split : py; exz = (axis == 2) ? split : pz;   // selects, not branches
 						ex_node = left + farRight;
 					}
 					cur = left + side;
-					nd = sc.nodes[cur];
+					nd = side1 ? make_uint2(pair.z, pair.w) : make_uint2(pair.x, pair.y);
 					inner = !(nd.x & 0x80000000u);
 				} } while ((uint32_t) __popcll(__builtin_amdgcn_ballot_w64(inner)) >= desc_min);
 
@@ -760,8 +763,8 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 							const float split = __uint_as_float(pn.y);
 							ex_node = (pn.x >> 2) + (ref & 1u);
 							ex_t = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
-							exx = ox + ex_t * dx; exy = oy + ex_t * dy; exz = oz + ex_t * dz;
-							if (axis == 0) exx = split; else if (axis == 1) exy = split; else exz = split;
+							const float px = ox + ex_t * dx, py = oy + ex_t * dy, pz = oz + ex_t * dz;
+							exx = (axis == 0) ? split : px; exy = (axis == 1) ? split : py; exz = (axis == 2) ? split : pz;
 							ex_ref = ref;
 						}
 					}
