@@ -661,8 +661,11 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 					}
 					cur = left + side;
 					nd = side1 ? make_uint2(pair.z, pair.w) : make_uint2(pair.x, pair.y);
-					inner = !(nd.x & 0x80000000u);
-				} } while ((uint32_t) __popcll(__builtin_amdgcn_ballot_w64(inner)) >= desc_min);
+				}
+				// evaluated for all lanes after the step (a lane that did not step sits on a leaf): the flag then is one
+				// compare on the merged register instead of a value carried through the branch
+				inner = !(nd.x & 0x80000000u);
+				} while ((uint32_t) __popcll(__builtin_amdgcn_ballot_w64(inner)) >= desc_min);
 
 				if (!inner) {
 				// --- leaf: test the primitives (sahkdtree3.h:262-288, skdtree.h:244-336) ---
@@ -734,8 +737,9 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 						*mslot = prim;         // (re)writing an entry that is already there changes nothing
 						A = An;
 						++e;
-						more = (e != last) && !hitShadow;
-					} } while ((uint32_t) __popcll(__builtin_amdgcn_ballot_w64(more)) >= leaf_min);
+					}
+					more = (e != last) && !hitShadow;      // for all lanes: those that did not step have e == last or hitShadow
+					} while ((uint32_t) __popcll(__builtin_amdgcn_ballot_w64(more)) >= leaf_min);
 					e_cont = more ? e : kNoPrim;
 				}
 				bool finished = false;

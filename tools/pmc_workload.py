@@ -1,4 +1,5 @@
-"""One untimed C3 frame for counter collection: python3 tools/pmc_workload.py [spp] [res]"""
+"""One untimed C3 frame for counter collection: python3 tools/pmc_workload.py [spp] [res] [count]
+(production kernels unless the third argument is "count": the counting build spills and writes more)"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import _pkgload
@@ -10,7 +11,7 @@ scene = pkg.Scene(sd)
 cam = pkg.PerspectiveCamera.for_description(sd, res, res)
 it = pkg.MIPathTracer(maxDepth=sd.max_depth)
 it.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp, seed=0x5EED)
-it.set_options(count_traversal=True)
+it.set_options(count_traversal=(len(sys.argv) > 3 and sys.argv[3] == "count"))
 assert it.render()
 st = it.stats()
 rays = st["rays_closest"] + st["rays_shadow"]
