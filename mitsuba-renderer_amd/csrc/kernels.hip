@@ -436,15 +436,15 @@ size_t trace_spill_levels() { return kSpillLevels; }
 // the descent / primitive loops are left as soon as fewer than q.desc_min / q.leaf_min lanes still
 // need them (the others stop waiting; stragglers resume in the next round).  None of this changes
 // what is computed for a ray.
+// The body is a device function so that k_mega (below) can run it on the private batch of one wave: `first` is the
+// queue index of the wave's first batch, `stride` the distance to its next one, `static_n` the statically dealt prefix.
 template <int MODE, bool COUNT, bool BIN>
-__global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trace(DScene sc, DPaths ps, DQueues q,
-                                                          const uint32_t *queue, uint32_t n) {
-	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
-	__shared__ uint32_t s_mbox[8][kTraceBlock];
+__device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n,
+                                           const uint32_t first, const uint32_t stride, const uint32_t static_n,
+                                           uint32_t (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock]) {
 	const uint32_t tid = threadIdx.x;
 	const uint32_t gtid = blockIdx.x * kTraceBlock + tid;     // spill slot of this lane
 	const uint32_t lane = lane_id();
-	const uint32_t stride = gridDim.x * (kTraceBlock / 64u) * q.batch;      // queue entries per round of the grid
 	const uint32_t shard = blockIdx.x % kBinShards;     // contention on a bin counter is spread over kBinShards words
 
 	uint32_t c_inner = 0, c_leaf = 0, c_idx = 0, c_tri = 0;
@@ -461,8 +461,6 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 	// as long as its slowest ray, and with the wave slots to spare narrower batches shorten that critical path.
 	const uint32_t B = q.batch;
 	const uint64_t limitMask = (B >= 64u) ? ~0ull : ((1ull << B) - 1ull);
-	const uint32_t first = (blockIdx.x * (kTraceBlock / 64u) + (tid >> 6)) * B;
-	const uint32_t static_n = q.static_n;   // whole rounds of the grid (or the whole queue of a small launch)
 	uint32_t next_static = first;           // queue index of this wave's next static batch (uniform)
 	uint32_t sup_base = 0, sup_left = 0;    // the chunk being handed out: queue[sup_base .. sup_base + sup_left)
 	bool dyn_done = static_n >= n;          // nothing (left) to claim dynamically
@@ -791,6 +789,17 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 				atomicAdd(&q.trace_counts[k], x);
 		}
 	}
+}
+
+template <int MODE, bool COUNT, bool BIN>
+__global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trace(DScene sc, DPaths ps, DQueues q,
+                                                          const uint32_t *queue, uint32_t n) {
+	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
+	__shared__ uint32_t s_mbox[8][kTraceBlock];
+	const uint32_t first = (blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6)) * q.batch;
+	const uint32_t stride = gridDim.x * (kTraceBlock / 64u) * q.batch;      // queue entries per round of the grid
+	// q.static_n: whole rounds of the grid (or the whole queue of a small launch)
+	trace_body<MODE, COUNT, BIN>(sc, ps, q, queue, n, first, stride, q.static_n, s_stack, s_mbox);
 }
 
 // ===========================================================================
@@ -1633,24 +1642,12 @@ __device__ __forceinline__ float mi_weight(float pdfA, float pdfB) {     // path
 // ===========================================================================
 // ROUNDS: the instantiation the rounds of MIDirectIntegrator use (DConfig::dr_mode != 0); the path tracer and the
 // one-sample direct integrator run the one without that code
+// The iteration for ONE path (id), shared by k_shade and k_mega: what it leaves behind in registers is whether the path
+// continues and its pending direct-light term with the shadow ray that guards it.
 template <int BT, bool ROUNDS>
-__global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, BinView view) {
-	__shared__ uint32_t s_cnt[2][kShadeBlock / 64];
-	__shared__ uint32_t s_base[2];
-	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-	const bool active = gtid < view.prefix[kBinShards];
-	uint32_t id = 0u;
-	if (active) {
-		int seg = 0;
-		#pragma unroll
-		for (int k = 1; k < kBinShards; ++k)
-			if (gtid >= view.prefix[k]) seg = k;
-		id = q.bins[BT][(size_t) seg * q.bin_seg_cap + (gtid - view.prefix[seg])];
-	}
-	bool continues = false, wantShadow = false;
-	V3 neeV(0, 0, 0), shO(0, 0, 0), shD(0, 0, 0);      // pending direct-light term and its shadow ray
-
-	if (active) {
+__device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, const DConfig &cfg, const uint32_t id,
+                                           bool &continues, bool &wantShadow, V3 &neeV, V3 &shO, V3 &shD) {
+	{
 		// rounds of MIDirectIntegrator (DConfig::dr_mode): later BSDF samples start again from the camera hit
 		const int mode = ROUNDS ? cfg.dr_mode : 0;
 		const bool skipToNee = ROUNDS && mode == 1 && cfg.dr_index > 0, skipToBsdf = ROUNDS && mode == 2;
@@ -1840,6 +1837,27 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 		ps.Li(id) = make_float4(Li.x, Li.y, Li.z, __uint_as_float(flags));
 		ps.misc(id) = make_uint4((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32), misc_zw.x, misc_zw.y);
 	}
+
+}
+
+template <int BT, bool ROUNDS>
+__global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, BinView view) {
+	__shared__ uint32_t s_cnt[2][kShadeBlock / 64];
+	__shared__ uint32_t s_base[2];
+	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool active = gtid < view.prefix[kBinShards];
+	uint32_t id = 0u;
+	if (active) {
+		int seg = 0;
+		#pragma unroll
+		for (int k = 1; k < kBinShards; ++k)
+			if (gtid >= view.prefix[k]) seg = k;
+		id = q.bins[BT][(size_t) seg * q.bin_seg_cap + (gtid - view.prefix[seg])];
+	}
+	bool continues = false, wantShadow = false;
+	V3 neeV(0, 0, 0), shO(0, 0, 0), shD(0, 0, 0);      // pending direct-light term and its shadow ray
+	if (active)
+		shade_path<BT, ROUNDS>(sc, ps, cfg, id, continues, wantShadow, neeV, shO, shD);
 
 	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue.
 	// ballot + prefix popcount inside each wave, an LDS scan across the 8 waves, ONE atomic per
