@@ -4,16 +4,26 @@
 Workload (BASELINE.json configs[2]/[3], SURVEY.md 8d "C3/C4"): procedural Cornell variant with one
 1 024 000-triangle displaced walls TriMesh (lambertian), a 20 480-triangle dielectric icosphere and
 an area luminaire; `path` integrator maxDepth=16, rrDepth=10; 1024x1024, low-discrepancy sampler.
-A "step" is one full-frame render.  Weak scaling: every GPU renders 64 spp worth of samples for its
-share of the ImageBlock tiles (spp = 64*N, tiles t % N == rank), then the per-GPU films are summed
-once per step with a reduce over RCCL/xGMI (Film::putImageBlock).  Scene upload is excluded, the film
-reduce is included.  value = total camera samples / wall time.
+A "step" is one full-frame render.  Every GPU renders its share of the ImageBlock tiles (bit-reversal
+shuffled, mtsgpu_set_tiles) into a full-frame film; the films are summed once per step with a reduce over
+RCCL/xGMI (Film::putImageBlock).  Scene upload is excluded, the film reduce is included.
+value = total camera samples / wall time.
+
+Two scaling modes:
+  weak   (default)         every GPU renders 64 spp worth of samples: the frame has 64*N spp, per-GPU work constant
+  strong (--spp-total S)   the frame has S spp whatever N is (BASELINE.json configs[3] "C4": --spp-total 4096)
+
+`python bench.py --gpus N` needs no launcher: with N > 1 and no WORLD_SIZE in the environment it starts N
+worker processes itself (before anything touches a GPU) and prints rank 0's JSON line.  Under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is a worker right away.
 
 One JSON line on rank 0 (see DESIGN.md section 8 for the definition of every field)."""
 import argparse
-import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +33,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def kernel_source_hash():
+    """identifies the kernels a committed PMC traffic record belongs to"""
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "kernels.h", "devmath.h"):
+        h.update(open(os.path.join(ROOT, "mitsuba-renderer_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(st):
     """B_ray = 8 n_inner + 8 n_leaf + 4 n_idx + 48 n_tri + 48 (ray in 32 B + hit out 16 B),
     n_tri counted without mailbox credit (= index entries visited)."""
@@ -30,30 +48,121 @@ def algorithmic_bytes(st):
     return 8 * st["n_inner"] + 8 * st["n_leaf"] + 4 * st["n_idx"] + 48 * st["n_idx"] + 48 * rays
 
 
-def cpu_baseline(pkg, sd, res, spp, max_depth, seconds=15.0):
-    """The oracle (CPU restatement, kind 'port') on a bounded centre crop of the same frame,
-    all host cores (OpenMP).  Test infrastructure used as a reported baseline only."""
+def shade_algorithmic_bytes(st):
+    """k_shade, DESIGN.md section 6: per shaded path-bounce the state it must read and write (ray 32 B, hit 16 B,
+    throughput + depth 16 B, Li + flags 16 B, bsdfVal + pdf 16 B, sampler state 16 B -> 112 B read; the same minus
+    the hit written back: 96 B), the 48-byte triangle record of the hit (84 B with vertex normals, counted as 48),
+    and 48 B per shadow ray appended to the shadow queue."""
+    return st["rays_closest"] * (112 + 96 + 48) + st["rays_shadow"] * 48
+
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes show 256
+    CPUs and grant 16: cpu.max = '1600000 100000')"""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, len(os.sched_getaffinity(0)), quota
+
+
+def cpu_baseline(pkg, sd, res, spp, max_depth, seconds=12.0):
+    """The oracle (CPU restatement, kind 'port') on a bounded centre crop of the same frame: one thread, then all
+    usable cores (OpenMP), built with -O3 -march=native on this machine (SURVEY.md 8d "CPU reference timing (ii)").
+    Test infrastructure used as a reported baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
+    flags = "-O3 -march=native -ffp-contract=off"
+    try:
+        orc.use_native_build()
+        orc.lib()
+    except Exception as e:                      # no compiler on the box: the portable -O2 build
+        orc._variant = "liboracle.so"
+        flags = "-O2 -ffp-contract=off (native build failed: %s)" % type(e).__name__
+    cores, visible, quota = usable_cpus()
     oscene = orc.FlatScene(sd)
     cam = orc.make_camera(sd, res, res)
-    prm = orc.render_params(max_depth, sampler=pkg.abi.SAMPLER_LD_KEYED, spp=spp, seed=0x5EED)
-    cores = os.cpu_count() or 1
     c = res // 2
-    # calibrate on a small crop, then size the measured crop for ~`seconds` of wall time
-    t0 = time.time()
-    orc.render(oscene.scene, cam, prm, rect=(c - 8, c - 8, c + 8, c + 8))
-    rate = 16 * 16 * spp / max(time.time() - t0, 1e-3)
-    side = int(min(res, max(16, (rate * seconds / spp) ** 0.5)))
-    side -= side % 2
-    h = side // 2
-    t0 = time.time()
-    _, st = orc.render(oscene.scene, cam, prm, rect=(c - h, c - h, c + h, c + h))
-    dt = time.time() - t0
-    n = side * side * spp
-    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%dx%d-pixel centre crop of the %dx%d frame x %d spp (%d camera samples, %.1f s), oracle/liboracle.so with OpenMP"
-                      % (side, side, res, res, spp, n, dt)}
+
+    def timed(side, threads):
+        prm = orc.render_params(max_depth, sampler=pkg.abi.SAMPLER_LD_KEYED, spp=spp, seed=0x5EED, n_threads=threads)
+        h = side // 2
+        t0 = time.perf_counter()
+        _, st = orc.render(oscene.scene, cam, prm, rect=(c - h, c - h, c + h, c + h))
+        dt = time.perf_counter() - t0
+        return side * side * spp / dt, (st.rays_closest + st.rays_shadow) / dt, dt
+
+    def side_for(rate, secs):
+        s = int(min(res, max(8, (rate * secs / spp) ** 0.5)))
+        return s - s % 2
+
+    rate1, _, _ = timed(8, 1)                                           # calibration
+    s1 = side_for(rate1, seconds / 3)
+    rate1, rays1, dt1 = timed(s1, 1)
+    sN = side_for(rate1 * cores * 0.8, seconds)
+    rateN, raysN, dtN = timed(sN, cores)
+    return {"value": rateN / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "threads": cores, "visible_cpus": visible, "cgroup_cpu_quota": quota,
+            "one_thread_msamples_per_s": rate1 / 1e6,
+            "mrays_per_s_per_thread": rays1 / 1e6,
+            "mrays_per_s_per_thread_all_threads": raysN / 1e6 / cores,
+            "scaling_efficiency": rateN / (rate1 * cores),
+            "build": flags,
+            "sample": "centre crops of the %dx%d frame x %d spp: %dx%d pixels on 1 thread (%.1f s), %dx%d pixels on %d threads "
+                      "(%d camera samples, %.1f s); oracle/liboracle_native.so, OpenMP over pixels"
+                      % (res, res, spp, s1, s1, dt1, sN, sN, cores, sN * sN * spp, dtN)}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_workers(n):
+    """`python bench.py --gpus N` without a launcher: N fresh worker processes (this parent never touches a GPU and
+    never execs), one per GPU, rank 0 prints the JSON line on our stdout."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:           # one rank failed: the others would wait in the rendezvous forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
@@ -62,57 +171,78 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--res", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=64, help="samples per pixel per GPU")
+    ap.add_argument("--spp", type=int, default=64, help="weak scaling: samples per pixel per GPU (the frame has spp * N)")
+    ap.add_argument("--spp-total", type=int, default=0, help="strong scaling: samples per pixel of the frame, whatever N is (C4: 4096)")
     ap.add_argument("--grid", type=int, default=320, help="wall grid resolution (320 -> 1 024 000 triangles)")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-1spp", action="store_true", help="skip the time-to-1spp frames")
     ap.add_argument("--host-kd", action="store_true", help="kd-tree binning phase on the host instead of the GPU (same tree)")
+    ap.add_argument("--devices", default="", help="comma list: HIP device of each local rank (default: LOCAL_RANK). "
+                    "Ranks sharing a device reduce their films through gloo on host copies (test mode)")
+    ap.add_argument("--dump-film", default="", help="rank 0 writes the reduced film of the last step to this .npy file")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_workers(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     import _pkgload
     pkg = _pkgload.load()
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(world))
+    if len(devices) < world:
+        sys.exit("--devices names %d devices for %d ranks" % (len(devices), world))
+    device = devices[local_rank]
+    shared_device = len(set(devices[:world])) < world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X; libmtsgpu has no CPU path")
-    torch.cuda.set_device(local_rank)
+    if device >= torch.cuda.device_count():
+        sys.exit("rank %d: device %d requested, %d visible" % (rank, device, torch.cuda.device_count()))
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
 
     # --- scene (host side: generate, flatten, upload; not timed) ---
     sd = pkg.scenes.cornell_c3(grid=args.grid, sphere_subdiv=5)
     t0 = time.time()
-    kp = None
-    if os.environ.get("MTSGPU_KD_TRAV"):          # experiment knob: Scene property kdTraversalCost (scene.cpp:54-88)
-        kp = pkg.abi.KdParams(); kp.traversal_cost = float(os.environ["MTSGPU_KD_TRAV"])
-    scene = pkg.Scene(sd, kp, gpu_binning=not args.host_kd)
+    scene = pkg.Scene(sd, None, gpu_binning=not args.host_kd)
     flatten_s = time.time() - t0
     W = H = args.res
-    spp_total = args.spp * world
+    strong = args.spp_total > 0
+    spp_total = args.spp_total if strong else args.spp * world
     cam = pkg.PerspectiveCamera.for_description(sd, W, H)
-    it = pkg.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth, device=local_rank)
+    it = pkg.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth, device=device)
     it.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp_total, seed=0x5EED)
     it.set_tiles(32, rank, world)
     film = torch.zeros((H, W, 5), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
     it.set_stream(stream.cuda_stream)
     it.set_film_buffer(film.data_ptr(), keepalive=film)
+    host_film = torch.zeros((H, W, 5), dtype=torch.float32).pin_memory() if (world > 1 and shared_device) else None
 
     def step():
         film.zero_()
         if not it.render():
             raise RuntimeError("render cancelled")
         if world > 1:
-            pkg.filmreduce.reduce_film(film, dst=0)
+            if shared_device:                   # test mode: two ranks on one GPU cannot form an RCCL communicator
+                host_film.copy_(film)
+                pkg.filmreduce.reduce_film(host_film, dst=0)
+                if rank == 0:
+                    film.copy_(host_film)
+            else:
+                pkg.filmreduce.reduce_film(film, dst=0)
 
     def fence():
         torch.cuda.synchronize()
@@ -144,49 +274,70 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_device else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if args.dump_film and rank == 0:
+        np.save(args.dump_film, film.cpu().numpy())
 
     # --- time to a 1-spp frame (second half of BASELINE.json's metric), untimed region ---
-    it.preprocess(scene, cam, sampler="ldsampler", sampleCount=1, seed=0x5EED)
-    it.set_tiles(32, rank, world)
-    step(); fence()
-    t1 = time.perf_counter()
-    step(); fence()
-    one_spp_ms = (time.perf_counter() - t1) * 1e3
+    one_spp_ms = None
+    if not args.no_1spp:
+        it.preprocess(scene, cam, sampler="ldsampler", sampleCount=1, seed=0x5EED)
+        it.set_tiles(32, rank, world)
+        it.set_options(max_paths=args.max_paths, count_traversal=False, time_kernels=False)
+        step(); fence()
+        best = 1e30
+        for _ in range(3):
+            t1 = time.perf_counter()
+            step(); fence()
+            best = min(best, (time.perf_counter() - t1) * 1e3)
+        one_spp_ms = best
 
     if rank == 0:
-        # HBM traffic of the traversal launches from a separate PMC pass of the same frame (profiles/)
+        # HBM traffic of the traversal launches from a separate PMC pass of the same frame (profiles/); only a
+        # record taken with exactly these kernel sources counts
         traffic = None
+        traffic_note = "no PMC record for these kernel sources (tools/profile_round.sh writes profiles/*_traffic.json)"
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj["workload"] == {"grid": args.grid, "res": args.res, "spp": args.spp} and world == 1:
-                traffic = tj["hbm_bytes_per_launch"]
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+            for f in reversed(cands):
+                tj = json.load(open(os.path.join(ROOT, "profiles", f)))
+                if tj.get("kernel_source_hash") == kernel_source_hash() and world == 1 and not strong \
+                        and tj["workload"] == {"grid": args.grid, "res": args.res, "spp": args.spp}:
+                    traffic = tj["hbm_bytes_per_launch"]; traffic_note = "profiles/" + f
+                    break
         except Exception:
-            traffic = None
+            pass
         total_samples = W * H * spp_total * args.steps
         value = total_samples / elapsed / 1e6
         achieved = bytes_per_step * args.steps / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         rays = counts["rays_closest"] + counts["rays_shadow"]
+        triad = pkg.hbm_triad_gbs(device)
+        sh_bytes = shade_algorithmic_bytes(counts)
+        sh_achieved = sh_bytes * args.steps / (shade_ms * 1e-3) / 1e9 if shade_ms > 0 else 0.0
         out = {
             "metric": "Msamples/s", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "C3/C4 1M-tri Cornell: %d-tri displaced walls TriMesh + 20480-tri dielectric icosphere + area light, "
-                            "path maxDepth=%d rrDepth=%d, %dx%d, ldsampler %d spp per GPU (%d total), box filter"
-                            % (5 * 2 * args.grid * args.grid, sd.max_depth, sd.rr_depth, W, H, args.spp, spp_total),
+                "workload": "%s 1M-tri Cornell: %d-tri displaced walls TriMesh + 20480-tri dielectric icosphere + area light, "
+                            "path maxDepth=%d rrDepth=%d, %dx%d, ldsampler %s, box filter"
+                            % ("C4" if strong else "C3", 5 * 2 * args.grid * args.grid, sd.max_depth, sd.rr_depth, W, H,
+                               ("%d spp per frame (strong scaling)" % spp_total) if strong
+                               else ("%d spp per GPU (%d per frame, weak scaling)" % (args.spp, spp_total))),
                 "triangles": int(scene.sc.n_tris), "kd_nodes": int(scene.sc.n_nodes), "kd_indices": int(scene.sc.n_indices),
-                "parallelism": "ImageBlock tiles t%%%d + one RCCL film reduce per frame" % world,
+                "parallelism": "ImageBlock tiles, bit-reversed tile index %% %d + one RCCL film reduce per frame" % world,
                 "host_flatten_s": flatten_s,
             },
             "time_to_1spp_frame_ms": one_spp_ms,
+            "avg_path_length": counts.get("avg_path_length"),
             "roofline": {
                 "kernel": "k_trace (closest-hit + shadow kd-tree traversal)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                "peak_measured_triad": triad, "frac_of_triad": achieved / triad if triad else None,
                 "algorithmic_bytes_per_launch": bytes_per_step / max(counts["trace_launches"], 1),
                 "algorithmic_bytes_per_step": bytes_per_step, "bytes_per_ray": bytes_per_step / max(rays, 1),
                 "rays_per_step": rays, "launches_per_step": counts["trace_launches"],
@@ -195,10 +346,15 @@ def main():
                 "n_inner_per_ray": counts["n_inner"] / max(rays, 1), "n_leaf_per_ray": counts["n_leaf"] / max(rays, 1),
                 "n_idx_per_ray": counts["n_idx"] / max(rays, 1), "n_tri_tested_per_ray": counts["n_tri_tested"] / max(rays, 1),
             },
+            "roofline_shade": {
+                "kernel": "k_shade (one Li iteration per path: emitter hit, MIS, RR, NEE sample, BSDF sample) + k_generate + k_accumulate",
+                "bound": "hbm", "achieved": sh_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sh_achieved / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_step": sh_bytes, "ms_per_step": shade_ms / args.steps,
+            },
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, sd, args.res, args.spp, sd.max_depth)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

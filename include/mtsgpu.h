@@ -13,7 +13,10 @@
  *   (2) the host-side mirror in mitsuba-renderer_amd/ (ctypes), used by tests/ and bench.py.
  *
  * All functions return 0 on success or a negative MTSGPU_E* code;
- * mtsgpu_last_error() gives the text.  One ctx = one GPU = one host thread.
+ * mtsgpu_last_error() gives the text.  One ctx = one GPU = one host thread; a
+ * device group (mtsgpu_create_multi, below) drives several ctx -- one per GPU of the node -- from ONE host
+ * process and sums their films over xGMI, which is what a Mitsuba process needs
+ * (Scene::render calls Integrator::render once, src/librender/scene.cpp:356-359).
  */
 #ifndef MTSGPU_H
 #define MTSGPU_H
@@ -25,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MTSGPU_ABI_VERSION 3
+#define MTSGPU_ABI_VERSION 4
 
 enum {
 	MTSGPU_OK = 0,
@@ -177,12 +180,22 @@ typedef struct mtsgpu_camera {
 	float raster_to_camera[16]; /* row-major 4x4, m_rasterToCamera                            */
 	float camera_to_world[16];  /* row-major 4x4, m_cameraToWorld                             */
 	float near_clip, far_clip;  /* camera.cpp:121-123                                         */
-	int32_t width, height;      /* film size == crop size                                     */
+	int32_t width, height;      /* size of the rendered film = the crop window's size (Film::getCropSize,
+	                               film.cpp:38-41); raster_to_camera maps ITS pixel coordinates            */
 	float aperture_radius;      /* thin lens (perspective.cpp:90-103); 0 = pinhole            */
 	float focus_depth;          /* camera.cpp:164                                             */
 	int32_t kind;               /* 0 = perspective (src/cameras/perspective.cpp), 1 = orthographic
 	                               (src/cameras/orthographic.cpp:104-118: origin = rasterToCamera(sample), d = +z,
 	                               mint = 0, maxt = far - near; no lens sample)               */
+	/* Film crop window (film.cpp:33-41: cropOffsetX/Y, cropWidth/Height inside a film_width x film_height film).
+	 * The camera's raster space is that of the FULL film (perspective.cpp:52-63 scales NDC by m_film->getSize());
+	 * the work units cover the crop window only and carry its offset (renderproc.cpp:146-154, imageproc.cpp:28-52:
+	 * rect.setOffset(pos + m_offset)), so camera samples are generated at raster positions crop_offset +
+	 * [0, width) x [0, height), and the film stores pixel (x, y) of the crop window at [y][x] (mfilm.cpp:118-143).
+	 * Sampler keys are derived from the full-film pixel position: a cropped render equals the corresponding rectangle
+	 * of the full render bit for bit.  film_width / film_height == 0 means no crop (film size = width x height). */
+	int32_t crop_offset_x, crop_offset_y;
+	int32_t film_width, film_height;
 } mtsgpu_camera;
 
 /* Per-kernel-class counters/timings of the last render (measurement, section 8d) */
@@ -195,6 +208,11 @@ typedef struct mtsgpu_stats {
 	double trace_ms;     /* sum of HIP-event durations of all traversal launches        */
 	double shade_ms;     /* shade / generate / accumulate kernels                       */
 	double total_ms;     /* first launch -> last kernel end (device events)             */
+	/* the `avgPathLength` statistic of the path tracer (path.cpp:24, :212-213: avgPathLength.incrementBase() per
+	 * Li() call, += rRec.depth at its end): sum of the final depths; the average is path_length_sum / camera_samples */
+	uint64_t path_length_sum;
+	/* closest-hit launches repeated with static ray dealing because a material-queue segment overflowed */
+	uint64_t bin_overflow_retries;
 } mtsgpu_stats;
 
 typedef struct mtsgpu_ctx mtsgpu_ctx;
@@ -224,8 +242,11 @@ int  mtsgpu_set_integrator(mtsgpu_ctx *ctx, int max_depth, int rr_depth, int str
 int  mtsgpu_set_direct_integrator(mtsgpu_ctx *ctx, int luminaire_samples, int bsdf_samples);
 /* Sampler (src/samplers/{independent,ldsampler}.cpp): kind, sampleCount (LD: rounded up to pow2), LD depth, seed */
 int  mtsgpu_set_sampler(mtsgpu_ctx *ctx, int kind, uint32_t spp, int ld_depth, uint64_t seed);
-/* ImageBlock sharding (src/librender/imageproc.cpp:43-78): this ctx renders the
- * tiles t of the block_size^2 grid with (t % n_parts) == part. */
+/* ImageBlock sharding (src/librender/imageproc.cpp:43-78): this ctx renders the tiles (tx, ty) of the
+ * block_size^2 grid with morton(tx, ty) % n_parts == part (bits of tx and ty interleaved, tx lowest): with 8 parts
+ * every 4 x 2 group of tiles holds one tile of each part, so the parts sample the image on a 2-D lattice and their
+ * loads stay balanced whatever the picture shows.  The reference's own order (a spiral from the
+ * centre) only serves the preview. */
 int  mtsgpu_set_tiles(mtsgpu_ctx *ctx, int block_size, int part, int n_parts);
 /* Reconstruction filter of the film as a TabulatedFilter (src/librender/rfilter.cpp:40-69,
  * include/mitsuba/render/rfilter.h:65-102): half extents and the 16x16 table Film::getTabulatedFilter()
@@ -241,6 +262,14 @@ int  mtsgpu_set_film_buffer(mtsgpu_ctx *ctx, void *device_ptr);
 /* Tuning knobs (0 = default): paths in flight per pass; enable traversal counters */
 int  mtsgpu_set_options(mtsgpu_ctx *ctx, uint64_t max_paths, int count_traversal, int time_kernels);
 
+/* Scheduling knobs of the traversal kernel, for experiments and tests (none of them changes a result):
+ *   refill_min / desc_min / leaf_min (1..64)  lane thresholds of k_trace
+ *   batch (1..64, 0 = rule)                   rays per wave and batch
+ *   dyn_div (0 = 4)                           1/dyn_div of a large launch's rounds are claimed dynamically
+ *   sync_free (-1 rule, 0 off, 1 on)          bounce loop without host round trips (device-side counts)
+ *   test_retry (0/1)                          treat every first closest-hit launch as overflowed (exercises the retry) */
+int  mtsgpu_set_tuning(mtsgpu_ctx *ctx, const char *key, long value);
+
 /* --- the hot path (replaces SampleIntegrator::render, integrator.cpp:87-120) */
 int  mtsgpu_render(mtsgpu_ctx *ctx, volatile const int *cancel);
 int  mtsgpu_sync(mtsgpu_ctx *ctx);
@@ -248,6 +277,42 @@ int  mtsgpu_sync(mtsgpu_ctx *ctx);
 int  mtsgpu_read_film(mtsgpu_ctx *ctx, float *rgbaw);
 int  mtsgpu_clear_film(mtsgpu_ctx *ctx);
 int  mtsgpu_get_stats(mtsgpu_ctx *ctx, mtsgpu_stats *out);
+
+/* --- several GPUs in one process -------------------------------------------------------------------------
+ * A group owns one ctx per entry of devs[] (entries may repeat: two ctx on one GPU is how the single-GPU test box
+ * exercises this path).  Configuration goes to every member through mtsgpu_group_ctx(g, i) with the ordinary
+ * calls, or to all of them at once with the mtsgpu_group_* helpers; mtsgpu_group_render() then
+ *   1. gives member i the tiles of part i of n (mtsgpu_set_tiles) and clears its film,
+ *   2. renders all members concurrently, one host thread per member (SampleIntegrator::render, integrator.cpp:87-120,
+ *      with the GPUs in the role of the scheduler's workers),
+ *   3. sums the films into member 0's film (BlockedRenderProcess::processResult -> Film::putImageBlock,
+ *      src/librender/renderproc.cpp:123-130, src/films/mfilm.cpp:118-143): ONE ncclReduce(sum, f32, W*H*5, root 0)
+ *      over RCCL/xGMI when the devices are distinct and librccl can be loaded, otherwise -- and always when
+ *      `ordered_reduce` is set -- peer copies into a staging buffer on device 0 added in member order 1, 2, ...,
+ *      which makes the film independent of the collective's internal order for filters wider than a pixel.
+ * mtsgpu_read_film(mtsgpu_group_ctx(g, 0)) returns the merged film.  The group call is blocking and must not be
+ * entered concurrently; cancel is polled by every member. */
+typedef struct mtsgpu_group mtsgpu_group;
+int  mtsgpu_create_multi(int ndev, const int *devs, mtsgpu_group **out);
+void mtsgpu_group_destroy(mtsgpu_group *g);
+int  mtsgpu_group_size(const mtsgpu_group *g);
+mtsgpu_ctx *mtsgpu_group_ctx(mtsgpu_group *g, int i);
+const char *mtsgpu_group_last_error(const mtsgpu_group *g);
+/* the same call on every member (scene upload runs on all devices concurrently) */
+int  mtsgpu_group_upload_scene(mtsgpu_group *g, const mtsgpu_scene *scene);
+int  mtsgpu_group_set_camera(mtsgpu_group *g, const mtsgpu_camera *cam);
+int  mtsgpu_group_set_integrator(mtsgpu_group *g, int max_depth, int rr_depth, int strict_normals);
+int  mtsgpu_group_set_sampler(mtsgpu_group *g, int kind, uint32_t spp, int ld_depth, uint64_t seed);
+int  mtsgpu_group_set_rfilter(mtsgpu_group *g, float size_x, float size_y, const float *values);
+/* block_size as in mtsgpu_set_tiles; ordered_reduce: 0 = RCCL when possible, 1 = always the ordered peer-copy sum,
+ * 2 = RCCL or fail, also for a single member (self-test of the collective path on a one-GPU machine) */
+int  mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, volatile const int *cancel);
+/* 0 = ordered peer-copy sum, 1 = RCCL ncclReduce: what the last mtsgpu_group_render used */
+int  mtsgpu_group_last_reduce_kind(const mtsgpu_group *g);
+
+/* HBM triad a[i] = b[i] + s * c[i] over three arrays of `bytes` each on `device` (float4 lanes, best of `iters`
+ * launches): the practical bandwidth roof next to the 8 TB/s specification.  GB/s in *gbs. */
+int  mtsgpu_hbm_triad(int device, size_t bytes, int iters, double *gbs);
 
 /* --- standalone kernels exposed for parity tests and the traversal benchmark */
 /* ShapeKDTree::rayIntersect(ray, its) / (ray) on n host rays.
@@ -257,6 +322,11 @@ int  mtsgpu_trace_rays(mtsgpu_ctx *ctx, const float *rays, uint32_t n, int shado
 /* LowDiscrepancySampler::generate() for one pixel key (keyed stream), tables as f32:
  * out1d [depth][spp], out2d [depth][spp][2] */
 int  mtsgpu_ld_tables(mtsgpu_ctx *ctx, uint32_t pixel_key, float *out1d, float *out2d);
+/* What the configured Sampler hands out on the device: generate() for the pixel with key `pixel_key`, then, for camera
+ * sample `sample_index`, n calls of next1D() (two_d == 0: out[n]) or next2D() (out[2n]) (src/librender/sampler.cpp,
+ * the plugins under src/samplers).  With the halton / hammersley samplers these are the reference's own numbers: the tables of
+ * src/tests/test_samplers.cpp:33-78 are checked against this call.  n <= 4096. */
+int  mtsgpu_sampler_values(mtsgpu_ctx *ctx, uint32_t pixel_key, uint32_t sample_index, uint32_t n, int two_d, float *out);
 /* MIPathTracer::Li for explicit camera samples: in [n][3] u32 = pixel x, y, sample index;
  * out [n][8] f32 = Li rgb, alpha, raster x, raster y, depth, unused */
 int  mtsgpu_li_samples(mtsgpu_ctx *ctx, const uint32_t *pix_samples, uint32_t n, float *out);
@@ -331,6 +401,12 @@ int  mtsgpu_tabulate_filter(int kind, float half_size, float p0, float p1, float
  * transform.cpp:100-124,174-190).  fov in degrees along the smaller image side. */
 int  mtsgpu_make_camera(const float origin[3], const float target[3], const float up[3],
                         float fov_deg, int width, int height, mtsgpu_camera *out);
+/* the same camera looking through a crop window of a film_width x film_height film (perspective.cpp:52-63,
+ * film.cpp:33-41): out->width/height = crop size, out->crop_offset_* = crop offset; fov along the smaller side of
+ * the FULL film */
+int  mtsgpu_make_camera_crop(const float origin[3], const float target[3], const float up[3], float fov_deg,
+                             int film_width, int film_height, int crop_x, int crop_y, int crop_width, int crop_height,
+                             mtsgpu_camera *out);
 /* OrthographicCamera::configure (orthographic.cpp:46-82, transform.cpp:155-158) with toWorld =
  * lookAt(origin, target, up) * scale(scale_x, scale_y, 1): the view volume is 2*scale wide along its smaller side. */
 int  mtsgpu_make_camera_ortho(const float origin[3], const float target[3], const float up[3],

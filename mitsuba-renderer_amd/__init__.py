@@ -28,6 +28,10 @@ EXPORTS = [
     "mtsgpu_read_film", "mtsgpu_clear_film", "mtsgpu_get_stats", "mtsgpu_trace_rays", "mtsgpu_ld_tables",
     "mtsgpu_li_samples", "mtsgpu_flatten", "mtsgpu_flat_scene_get", "mtsgpu_flat_scene_free",
     "mtsgpu_flat_scene_kdstats", "mtsgpu_make_camera", "mtsgpu_make_camera_ortho", "mtsgpu_load_serialized", "mtsgpu_loaded_mesh_free",
+    "mtsgpu_make_camera_crop", "mtsgpu_hbm_triad", "mtsgpu_sampler_values", "mtsgpu_set_tuning",
+    "mtsgpu_create_multi", "mtsgpu_group_destroy", "mtsgpu_group_size", "mtsgpu_group_ctx", "mtsgpu_group_last_error",
+    "mtsgpu_group_upload_scene", "mtsgpu_group_set_camera", "mtsgpu_group_set_integrator", "mtsgpu_group_set_sampler",
+    "mtsgpu_group_set_rfilter", "mtsgpu_group_render", "mtsgpu_group_last_reduce_kind",
 ]
 
 
@@ -104,6 +108,22 @@ def lib():
     L.mtsgpu_make_camera_ortho.argtypes = [f32p, f32p, f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(abi.Camera)]
     L.mtsgpu_load_serialized.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(abi.Mesh)]
     L.mtsgpu_loaded_mesh_free.argtypes = [vp]; L.mtsgpu_loaded_mesh_free.restype = None
+    L.mtsgpu_make_camera_crop.argtypes = [f32p, f32p, f32p, C.c_float] + [C.c_int] * 6 + [C.POINTER(abi.Camera)]
+    L.mtsgpu_set_tuning.argtypes = [vp, C.c_char_p, C.c_long]
+    L.mtsgpu_sampler_values.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, f32p]
+    L.mtsgpu_hbm_triad.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    L.mtsgpu_create_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
+    L.mtsgpu_group_destroy.argtypes = [vp]; L.mtsgpu_group_destroy.restype = None
+    L.mtsgpu_group_size.argtypes = [vp]
+    L.mtsgpu_group_ctx.argtypes = [vp, C.c_int]; L.mtsgpu_group_ctx.restype = vp
+    L.mtsgpu_group_last_error.argtypes = [vp]; L.mtsgpu_group_last_error.restype = C.c_char_p
+    L.mtsgpu_group_upload_scene.argtypes = [vp, C.POINTER(abi.Scene)]
+    L.mtsgpu_group_set_camera.argtypes = [vp, C.POINTER(abi.Camera)]
+    L.mtsgpu_group_set_integrator.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.mtsgpu_group_set_sampler.argtypes = [vp, C.c_int, C.c_uint32, C.c_int, C.c_uint64]
+    L.mtsgpu_group_set_rfilter.argtypes = [vp, C.c_float, C.c_float, f32p]
+    L.mtsgpu_group_render.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.mtsgpu_group_last_reduce_kind.argtypes = [vp]
     _lib = L
     return L
 
@@ -161,6 +181,18 @@ class PerspectiveCamera:
         if apertureRadius > 0:                       # thin lens (camera.cpp:164-166, perspective.cpp:90-103)
             self.c.aperture_radius = apertureRadius
             self.c.focus_depth = self.c.far_clip if focusDepth is None else focusDepth
+
+    @classmethod
+    def cropped(cls, desc, film_width, film_height, crop):
+        """the camera of `desc` behind a film with a crop window (film.cpp:33-41): crop = (offsetX, offsetY, width, height)"""
+        c = desc.camera
+        self = cls.__new__(cls)
+        self.c = abi.Camera()
+        rc = lib().mtsgpu_make_camera_crop(abi.ptr(_f(c["origin"]), abi.f32p), abi.ptr(_f(c["target"]), abi.f32p), abi.ptr(_f(c["up"]), abi.f32p),
+                                           C.c_float(c["fov"]), int(film_width), int(film_height), *[int(v) for v in crop], C.byref(self.c))
+        if rc != 0:
+            raise MtsGpuError("mtsgpu_make_camera_crop: %s" % lib().mtsgpu_last_error(None).decode())
+        return self
 
     @classmethod
     def for_description(cls, desc, width, height):
@@ -256,6 +288,11 @@ class MIPathTracer:
     def set_options(self, max_paths=0, count_traversal=False, time_kernels=False):
         self._chk(lib().mtsgpu_set_options(self._ctx, int(max_paths), int(count_traversal), int(time_kernels)), "set_options")
 
+    def set_tuning(self, **knobs):
+        """scheduling knobs of the traversal kernel (mtsgpu_set_tuning); results never depend on them"""
+        for k, v in knobs.items():
+            self._chk(lib().mtsgpu_set_tuning(self._ctx, k.encode(), int(v)), "set_tuning")
+
     def set_stream(self, hip_stream):
         self._chk(lib().mtsgpu_set_stream(self._ctx, C.c_void_p(hip_stream)), "set_stream")
 
@@ -306,6 +343,13 @@ class MIPathTracer:
         self._chk(lib().mtsgpu_ld_tables(self._ctx, int(pixel_key), abi.ptr(t1, abi.f32p), abi.ptr(t2, abi.f32p)), "ld_tables")
         return t1, t2
 
+    def sampler_values(self, pixel_key, sample_index, n, two_d=False):
+        """generate() for the pixel, then n x next1D() (or next2D()) of camera sample `sample_index`, on the device"""
+        out = np.zeros((n, 2) if two_d else (n,), dtype=np.float32)
+        self._chk(lib().mtsgpu_sampler_values(self._ctx, int(pixel_key), int(sample_index), int(n), int(bool(two_d)),
+                                              abi.ptr(out, abi.f32p)), "sampler_values")
+        return out
+
     def li_samples(self, pix_samples):
         ps = np.ascontiguousarray(pix_samples, dtype=np.uint32).reshape(-1, 3)
         out = np.zeros((ps.shape[0], 8), dtype=np.float32)
@@ -322,6 +366,97 @@ class MIPathTracer:
             self.close()
         except Exception:
             pass
+
+
+class DeviceGroup:
+    """Several GPUs behind one host process (mtsgpu_create_multi): what the Mitsuba plugin uses, since Scene::render
+    calls Integrator::render once (src/librender/scene.cpp:356-359).  devices may repeat (two contexts on one GPU)."""
+
+    def __init__(self, devices, maxDepth=-1, rrDepth=10, strictNormals=False):
+        self.maxDepth, self.rrDepth, self.strictNormals = int(maxDepth), int(rrDepth), bool(strictNormals)
+        self._g = C.c_void_p()
+        self._cancel = C.c_int(0)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = lib().mtsgpu_create_multi(len(devices), devs, C.byref(self._g))
+        if rc != 0:
+            raise MtsGpuError("mtsgpu_create_multi: %s" % lib().mtsgpu_last_error(None).decode())
+        self.camera = None
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise MtsGpuError("%s: %s (code %d)" % (what, lib().mtsgpu_group_last_error(self._g).decode(), rc))
+
+    def __len__(self):
+        return lib().mtsgpu_group_size(self._g)
+
+    def member(self, i):
+        return lib().mtsgpu_group_ctx(self._g, int(i))
+
+    def preprocess(self, scene, camera, sampler="independent", sampleCount=4, depth=3, seed=0x5EED):
+        sp = scene.ptr if isinstance(scene, Scene) else scene
+        self._chk(lib().mtsgpu_group_set_integrator(self._g, self.maxDepth, self.rrDepth, int(self.strictNormals)), "set_integrator")
+        self._chk(lib().mtsgpu_group_upload_scene(self._g, sp), "upload_scene")
+        self.camera = camera
+        self._chk(lib().mtsgpu_group_set_camera(self._g, C.byref(camera.c)), "set_camera")
+        kind = {"independent": abi.SAMPLER_INDEPENDENT_KEYED, "ldsampler": abi.SAMPLER_LD_KEYED, "halton": abi.SAMPLER_HALTON,
+                "hammersley": abi.SAMPLER_HAMMERSLEY, "stratified": abi.SAMPLER_STRATIFIED_KEYED}[sampler]
+        self._chk(lib().mtsgpu_group_set_sampler(self._g, kind, int(sampleCount), int(depth), int(seed)), "set_sampler")
+        return True
+
+    def set_rfilter(self, kind="box", halfSize=-1.0, stddev=-1.0):
+        if kind == "box":
+            self._chk(lib().mtsgpu_group_set_rfilter(self._g, 0.5, 0.5, None), "set_rfilter")
+            return
+        size = np.zeros(2, dtype=np.float32); values = np.zeros(256, dtype=np.float32)
+        rc = lib().mtsgpu_tabulate_filter({"gaussian": 1, "mitchell": 2, "catmullrom": 3, "wsinc": 4}[kind], halfSize, stddev, -1.0,
+                                          abi.ptr(size, abi.f32p), abi.ptr(values, abi.f32p))
+        if rc != 0:
+            raise MtsGpuError("mtsgpu_tabulate_filter: %s" % lib().mtsgpu_last_error(None).decode())
+        self._chk(lib().mtsgpu_group_set_rfilter(self._g, float(size[0]), float(size[1]), abi.ptr(values, abi.f32p)), "set_rfilter")
+
+    def render(self, block_size=32, ordered_reduce=False):
+        self._cancel.value = 0
+        rc = lib().mtsgpu_group_render(self._g, int(block_size), int(bool(ordered_reduce)), C.byref(self._cancel))
+        if rc == -4:
+            return False
+        self._chk(rc, "group_render")
+        return True
+
+    def cancel(self):
+        self._cancel.value = 1
+
+    def reduce_kind(self):
+        return {0: "ordered peer-copy sum", 1: "rccl ncclReduce"}.get(lib().mtsgpu_group_last_reduce_kind(self._g))
+
+    def film(self):
+        out = np.zeros((self.camera.c.height, self.camera.c.width, 5), dtype=np.float32)
+        rc = lib().mtsgpu_read_film(self.member(0), abi.ptr(out, abi.f32p))
+        if rc != 0:
+            raise MtsGpuError("read_film: %s" % lib().mtsgpu_last_error(self.member(0)).decode())
+        return out
+
+    def member_stats(self, i):
+        st = abi.Stats()
+        lib().mtsgpu_get_stats(self.member(i), C.byref(st))
+        return st.as_dict()
+
+    def close(self):
+        if self._g and _lib is not None:
+            _lib.mtsgpu_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def hbm_triad_gbs(device=0, gib=1.0, iters=5):
+    """measured HBM triad bandwidth in GB/s (the practical roof next to the 8 TB/s specification), None on failure"""
+    out = C.c_double(0)
+    rc = lib().mtsgpu_hbm_triad(int(device), int(gib * (1 << 30)), int(iters), C.byref(out))
+    return float(out.value) if rc == 0 and out.value > 0 else None
 
 
 class MIDirectIntegrator(MIPathTracer):

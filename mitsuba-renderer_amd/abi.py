@@ -5,7 +5,7 @@ against the sizes the C compiler reports (mtsgpu_abi_sizeof)."""
 import ctypes as C
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET, BSDF_MIRROR, BSDF_PHONG, BSDF_ROUGHGLASS, BSDF_DIFFTRANS = 0, 1, 2, 3, 4, 5, 6, 7
 BSDF_TWOSIDED = 0x100
 BSDF_NPARAMS = 16
@@ -48,6 +48,7 @@ class Camera(C.Structure):
         ("near_clip", C.c_float), ("far_clip", C.c_float),
         ("width", C.c_int32), ("height", C.c_int32),
         ("aperture_radius", C.c_float), ("focus_depth", C.c_float), ("kind", C.c_int32),
+        ("crop_offset_x", C.c_int32), ("crop_offset_y", C.c_int32), ("film_width", C.c_int32), ("film_height", C.c_int32),
     ]
 
 
@@ -57,10 +58,14 @@ class Stats(C.Structure):
         ("n_inner", C.c_uint64), ("n_leaf", C.c_uint64), ("n_idx", C.c_uint64), ("n_tri_tested", C.c_uint64),
         ("trace_launches", C.c_uint64),
         ("trace_ms", C.c_double), ("shade_ms", C.c_double), ("total_ms", C.c_double),
+        ("path_length_sum", C.c_uint64), ("bin_overflow_retries", C.c_uint64),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        # the reference's `avgPathLength` statistic (path.cpp:24,212-213)
+        d["avg_path_length"] = self.path_length_sum / self.camera_samples if self.camera_samples else None
+        return d
 
 
 class Mesh(C.Structure):

@@ -4,6 +4,7 @@
 #include "host.h"
 #include "kernels.h"
 #include "devmath.h"
+#include "ctx.h"
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -13,63 +14,8 @@
 
 using namespace mg;
 
-namespace {
+namespace mg {
 thread_local std::string g_lastError;
-}
-
-struct mtsgpu_ctx {
-	int device = 0;
-	hipStream_t stream = nullptr;
-	bool ownStream = false;
-	std::string error;
-
-	// scene
-	bool haveScene = false;
-	DScene dsc{};
-	std::vector<void *> sceneAllocs;
-	uint32_t nTris = 0;
-
-	// configuration
-	bool haveCamera = false;
-	mtsgpu_camera cam{};
-	int maxDepth = -1, rrDepth = 10, strictNormals = 0;
-	int samplerKind = MTSGPU_SAMPLER_INDEPENDENT_KEYED;
-	uint32_t spp = 4; int ldDepth = 3; uint64_t seed = 0;
-	int blockSize = 32, part = 0, nParts = 1;
-	uint64_t maxPaths = 0; bool countTraversal = false, timeKernels = false;
-
-	// film
-	float *film = nullptr; bool ownFilm = false; size_t filmPixels = 0;
-	float filtSizeX = 0.5f, filtSizeY = 0.5f; int filtBorder = 0;
-	bool hqEdges = false;
-	int integrator = 0, nLumSamples = 1, nBsdfSamples = 1;
-	float *filtValues = nullptr;           // device [16][16]
-	TileMeta *tileMeta = nullptr; size_t tileMetaCap = 0;
-	float *blocks = nullptr; size_t blocksCap = 0;
-
-	// per-pass buffers
-	size_t pathCap = 0;
-	DPaths paths{};
-	DQueues q{};
-	uint32_t *queueA = nullptr, *queueB = nullptr;
-	uint32_t *pixelList = nullptr; size_t pixelListCap = 0;
-	uint32_t *ldScr = nullptr; uint16_t *ldPerm = nullptr; size_t ldScrCap = 0, ldPermCap = 0;
-	// Sampler::request2DArray arrays of the direct integrator (per pass, like the tables above)
-	unsigned long long *ldState = nullptr; size_t ldStateCap = 0;
-	uint32_t *arrScr = nullptr; uint16_t *arrPerm = nullptr; float2 *arrPts = nullptr; size_t arrScrCap = 0, arrPermCap = 0, arrPtsCap = 0;
-	float4 *primSave = nullptr; size_t primSaveCap = 0;
-	uint16_t *primes = nullptr;        // primeTable (util.cpp:64-122) on the device
-	uint32_t *explicitSamples = nullptr; size_t explicitCap = 0;
-	uint32_t *hostCounters = nullptr;       // pinned
-	std::vector<void *> pathAllocs;
-
-	// stats
-	mtsgpu_stats stats{};
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> traceEvents, shadeEvents;
-	size_t traceEvUsed = 0, shadeEvUsed = 0;
-};
-
-namespace {
 
 int fail(mtsgpu_ctx *ctx, int code, const char *fmt, ...) {
 	char buf[512];
@@ -78,9 +24,9 @@ int fail(mtsgpu_ctx *ctx, int code, const char *fmt, ...) {
 	if (ctx) ctx->error = buf;
 	return code;
 }
+}
 
-#define HIPCHK(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
-	return fail(ctx, MTSGPU_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+namespace {
 
 template <typename T> int devAlloc(mtsgpu_ctx *ctx, T **p, size_t count, std::vector<void *> &owner) {
 	void *raw = nullptr;
@@ -111,6 +57,31 @@ uint32_t effectiveSpp(const mtsgpu_ctx *c) {
 	return c->spp;
 }
 
+// scheduling parameters of k_trace: the defaults, or what mtsgpu_set_tuning asked for
+void applyTuning(mtsgpu_ctx *c) {
+	auto get = [&](const char *key, long dflt) { auto it = c->tuning.find(key); return it == c->tuning.end() ? dflt : it->second; };
+	c->q.refill_min = (uint32_t) get("refill_min", 32);
+	c->q.desc_min = (uint32_t) get("desc_min", 8);
+	c->q.leaf_min = (uint32_t) get("leaf_min", 8);
+	c->q.tune_refill = c->tuning.count("refill_min") ? 1u : 0u;
+	c->q.tune_batch = (uint32_t) get("batch", 0);
+	c->q.tune_dyn_div = (uint32_t) get("dyn_div", 0);
+}
+
+// size of the full film the crop window lies in (film.cpp:33-41); without a crop window the film itself
+int filmWidth(const mtsgpu_ctx *c) { return c->cam.film_width > 0 ? c->cam.film_width : c->cam.width; }
+int filmHeight(const mtsgpu_ctx *c) { return c->cam.film_height > 0 ? c->cam.film_height : c->cam.height; }
+
+// Which part renders tile (tx, ty): the bits of tx and ty interleaved (tx lowest) modulo the number of parts, so the
+// parts sample the image on a 2-D lattice (mtsgpu_set_tiles in include/mtsgpu.h; the same function lives in
+// oracle/orc_render.c and filmreduce.py)
+uint32_t tileMorton(uint32_t tx, uint32_t ty) {
+	uint32_t m = 0;
+	for (int b = 0; b < 16; ++b)
+		m |= ((tx >> b) & 1u) << (2 * b) | ((ty >> b) & 1u) << (2 * b + 1);
+	return m;
+}
+
 // the samplers whose generate() fills per-pixel tables (permutations, scrambles)
 bool samplerHasTables(const mtsgpu_ctx *c) {
 	return c->samplerKind == MTSGPU_SAMPLER_LD_KEYED || c->samplerKind == MTSGPU_SAMPLER_STRATIFIED_KEYED;
@@ -126,24 +97,24 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	int rc = 0;
 	rc |= devAlloc(c, &c->paths.base, cap * kPathSlots, o);
 	rc |= devAlloc(c, &c->paths.shq_o, cap, o); rc |= devAlloc(c, &c->paths.shq_d, cap, o); rc |= devAlloc(c, &c->paths.shq_nee, cap, o);
-	// every shard (workgroups with blockIdx % kBinShards == s) sees at most 1/kBinShards of the 256-ray
-	// batches plus one per workgroup, and all of them may land in one bin
-	const size_t segCap = cap / kBinShards + (size_t) kTraceBlock * (kTraceGridBlocks / kBinShards + 2);
+	// With static dealing every shard (workgroups with blockIdx % kBinShards == s) sees at most 1/kBinShards of the
+	// 256-ray batches plus one per workgroup, and all of them may land in one bin.  The dynamically claimed tail of a
+	// large launch (a quarter of the queue) goes to whichever waves are free, so a shard can take more than its share:
+	// a quarter of headroom covers what was ever observed; k_trace drops entries beyond the capacity and
+	// traceAndBin() repeats such a launch with static dealing, for which the bound holds by construction.
+	const unsigned gridBlocksMax = c->nCUs * kTraceBlocksPerCuMax;
+	const size_t segCap = cap / kBinShards + cap / (4 * kBinShards) + (size_t) kTraceBlock * (gridBlocksMax / kBinShards + 2);
 	for (int b = 0; b < kNumBins; ++b) rc |= devAlloc(c, &c->q.bins[b], segCap * kBinShards, o);
 	c->q.bin_seg_cap = (uint32_t) segCap;
 	rc |= devAlloc(c, &c->queueA, cap, o); rc |= devAlloc(c, &c->queueB, cap, o);
 	rc |= devAlloc(c, &c->q.shadow, cap, o);
 	rc |= devAlloc(c, &c->q.counters, kNumCounters * kCounterStride, o);
 	rc |= devAlloc(c, &c->q.trace_counts, 8, o);
-	rc |= devAlloc(c, &c->q.spill, (size_t) kTraceGridBlocks * kTraceBlock * trace_spill_levels(), o);
+	rc |= devAlloc(c, &c->q.spill, (size_t) gridBlocksMax * kTraceBlock * trace_spill_levels(), o);
 	if (rc) return rc;
-	c->q.spill_stride = kTraceGridBlocks * kTraceBlock;
-	c->q.refill_min = 32;
-	c->q.desc_min = 8;
-	c->q.leaf_min = 8;
-	if (const char *e = getenv("MTSGPU_LEAFMIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->q.leaf_min = (uint32_t) v; }
-	if (const char *e = getenv("MTSGPU_DESCMIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->q.desc_min = (uint32_t) v; }
-	if (const char *e = getenv("MTSGPU_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) c->q.refill_min = (uint32_t) v; }
+	c->q.spill_stride = gridBlocksMax * kTraceBlock;
+	c->q.n_cus = c->nCUs; c->q.force_static = 0;
+	applyTuning(c);
 	HIPCHK(c, hipMemset(c->q.trace_counts, 0, 8 * sizeof(unsigned long long)));
 	c->pathCap = cap;
 	return 0;
@@ -166,7 +137,8 @@ DConfig makeConfig(const mtsgpu_ctx *c, bool slotPerPath) {
 	cfg.near_clip = c->cam.near_clip; cfg.far_clip = c->cam.far_clip;
 	cfg.aperture_radius = c->cam.aperture_radius; cfg.focus_depth = c->cam.focus_depth; cfg.camera_kind = c->cam.kind;
 	cfg.width = c->cam.width; cfg.height = c->cam.height;
-	cfg.pix_w = c->cam.width; cfg.pix_off = 0;
+	cfg.crop_x = c->cam.crop_offset_x; cfg.crop_y = c->cam.crop_offset_y;
+	cfg.pix_w = filmWidth(c); cfg.pix_off = 0;
 	cfg.max_depth = c->maxDepth; cfg.rr_depth = c->rrDepth; cfg.strict_normals = c->strictNormals;
 	cfg.integrator = c->integrator; cfg.n_lum = c->nLumSamples; cfg.n_bsdf = c->nBsdfSamples;
 	// MIDirectIntegrator::configure (direct.cpp:51-56)
@@ -232,6 +204,42 @@ int readCounters(mtsgpu_ctx *c) {
 	return 0;
 }
 
+
+// Closest-hit launch over queue[0..n) with the material sort, then the per-bin segment sizes (one blocking read of the
+// counters).  A shard segment that overflowed (possible only with dynamically claimed batches, see ensurePaths) makes
+// the launch run again with static dealing: tracing a ray twice writes the same hit twice.
+int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent, BinView *views) {
+	hipStream_t s = c->stream;
+	const size_t counterBytes = kNumCounters * kCounterStride * sizeof(uint32_t);
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		if (attempt) HIPCHK(c, hipMemsetAsync(c->q.counters, 0, counterBytes, s));
+		c->q.force_static = attempt ? 1u : 0u;
+		hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
+		if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
+		launch_trace(s, 0, c->countTraversal && attempt == 0, true, c->dsc, c->paths, c->q, queue, n, coherent);
+		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
+		c->q.force_static = 0;
+		HIPCHK(c, hipGetLastError());
+		c->stats.trace_launches++;
+		int rc = readCounters(c); if (rc) return rc;
+		bool overflow = false;
+		for (int b = 0; b < kNumBins; ++b) {
+			uint32_t acc = 0;
+			for (int k = 0; k < kBinShards; ++k) {
+				views[b].prefix[k] = acc;
+				const uint32_t cnt = c->hostCounters[(b * kBinShards + k) * kCounterStride];
+				if (cnt > c->q.bin_seg_cap) overflow = true;
+				acc += cnt;
+			}
+			views[b].prefix[kBinShards] = acc;
+		}
+		if (attempt == 0 && c->tuning.count("test_retry") && c->tuning["test_retry"]) overflow = true;   // exercises the retry (tests)
+		if (!overflow) return 0;
+		c->stats.bin_overflow_retries++;
+	}
+	return fail(c, MTSGPU_EHIP, "internal: bin segment overflow with static dealing");
+}
+
 // MIDirectIntegrator with more than one sample per strategy (direct.cpp:129-150,163-195): after the camera rays are
 // traced and sorted by material, the two sampling loops run as rounds over those queues -- round j of the first loop
 // shades with luminaire sample j and traces its shadow rays, round j of the second loop shades with BSDF sample j,
@@ -252,20 +260,9 @@ int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatil
 	};
 	HIPCHK(c, hipMemsetAsync(c->q.counters, 0, counterBytes, s));
 	c->q.next = c->queueB;
-	int rc = timedTrace(0, true, c->queueA, nPaths, true); if (rc) return rc;
-	c->stats.rays_closest += nPaths;
-	rc = readCounters(c); if (rc) return rc;
 	BinView views[kNumBins];
-	for (int b = 0; b < kNumBins; ++b) {
-		uint32_t acc = 0;
-		for (int k = 0; k < kBinShards; ++k) {
-			views[b].prefix[k] = acc;
-			const uint32_t cnt = c->hostCounters[(b * kBinShards + k) * kCounterStride];
-			if (cnt > c->q.bin_seg_cap) return fail(c, MTSGPU_EHIP, "internal: bin segment overflow");
-			acc += cnt;
-		}
-		views[b].prefix[kBinShards] = acc;
-	}
+	int rc = traceAndBin(c, c->queueA, nPaths, true, views); if (rc) return rc;
+	c->stats.rays_closest += nPaths;
 	auto shadeRound = [&](int mode, int index, bool withTerminal) -> int {
 		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
 		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, counterBytes, s));     // the bins stay as they are; views[] holds their sizes
@@ -325,28 +322,12 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, kNumCounters * kCounterStride * sizeof(uint32_t), s));
 		c->q.next = nxt;
 		// closest hit + material sort
-		hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
-		if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
-		launch_trace(s, 0, c->countTraversal, true, c->dsc, c->paths, c->q, cur, nQ, first);
-		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
-		HIPCHK(c, hipGetLastError());
-		c->stats.rays_closest += nQ; c->stats.trace_launches++;
-		HIPCHK(c, hipMemcpyAsync(c->hostCounters, c->q.counters, kNumCounters * kCounterStride * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-		HIPCHK(c, hipStreamSynchronize(s));
+		BinView views[kNumBins];
+		int rc = traceAndBin(c, cur, nQ, first, views); if (rc) return rc;
+		c->stats.rays_closest += nQ;
 		// shade, one launch per BSDF type
 		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
 		if (sev) HIPCHK(c, hipEventRecord(sev[0], s));
-		BinView views[kNumBins];
-		for (int b = 0; b < kNumBins; ++b) {
-			uint32_t acc = 0;
-			for (int k = 0; k < kBinShards; ++k) {
-				views[b].prefix[k] = acc;
-				const uint32_t cnt = c->hostCounters[(b * kBinShards + k) * kCounterStride];
-				if (cnt > c->q.bin_seg_cap) return fail(c, MTSGPU_EHIP, "internal: bin segment overflow");
-				acc += cnt;
-			}
-			views[b].prefix[kBinShards] = acc;
-		}
 		for (int b = 0; b < kNumBins; ++b)
 			launch_shade(s, b, c->dsc, c->paths, cfg, c->q, views[b]);
 		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
@@ -445,10 +426,14 @@ int mtsgpu_create(int device, mtsgpu_ctx **out) {
 	HIPCHK(nullptr, hipSetDevice(device));
 	mtsgpu_ctx *c = new mtsgpu_ctx();
 	c->device = device;
+	c->nCUs = (uint32_t) std::max(1, prop.multiProcessorCount);
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(nullptr, MTSGPU_EHIP, "hipStreamCreate failed"); }
 	c->ownStream = true;
-	if (hipHostMalloc((void **) &c->hostCounters, kNumCounters * kCounterStride * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+	if (hipHostMalloc((void **) &c->hostCounters, (kNumCounters * kCounterStride + 4) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
 		(void) hipStreamDestroy(c->stream); delete c; return fail(nullptr, MTSGPU_EHIP, "hipHostMalloc failed");
+	}
+	if (hipMalloc((void **) &c->pathLen, sizeof(unsigned long long)) != hipSuccess) {
+		mtsgpu_destroy(c); return fail(nullptr, MTSGPU_EHIP, "hipMalloc failed");
 	}
 	{
 		// the first 1000 primes (primeTable, src/libcore/util.cpp:64-122) for the halton / hammersley samplers
@@ -482,6 +467,7 @@ void mtsgpu_destroy(mtsgpu_ctx *c) {
 	if (c->arrPts) (void) hipFree(c->arrPts);
 	if (c->primSave) (void) hipFree(c->primSave);
 	if (c->primes) (void) hipFree(c->primes);
+	if (c->pathLen) (void) hipFree(c->pathLen);
 	if (c->explicitSamples) (void) hipFree(c->explicitSamples);
 	if (c->filtValues) (void) hipFree(c->filtValues);
 	if (c->tileMeta) (void) hipFree(c->tileMeta);
@@ -517,6 +503,27 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 			const uint64_t left = (uint64_t) i + ((a & 0x3FFFFFFCu) >> 2);
 			if ((a & 3u) == 3u || left <= i || left + 1 >= sc->n_nodes) return fail(c, MTSGPU_EINVAL, "kd node %u: bad axis/child offset", i);
 		}
+	}
+	{
+		// every node is reached exactly once from the root (the device order below is built by walking the tree: an
+		// unreached node would land on the root's slot, a shared one twice) and no branch is deeper than the traversal
+		// stack of k_trace (LDS levels + spill levels; the reference's own limit is MTS_KD_MAXDEPTH = 48, gkdtree.h:35)
+		const uint32_t depthLimit = (uint32_t) trace_stack_levels() - 2;
+		std::vector<uint8_t> seen(sc->n_nodes, 0);
+		std::vector<std::pair<uint32_t, uint32_t>> stack;       // node, depth
+		stack.emplace_back(0u, 1u);
+		uint32_t visited = 0;
+		while (!stack.empty()) {
+			const auto [i, depth] = stack.back(); stack.pop_back();
+			if (seen[i]) return fail(c, MTSGPU_EINVAL, "kd node %u is the child of two nodes", i);
+			seen[i] = 1; ++visited;
+			const uint32_t a = sc->kd_nodes[2 * (size_t) i];
+			if (a & 0x80000000u) continue;
+			if (depth >= depthLimit) return fail(c, MTSGPU_EINVAL, "kd-tree deeper than %u levels", depthLimit);
+			const uint32_t left = i + ((a & 0x3FFFFFFCu) >> 2);
+			stack.emplace_back(left + 1, depth + 1); stack.emplace_back(left, depth + 1);
+		}
+		if (visited != sc->n_nodes) return fail(c, MTSGPU_EINVAL, "kd-tree: %u of %u nodes are unreachable from the root", sc->n_nodes - visited, sc->n_nodes);
 	}
 	for (uint32_t i = 0; i < sc->n_indices; ++i)
 		if (sc->kd_indices[i] >= sc->n_tris) return fail(c, MTSGPU_EINVAL, "kd index %u out of range", i);
@@ -723,6 +730,14 @@ int mtsgpu_set_camera(mtsgpu_ctx *c, const mtsgpu_camera *cam) {
 	if (cam->width <= 0 || cam->height <= 0 || (uint64_t) cam->width * (uint64_t) cam->height > 0x7FFFFFFFull)
 		return fail(c, MTSGPU_EINVAL, "bad film size %dx%d", cam->width, cam->height);
 	if (cam->kind != 0 && cam->kind != 1) return fail(c, MTSGPU_EINVAL, "unknown camera kind %d", cam->kind);
+	if (cam->film_width != 0 || cam->film_height != 0 || cam->crop_offset_x != 0 || cam->crop_offset_y != 0) {
+		// "Invalid crop window specification!" (film.cpp:41-45)
+		if (cam->crop_offset_x < 0 || cam->crop_offset_y < 0 || cam->film_width <= 0 || cam->film_height <= 0
+		    || (int64_t) cam->crop_offset_x + cam->width > cam->film_width || (int64_t) cam->crop_offset_y + cam->height > cam->film_height
+		    || (uint64_t) cam->film_width * (uint64_t) cam->film_height > 0x7FFFFFFFull)
+			return fail(c, MTSGPU_EINVAL, "invalid crop window %dx%d at (%d, %d) of a %dx%d film", cam->width, cam->height,
+			            cam->crop_offset_x, cam->crop_offset_y, cam->film_width, cam->film_height);
+	}
 	c->cam = *cam; c->haveCamera = true;
 	return 0;
 }
@@ -820,6 +835,21 @@ int mtsgpu_set_film_buffer(mtsgpu_ctx *c, void *device_ptr) {
 	return 0;
 }
 
+int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
+	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
+	struct Knob { const char *key; long lo, hi; };
+	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 } };
+	for (const Knob &k : knobs)
+		if (std::strcmp(k.key, key) == 0) {
+			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);
+			c->tuning[key] = value;
+			applyTuning(c);
+			return 0;
+		}
+	return fail(c, MTSGPU_EINVAL, "unknown tuning knob '%s'", key);
+}
+
 int mtsgpu_set_options(mtsgpu_ctx *c, uint64_t max_paths, int count_traversal, int time_kernels) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
 	c->maxPaths = max_paths; c->countTraversal = count_traversal != 0; c->timeKernels = time_kernels != 0;
@@ -863,17 +893,21 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	const int off = c->hqEdges ? -c->filtBorder : 0;
 	const int RW = W - 2 * off, RH = H - 2 * off;
 	const int tx = (RW + bs - 1) / bs, ty = (RH + bs - 1) / bs;
+	// keys: index of the raster pixel in the (full film + border) grid; the crop window only moves the rectangle
+	const int cx = c->cam.crop_offset_x, cy = c->cam.crop_offset_y;
+	const int keyW = filmWidth(c) - 2 * off;
+	if ((uint64_t) keyW * (uint64_t) (filmHeight(c) - 2 * off) > 0xFFFFFFFFull) return fail(c, MTSGPU_EINVAL, "film too large");
 	for (int t = 0; t < tx * ty; ++t) {
-		if (t % c->nParts != c->part) continue;
-		const int x0 = off + (t % tx) * bs, y0 = off + (t / tx) * bs;
+		if (tileMorton((uint32_t) (t % tx), (uint32_t) (t / tx)) % (uint32_t) c->nParts != (uint32_t) c->part) continue;
+		const int x0 = off + (t % tx) * bs, y0 = off + (t / tx) * bs;            // inside the crop window
 		TileMeta tm{};
-		tm.x0 = x0; tm.y0 = y0; tm.w = std::min(bs, off + RW - x0); tm.h = std::min(bs, off + RH - y0);
+		tm.x0 = x0 + cx; tm.y0 = y0 + cy; tm.w = std::min(bs, off + RW - x0); tm.h = std::min(bs, off + RH - y0);
 		tm.slot_base = (uint32_t) pixels.size(); tm.block_index = (uint32_t) tiles.size();
 		tm.colour = (uint32_t) (((t % tx) & 1) + 2 * ((t / tx) & 1));
 		tiles.push_back(tm);
-		for (int y = y0; y < y0 + tm.h; ++y)
-			for (int x = x0; x < x0 + tm.w; ++x)
-				pixels.push_back((uint32_t) (y - off) * (uint32_t) RW + (uint32_t) (x - off));   // id inside the rendered rectangle
+		for (int y = tm.y0; y < tm.y0 + tm.h; ++y)
+			for (int x = tm.x0; x < tm.x0 + tm.w; ++x)
+				pixels.push_back((uint32_t) (y - off) * (uint32_t) keyW + (uint32_t) (x - off));
 	}
 	std::memset(&c->stats, 0, sizeof(c->stats));
 	c->traceEvUsed = c->shadeEvUsed = 0;
@@ -895,15 +929,21 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	rc = ensureSampleArrays(c, slotsPerPass, slotsPerPass * spp); if (rc) return rc;
 	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 8 * sizeof(unsigned long long), c->stream));
 	DConfig cfg = makeConfig(c, false);
-	cfg.pix_w = RW; cfg.pix_off = off;
+	cfg.pix_w = keyW; cfg.pix_off = off;
+	HIPCHK(c, hipMemsetAsync(c->pathLen, 0, sizeof(unsigned long long), c->stream));
 	const size_t fullBlock = (size_t) (bs + 2 * c->filtBorder) * (bs + 2 * c->filtBorder) * 5;
 	if (wideFilter) {
 		rc = ensureBuf(c, &c->tileMeta, &c->tileMetaCap, tiles.size()); if (rc) return rc;
 		rc = ensureBuf(c, &c->blocks, &c->blocksCap, tiles.size() * fullBlock); if (rc) return rc;
 	}
 
-	hipEvent_t t0, t1;
-	HIPCHK(c, hipEventCreate(&t0)); HIPCHK(c, hipEventCreate(&t1));
+	// frame timing events, released on every way out of this function
+	struct EventPair {
+		hipEvent_t a = nullptr, b = nullptr;
+		~EventPair() { if (a) (void) hipEventDestroy(a); if (b) (void) hipEventDestroy(b); }
+	} frameEv;
+	HIPCHK(c, hipEventCreate(&frameEv.a)); HIPCHK(c, hipEventCreate(&frameEv.b));
+	const hipEvent_t t0 = frameEv.a, t1 = frameEv.b;
 	HIPCHK(c, hipEventRecord(t0, c->stream));
 	size_t tileCursor = 0;
 	for (size_t base = 0; base < pixels.size();) {
@@ -929,13 +969,14 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 		launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList + base, nSlots, nullptr, nPaths, c->queueA);
 		HIPCHK(c, hipGetLastError());
 		rc = runBounces(c, cfg, nPaths, cancel);
-		if (rc) { (void) hipEventDestroy(t0); (void) hipEventDestroy(t1); return rc; }
+		if (rc) return rc;
 		if (wideFilter) {
 			const uint32_t nT = (uint32_t) (tileCursor - tileFirst);
 			HIPCHK(c, hipMemcpyAsync(c->tileMeta + tileFirst, tiles.data() + tileFirst, nT * sizeof(TileMeta), hipMemcpyHostToDevice, c->stream));
 			launch_splat_blocks(c->stream, c->paths, cfg, c->tileMeta + tileFirst, nT, spp, bs, c->blocks);
+			launch_path_lengths(c->stream, c->paths, nPaths, c->pathLen);
 		} else {
-			launch_accumulate(c->stream, c->paths, cfg, nSlots, spp, c->film);
+			launch_accumulate(c->stream, c->paths, cfg, nSlots, spp, c->film, c->pathLen);
 		}
 		HIPCHK(c, hipGetLastError());
 		c->stats.camera_samples += nPaths;
@@ -946,11 +987,12 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 			launch_add_blocks(c->stream, cfg, c->tileMeta, (uint32_t) tiles.size(), colour, bs, c->blocks, c->film);
 	HIPCHK(c, hipGetLastError());
 	HIPCHK(c, hipEventRecord(t1, c->stream));
+	HIPCHK(c, hipMemcpyAsync(&c->hostCounters[kNumCounters * kCounterStride], c->pathLen, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
+	std::memcpy(&c->stats.path_length_sum, &c->hostCounters[kNumCounters * kCounterStride], sizeof(uint64_t));
 	float ms = 0;
 	HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
 	c->stats.total_ms = ms;
-	(void) hipEventDestroy(t0); (void) hipEventDestroy(t1);
 	collectTimings(c);
 	if (c->countTraversal) { rc = fetchTraceCounts(c); if (rc) return rc; }
 	return 0;
@@ -1034,6 +1076,36 @@ int mtsgpu_ld_tables(mtsgpu_ctx *c, uint32_t pixel_key, float *out1d, float *out
 	return 0;
 }
 
+int mtsgpu_sampler_values(mtsgpu_ctx *c, uint32_t pixel_key, uint32_t sample_index, uint32_t n, int two_d, float *out) {
+	if (!c || !out) return fail(c, MTSGPU_EINVAL, "null argument");
+	if (n == 0) return 0;
+	const uint32_t spp = effectiveSpp(c);
+	if (n > 4096u || sample_index >= spp) return fail(c, MTSGPU_EINVAL, "sample index or count out of range");
+	HIPCHK(c, hipSetDevice(c->device));
+	int rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, 1); if (rc) return rc;
+	HIPCHK(c, hipMemcpyAsync(c->pixelList, &pixel_key, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	if (samplerHasTables(c)) {
+		rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, (size_t) 3 * c->ldDepth); if (rc) return rc;
+		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, (size_t) 2 * c->ldDepth * spp); if (rc) return rc;
+	}
+	const int integratorSaved = c->integrator;
+	c->integrator = 0;                               // no sample arrays: the plain next1D / next2D sequence
+	const DConfig cfg = makeConfig(c, true);
+	c->integrator = integratorSaved;
+	if (samplerHasTables(c))
+		launch_ld_tables(c->stream, cfg, c->pixelList, 1, c->ldScr, c->ldPerm, nullptr);
+	float *dOut = nullptr;
+	const size_t nOut = (size_t) n * (two_d ? 2 : 1);
+	HIPCHK(c, hipMalloc((void **) &dOut, nOut * sizeof(float)));
+	launch_sampler_values(c->stream, cfg, pixel_key, sample_index, n, two_d, dOut);
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) e = hipMemcpyAsync(out, dOut, nOut * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	(void) hipFree(dOut);
+	if (e != hipSuccess) return fail(c, MTSGPU_EHIP, "sampler read-out failed: %s", hipGetErrorString(e));
+	return 0;
+}
+
 int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, float *out) {
 	int rc = checkReady(c); if (rc) return rc;
 	if (!pix_samples || !out) return fail(c, MTSGPU_EINVAL, "null argument");
@@ -1046,7 +1118,7 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 		const uint32_t x = pix_samples[3 * (size_t) i], y = pix_samples[3 * (size_t) i + 1], j = pix_samples[3 * (size_t) i + 2];
 		if (x >= (uint32_t) c->cam.width || y >= (uint32_t) c->cam.height || j >= spp)
 			return fail(c, MTSGPU_EINVAL, "sample %u: pixel or sample index out of range", i);
-		keys[i] = y * (uint32_t) c->cam.width + x;
+		keys[i] = (y + (uint32_t) c->cam.crop_offset_y) * (uint32_t) filmWidth(c) + x + (uint32_t) c->cam.crop_offset_x;
 	}
 	rc = ensurePaths(c, n); if (rc) return rc;
 	rc = ensureBuf(c, &c->explicitSamples, &c->explicitCap, 3 * (size_t) n); if (rc) return rc;

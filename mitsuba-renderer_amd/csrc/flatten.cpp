@@ -593,6 +593,7 @@ void makeCamera(const float origin[3], const float target[3], const float up[3],
 	out.width = width; out.height = height;
 	out.aperture_radius = 0.0f; out.focus_depth = farClip;     // camera.cpp:164-166 defaults
 	out.kind = 0;
+	out.crop_offset_x = out.crop_offset_y = 0; out.film_width = out.film_height = 0;
 }
 
 // OrthographicCamera::configure (src/cameras/orthographic.cpp:46-82) with toWorld = lookAt * scale(sx, sy, 1)
@@ -621,6 +622,7 @@ void makeCameraOrtho(const float origin[3], const float target[3], const float u
 	out.width = width; out.height = height;
 	out.aperture_radius = 0.0f; out.focus_depth = farClip;
 	out.kind = 1;
+	out.crop_offset_x = out.crop_offset_y = 0; out.film_width = out.film_height = 0;
 }
 
 } // namespace mg

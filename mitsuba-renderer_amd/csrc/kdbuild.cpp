@@ -20,7 +20,9 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <exception>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <chrono>
 #include <cstdio>
@@ -610,19 +612,29 @@ public:
 
 	void runJobs(int nThreads) {
 		std::atomic<size_t> next(0);
+		// an exception that leaves a std::thread ends the process: the first one is kept and rethrown on the calling
+		// thread after the join, where mtsgpu_flatten turns it into an error code
+		std::exception_ptr firstError;
+		std::mutex errorLock;
 		auto worker = [&]() {
-			std::unique_ptr<uint8_t[]> clsBuf(new uint8_t[m_nPrims]);
-			uint8_t *cls = clsBuf.get();
-			for (;;) {
-				const size_t k = next.fetch_add(1);
-				if (k >= m_jobs.size())
-					break;
-				Job &j = *m_jobs[k];
-				j.root = j.ctx.allocNodes(1);
-				const auto tj0 = std::chrono::steady_clock::now();
-				runExact(j.ctx, cls, j.depth, j.root, j.nodeBox, j.prims, j.badRefines);
-				j.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count();
-				std::vector<uint32_t>().swap(j.prims);
+			try {
+				std::unique_ptr<uint8_t[]> clsBuf(new uint8_t[m_nPrims]);
+				uint8_t *cls = clsBuf.get();
+				for (;;) {
+					const size_t k = next.fetch_add(1);
+					if (k >= m_jobs.size())
+						break;
+					Job &j = *m_jobs[k];
+					j.root = j.ctx.allocNodes(1);
+					const auto tj0 = std::chrono::steady_clock::now();
+					runExact(j.ctx, cls, j.depth, j.root, j.nodeBox, j.prims, j.badRefines);
+					j.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj0).count();
+					std::vector<uint32_t>().swap(j.prims);
+				}
+			} catch (...) {
+				std::lock_guard<std::mutex> guard(errorLock);
+				if (!firstError) firstError = std::current_exception();
+				next.store(m_jobs.size());           // the other workers stop after their current job
 			}
 		};
 		nThreads = std::max(1, std::min<int>(nThreads, (int) m_jobs.size()));
@@ -630,6 +642,7 @@ public:
 		for (int t = 1; t < nThreads; ++t) pool.emplace_back(worker);
 		worker();
 		for (auto &t : pool) t.join();
+		if (firstError) std::rethrow_exception(firstError);
 	}
 
 	const Geometry &m_g;

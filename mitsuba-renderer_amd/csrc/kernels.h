@@ -8,7 +8,7 @@ namespace mg {
 constexpr int kNumBsdfTypes = 8;      // lambertian, dielectric, roughmetal, microfacet, mirror, phong, roughglass, difftrans
 constexpr int kNumBins = kNumBsdfTypes + 1;   // + "terminal" (miss / no BSDF)
 constexpr int kTraceBlock = 256;
-constexpr unsigned kTraceGridBlocks = 256 * 8;   // largest persistent traversal grid: 256 CUs x resident workgroups
+constexpr unsigned kTraceBlocksPerCuMax = 8;      // largest persistent traversal grid: CUs x 8 resident workgroups
 constexpr unsigned trace_blocks_per_cu(int mode) { return mode == 0 ? 7u : 8u; }   // closest-hit state needs 72 VGPRs, shadow rays 64
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 constexpr int kTriStride = 8;         // float4 per primitive record: one 128-byte line holds positions AND normals
@@ -90,8 +90,11 @@ struct DConfig {
 	float near_clip, far_clip;
 	float aperture_radius, focus_depth;   // thin lens (perspective.cpp:90-103); 0 = pinhole
 	int32_t camera_kind;                  // 0 perspective, 1 orthographic (orthographic.cpp:104-118)
-	int32_t width, height;
-	int32_t pix_w, pix_off;            // rendered rectangle: pixel ids index a pix_w-wide grid whose origin is (pix_off, pix_off)
+	int32_t width, height;             // size of the film buffer = the crop window (Film::getCropSize)
+	int32_t crop_x, crop_y;            // film pixel (x, y) is raster position (x + crop_x, y + crop_y) (mfilm.cpp:118-143)
+	// pixel keys index a pix_w-wide grid over the FULL film's raster space whose origin is (pix_off, pix_off)
+	// (pix_off = -border with highQualityEdges): key -> raster pixel, and the sampler streams are keyed by it
+	int32_t pix_w, pix_off;
 	int32_t max_depth, rr_depth, strict_normals;
 	// integrator plugin: 0 = path (MIPathTracer), 1 = direct (MIDirectIntegrator, direct.cpp:51-56)
 	int32_t integrator, n_lum, n_bsdf;
@@ -135,6 +138,12 @@ struct DQueues {
 	uint32_t static_n, dyn_slot;       // k_trace: statically dealt queue prefix; counter (line index) of the dynamic head
 	uint32_t refill_min;               // k_trace refills its idle lanes once this many are idle (1..64)
 	uint32_t batch;                    // k_trace: rays per wave and batch (64; fewer when the launch cannot fill the chip)
+	uint32_t n_cus;                    // hipDeviceProp_t::multiProcessorCount: the persistent grids are sized from it
+	uint32_t force_static;             // k_trace launcher: deal the whole queue statically (retry after a bin segment overflow)
+	// experiment knobs of the k_trace launcher (mtsgpu_set_tuning; 0 = the default rule)
+	uint32_t tune_batch;               // rays per wave and batch, 1..64
+	uint32_t tune_dyn_div;             // 1/x of the rounds of a large launch are claimed dynamically (default 4)
+	uint32_t tune_refill;              // refill threshold for coherent launches too (default: 64 there)
 };
 
 // --- launchers (kernels.hip) -------------------------------------------------
@@ -144,6 +153,7 @@ void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_k
 // the requested sample arrays of the table-based samplers (ldsampler.cpp:152-153, stratified.cpp:136-138), continuing
 // that stream; writes cfg.arr_scr / arr_perm / arr_pts
 void launch_sample_arrays(hipStream_t s, const DConfig &cfg, uint32_t n_slots, const unsigned long long *state_in);
+void launch_sampler_values(hipStream_t s, const DConfig &cfg, uint32_t pixel_key, uint32_t j, uint32_t n, int two_d, float *out);
 void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg,
                      const uint32_t *pixel_list, uint32_t n_slots, const uint32_t *explicit_samples,
                      uint32_t n_paths, uint32_t *queue);
@@ -156,8 +166,14 @@ void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &s
 struct BinView { uint32_t prefix[kBinShards + 1]; };
 void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
                   const DQueues &q, const BinView &view);
+// path_len (may be NULL): u64 sum of the final path depths (the avgPathLength statistic, path.cpp:212-213)
 void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,
-                       uint32_t spp_per_slot, float *film);
+                       uint32_t spp_per_slot, float *film, unsigned long long *path_len);
+void launch_path_lengths(hipStream_t s, const DPaths &ps, uint32_t n_paths, unsigned long long *path_len);
+// a[i] = b[i] + s * c[i] over n float4
+void launch_triad(hipStream_t s, float4 *a, const float4 *b, const float4 *c, float scale, size_t n);
+// dst[i] += src[i] over n floats (the ordered film sum of a device group)
+void launch_add_film(hipStream_t s, float *dst, const float *src, size_t n);
 // ImageBlock tiles of one context: rect, first sampler slot of the tile inside its pass, block index
 struct TileMeta { int32_t x0, y0, w, h; uint32_t slot_base; uint32_t block_index; uint32_t colour; uint32_t pad; };
 void launch_splat_blocks(hipStream_t s, const DPaths &ps, const DConfig &cfg, const TileMeta *tiles, uint32_t n_tiles,
@@ -167,5 +183,6 @@ void launch_add_blocks(hipStream_t s, const DConfig &cfg, const TileMeta *tiles,
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, size_t n);
 void launch_iota(hipStream_t s, uint32_t *p, uint32_t n);
 size_t trace_spill_levels();
+size_t trace_stack_levels();      // depth of the traversal stack (LDS + spill levels)
 
 } // namespace mg

@@ -268,6 +268,20 @@ __device__ __forceinline__ void sampler_array2d(const DConfig &cfg, const PathSa
 	}
 }
 
+// Sampler read-out for tests (mtsgpu_sampler_values): the sampler state k_generate creates for (pixel, sample j) in
+// slot 0, then n draws
+__global__ void k_sampler_values(DConfig cfg, uint32_t pixel_key, uint32_t j, uint32_t n, int two_d, float *out) {
+	if (blockIdx.x != 0 || threadIdx.x != 0)
+		return;
+	PathSampler smp;
+	smp.stream = keyedInit(cfg.seed, pixel_key, 1 + (uint64_t) j);
+	smp.slot = 0; smp.j = j; smp.d1 = 0; smp.d2 = 0;
+	for (uint32_t i = 0; i < n; ++i) {
+		if (two_d) sampler_next2d(cfg, smp, out[2 * i], out[2 * i + 1]);
+		else out[i] = sampler_next1d(cfg, smp);
+	}
+}
+
 // ===========================================================================
 // K1: camera samples (integrator.cpp:154-166, perspective.cpp:77-112)
 // ===========================================================================
@@ -278,17 +292,18 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 		return;
 	uint32_t slot, j, pixel;
 	if (explicit_samples) {
+		// film pixel (x, y) of the crop window -> key in the full film's raster grid
 		slot = id;
-		pixel = explicit_samples[3 * (size_t) id + 1] * (uint32_t) cfg.width + explicit_samples[3 * (size_t) id];
+		pixel = (explicit_samples[3 * (size_t) id + 1] + (uint32_t) cfg.crop_y) * (uint32_t) cfg.pix_w
+		      + explicit_samples[3 * (size_t) id] + (uint32_t) cfg.crop_x;
 		j = explicit_samples[3 * (size_t) id + 2];
 	} else {
 		slot = id / cfg.spp;
 		j = id - slot * cfg.spp;
 		pixel = pixel_list[slot];
 	}
-	int px, py;       // pixel position; negative / beyond the film with highQualityEdges (renderproc.cpp:146-153)
-	if (explicit_samples) { px = (int) (pixel % (uint32_t) cfg.width); py = (int) (pixel / (uint32_t) cfg.width); }
-	else { px = (int) (pixel % (uint32_t) cfg.pix_w) + cfg.pix_off; py = (int) (pixel / (uint32_t) cfg.pix_w) + cfg.pix_off; }
+	// raster pixel of the key; negative / beyond the film with highQualityEdges (renderproc.cpp:146-153)
+	const int px = (int) (pixel % (uint32_t) cfg.pix_w) + cfg.pix_off, py = (int) (pixel / (uint32_t) cfg.pix_w) + cfg.pix_off;
 
 	PathSampler smp;
 	smp.stream = keyedInit(cfg.seed, pixel, 1 + (uint64_t) j);
@@ -427,6 +442,7 @@ constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 
 size_t trace_spill_levels() { return kSpillLevels; }
+size_t trace_stack_levels() { return kStackLDS + kSpillLevels; }
 
 // Persistent waves: the grid is sized to fill the chip once and every wave walks its own 64-ray
 // batches of the queue with a private cursor (no work-queue atomic: a single head word saturates at
@@ -436,8 +452,8 @@ size_t trace_spill_levels() { return kSpillLevels; }
 // the descent / primitive loops are left as soon as fewer than q.desc_min / q.leaf_min lanes still
 // need them (the others stop waiting; stragglers resume in the next round).  None of this changes
 // what is computed for a ray.
-// The body is a device function so that k_mega (below) can run it on the private batch of one wave: `first` is the
-// queue index of the wave's first batch, `stride` the distance to its next one, `static_n` the statically dealt prefix.
+// `first` is the queue index of the wave's first batch, `stride` the distance to its next one, `static_n` the
+// statically dealt prefix of the queue.
 template <int MODE, bool COUNT, bool BIN>
 __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n,
                                            const uint32_t first, const uint32_t stride, const uint32_t static_n,
@@ -526,9 +542,13 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 					if (lane < (uint32_t) kNumBins && cnt != 0u)
 						base = atomicAdd(&q.counters[(lane * kBinShards + shard) * kCounterStride], cnt);
 					base = __shfl(base, bin < 0 ? 0 : bin);
+					// a shard's segment holds its share of a statically dealt queue (api.cpp: ensurePaths); dynamic claims
+					// can in principle exceed it: the entry is dropped then, the counter still counts it, and the host
+					// repeats the launch with static dealing when it sees a count above the capacity
+					const uint32_t pos = base + rank;
 					#pragma unroll
 					for (int b = 0; b < kNumBins; ++b)
-						if (bin == b) q.bins[b][(size_t) shard * q.bin_seg_cap + base + rank] = id;
+						if (bin == b && pos < q.bin_seg_cap) q.bins[b][(size_t) shard * q.bin_seg_cap + pos] = id;
 				}
 			} else if (MODE == 1) {
 				// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
@@ -1642,8 +1662,8 @@ __device__ __forceinline__ float mi_weight(float pdfA, float pdfB) {     // path
 // ===========================================================================
 // ROUNDS: the instantiation the rounds of MIDirectIntegrator use (DConfig::dr_mode != 0); the path tracer and the
 // one-sample direct integrator run the one without that code
-// The iteration for ONE path (id), shared by k_shade and k_mega: what it leaves behind in registers is whether the path
-// continues and its pending direct-light term with the shadow ray that guards it.
+// The iteration for ONE path (id): what it leaves behind in registers is whether the path continues and its pending
+// direct-light term with the shadow ray that guards it.
 template <int BT, bool ROUNDS>
 __device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, const DConfig &cfg, const uint32_t id,
                                            bool &continues, bool &wantShadow, V3 &neeV, V3 &shO, V3 &shD) {
@@ -1691,6 +1711,10 @@ __device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, c
 				// rRec.rayIntersect (records.inl:89-105): alpha = 1 on a hit
 				flags &= ~F_FIRST;
 				if (valid) flags |= F_ALPHA;
+				// while (rRec.depth <= m_maxDepth || m_maxDepth < 0) with depth == 1 (path.cpp:61): maxDepth == 0 never
+				// enters the loop, the sample is black with the alpha of the camera ray
+				if (!direct && !(depth <= cfg.max_depth || cfg.max_depth < 0))
+					break;
 			} else {
 				// ---- tail of the previous iteration (path.cpp:147-208) ----
 				const float4 B4 = ps.bsdf(id);
@@ -1891,10 +1915,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 // One lane per pixel; its samples are added in sample-index order, so the film
 // is bit-reproducible and independent of how the image was sharded.
 // ===========================================================================
-__global__ void k_accumulate(DPaths ps, DConfig cfg, uint32_t n_slots, uint32_t spp, float *film) {
+__global__ void k_accumulate(DPaths ps, DConfig cfg, uint32_t n_slots, uint32_t spp, float *film, unsigned long long *path_len) {
 	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-	if (slot >= n_slots)
-		return;
+	unsigned long long depthSum = 0;
+	if (slot < n_slots) {
 	const int W = cfg.width, H = cfg.height;
 	// TabulatedFilter of the box filter: size 0.5, factor = 15 / 0.5, table = 1 inside, 0 on the border row
 	const float fsize = 0.5f, factor = 15 / fsize;
@@ -1902,6 +1926,7 @@ __global__ void k_accumulate(DPaths ps, DConfig cfg, uint32_t n_slots, uint32_t 
 		const size_t id = (size_t) slot * spp + j;
 		const float4 L = ps.Li(id);
 		const float4 sp = ps.spos(id);
+		if (path_len) depthSum += (unsigned long long) __float_as_int(ps.thr(id).w);      // same 128-byte line as Li / spos
 		// Spectrum::isValid (spectrum.h:285-290)
 		if (L.x != L.x || L.x < 0.0f || L.y != L.y || L.y < 0.0f || L.z != L.z || L.z < 0.0f)
 			continue;
@@ -1909,8 +1934,9 @@ __global__ void k_accumulate(DPaths ps, DConfig cfg, uint32_t n_slots, uint32_t 
 		const float sx = sp.x - 0.5f - 0, sy = sp.y - 0.5f - 0;
 		int xStart = (int) ceilf(sx - fsize), xEnd = (int) floorf(sx + fsize);
 		int yStart = (int) ceilf(sy - fsize), yEnd = (int) floorf(sy + fsize);
-		xStart = max(0, xStart); yStart = max(0, yStart);
-		xEnd = min(xEnd, W - 1); yEnd = min(yEnd, H - 1);
+		// Film::putImageBlock keeps what falls inside the crop window (mfilm.cpp:118-143)
+		xStart = max(cfg.crop_x, xStart); yStart = max(cfg.crop_y, yStart);
+		xEnd = min(xEnd, cfg.crop_x + W - 1); yEnd = min(yEnd, cfg.crop_y + H - 1);
 		for (int y = yStart; y <= yEnd; ++y) {
 			const int iy = min((int) (factor * fabsf(y - sy)), 15);
 			for (int x = xStart; x <= xEnd; ++x) {
@@ -1919,13 +1945,43 @@ __global__ void k_accumulate(DPaths ps, DConfig cfg, uint32_t n_slots, uint32_t 
 				// zero-weight taps add spec*0 in the reference: a no-op for valid spectra
 				if (weight == 0.0f)
 					continue;
-				float *px = film + 5 * ((size_t) y * W + x);
+				float *px = film + 5 * ((size_t) (y - cfg.crop_y) * W + (x - cfg.crop_x));
 				px[0] += L.x * weight; px[1] += L.y * weight; px[2] += L.z * weight;
 				px[3] += alpha * weight;
 				px[4] += weight;
 			}
 		}
 	}
+	}
+	if (path_len) {
+		for (int off = 32; off > 0; off >>= 1)
+			depthSum += __shfl_down(depthSum, off);
+		if (lane_id() == 0 && depthSum)
+			atomicAdd(path_len, depthSum);
+	}
+}
+
+// the avgPathLength statistic for passes that do not run k_accumulate (filters wider than a pixel)
+__global__ void k_path_lengths(DPaths ps, uint32_t n_paths, unsigned long long *path_len) {
+	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long d = id < n_paths ? (unsigned long long) __float_as_int(ps.thr(id).w) : 0ull;
+	for (int off = 32; off > 0; off >>= 1)
+		d += __shfl_down(d, off);
+	if (lane_id() == 0 && d)
+		atomicAdd(path_len, d);
+}
+
+__global__ void k_triad(float4 *a, const float4 *b, const float4 *c, float s, size_t n) {
+	const size_t stride = (size_t) gridDim.x * blockDim.x;
+	for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const float4 x = b[i], y = c[i];
+		a[i] = make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w);
+	}
+}
+
+__global__ void k_add_film(float *dst, const float *src, size_t n) {
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] += src[i];
 }
 
 // ===========================================================================
@@ -1949,7 +2005,7 @@ __global__ __launch_bounds__(256) void k_splat_blocks(DPaths ps, DConfig cfg, co
 		const int yl = p / fullW, xl = p - yl * fullW;
 		const int X = tm.x0 - border + xl, Y = tm.y0 - border + yl;
 		float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-		if (X >= 0 && X < cfg.width && Y >= 0 && Y < cfg.height) {
+		if (X >= cfg.crop_x && X < cfg.crop_x + cfg.width && Y >= cfg.crop_y && Y < cfg.crop_y + cfg.height) {
 			const int pyLo = max(Y - RY, tm.y0), pyHi = min(Y + RY, tm.y0 + tm.h - 1);
 			const int pxLo = max(X - RX, tm.x0), pxHi = min(X + RX, tm.x0 + tm.w - 1);
 			for (int py = pyLo; py <= pyHi; ++py)
@@ -1998,10 +2054,10 @@ __global__ __launch_bounds__(256) void k_add_blocks(DConfig cfg, const TileMeta 
 	for (int p = threadIdx.x; p < fullW * fullH; p += blockDim.x) {
 		const int yl = p / fullW, xl = p - yl * fullW;
 		const int X = tm.x0 - border + xl, Y = tm.y0 - border + yl;
-		if (X < 0 || X >= cfg.width || Y < 0 || Y >= cfg.height)
-			continue;
+		if (X < cfg.crop_x || X >= cfg.crop_x + cfg.width || Y < cfg.crop_y || Y >= cfg.crop_y + cfg.height)
+			continue;                                                     // outside the crop region (mfilm.cpp:123-135)
 		const float *b = blk + 5 * ((size_t) yl * full + xl);
-		float *o = film + 5 * ((size_t) Y * cfg.width + X);
+		float *o = film + 5 * ((size_t) (Y - cfg.crop_y) * cfg.width + (X - cfg.crop_x));
 		o[0] += b[0]; o[1] += b[1]; o[2] += b[2]; o[3] += b[3]; o[4] += b[4];
 	}
 }
@@ -2034,6 +2090,10 @@ void launch_sample_arrays(hipStream_t s, const DConfig &cfg, uint32_t n_slots, c
 	                   const_cast<uint32_t *>(cfg.arr_scr), const_cast<uint16_t *>(cfg.arr_perm), const_cast<float2 *>(cfg.arr_pts));
 }
 
+void launch_sampler_values(hipStream_t s, const DConfig &cfg, uint32_t pixel_key, uint32_t j, uint32_t n, int two_d, float *out) {
+	hipLaunchKernelGGL(k_sampler_values, dim3(1), dim3(64), 0, s, cfg, pixel_key, j, n, two_d, out);
+}
+
 void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg,
                      const uint32_t *pixel_list, uint32_t n_slots, const uint32_t *explicit_samples,
                      uint32_t n_paths, uint32_t *queue) {
@@ -2044,30 +2104,30 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 template <int MODE, bool COUNT, bool BIN>
 static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent) {
 	// persistent grid: enough workgroups to fill every CU, never more than there are rays
-	const unsigned maxBlocks = 256u * trace_blocks_per_cu(MODE), wavesPerBlock = kTraceBlock / 64;
+	const unsigned maxBlocks = q.n_cus * trace_blocks_per_cu(MODE), wavesPerBlock = kTraceBlock / 64;
 	DQueues qq = q;
 	// rays per wave: 64, or the smallest power of two (>= 8) with which the launch still fits into one round of the
 	// persistent grid -- a launch that cannot fill the lanes of the chip trades idle lanes for shorter waves
-	static const int batchEnv = getenv("MTSGPU_BATCH") ? atoi(getenv("MTSGPU_BATCH")) : 0;
 	unsigned batch = 64;
 	if (!coherent) while (batch > 8u && (unsigned long long) (batch / 2) * wavesPerBlock * maxBlocks >= n) batch /= 2;
-	if (batchEnv >= 1 && batchEnv <= 64) batch = (unsigned) batchEnv;
+	if (q.tune_batch >= 1 && q.tune_batch <= 64) batch = q.tune_batch;
 	qq.batch = batch;
 	const unsigned blocks = std::min<unsigned>(blocks_for(n, batch * wavesPerBlock), maxBlocks);
 	// static share of the queue: whole rounds of the grid; the last quarter of the rounds and the remainder are
 	// claimed dynamically (one atomic per 64-ray batch, far below the ~88 / us a single counter sustains)
 	const unsigned long long perRound = (unsigned long long) blocks * wavesPerBlock * batch;
 	const unsigned long long rounds = n / perRound;
-	static const int dynDiv = getenv("MTSGPU_DYNDIV") ? std::max(1, atoi(getenv("MTSGPU_DYNDIV"))) : 4;
+	const unsigned dynDiv = q.tune_dyn_div ? q.tune_dyn_div : 4u;
 	// small launches stay fully static: their waves finish together and would hit the counter in one burst
-	const unsigned long long dynRounds = rounds >= 8 ? std::max<unsigned long long>(1, rounds / dynDiv) : 0;
-	qq.static_n = rounds >= 8 ? (uint32_t) ((rounds - dynRounds) * perRound) : n;
+	const bool dynamic = rounds >= 8 && !q.force_static;
+	const unsigned long long dynRounds = dynamic ? std::max<unsigned long long>(1, rounds / dynDiv) : 0;
+	qq.static_n = dynamic ? (uint32_t) ((rounds - dynRounds) * perRound) : n;
 	qq.dyn_slot = (uint32_t) (kNumBins * kBinShards + 2 + (MODE == 0 ? 0 : 1));
 	// the early loop exits trade the latency of a few straggling rays for throughput; with only a few
 	// batches per wave the stragglers are the critical path, so small launches run the plain loops
-	if (n < 8u * kTraceGridBlocks * kTraceBlock || coherent)
+	if (n < 8u * (q.n_cus * 8u) * kTraceBlock || coherent)
 		qq.desc_min = qq.leaf_min = 1;
-	if (coherent && !getenv("MTSGPU_REFILL"))
+	if (coherent && !q.tune_refill)
 		qq.refill_min = 64;       // neighbouring camera samples finish together: refilling would only mix batches
 	qq.refill_min = std::min(qq.refill_min, batch);
 	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, sc, ps, qq, queue, n);
@@ -2108,8 +2168,17 @@ void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, co
 }
 
 void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,
-                       uint32_t spp_per_slot, float *film) {
-	if (n_slots) hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, ps, cfg, n_slots, spp_per_slot, film);
+                       uint32_t spp_per_slot, float *film, unsigned long long *path_len) {
+	if (n_slots) hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, ps, cfg, n_slots, spp_per_slot, film, path_len);
+}
+void launch_path_lengths(hipStream_t s, const DPaths &ps, uint32_t n_paths, unsigned long long *path_len) {
+	if (n_paths) hipLaunchKernelGGL(k_path_lengths, dim3(blocks_for(n_paths, 256)), dim3(256), 0, s, ps, n_paths, path_len);
+}
+void launch_triad(hipStream_t s, float4 *a, const float4 *b, const float4 *c, float scale, size_t n) {
+	if (n) hipLaunchKernelGGL(k_triad, dim3(256 * 16), dim3(256), 0, s, a, b, c, scale, n);
+}
+void launch_add_film(hipStream_t s, float *dst, const float *src, size_t n) {
+	if (n) hipLaunchKernelGGL(k_add_film, dim3(blocks_for(n, 256)), dim3(256), 0, s, dst, src, n);
 }
 
 } // namespace mg

@@ -121,6 +121,9 @@ typedef struct orc_render_params {
  * keyed samplers; film: full-frame [H][W][5] f32 (spec rgb, alpha, weight), summed into. */
 void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *p,
                      int x0, int y0, int x1, int y1, float *film, mtsgpu_stats *stats);
+/* Sampler::generate() for a pixel, then n x next1D() (or next2D(): out[2n]) of camera sample `sample_index`;
+ * same contract as mtsgpu_sampler_values */
+void orc_sampler_values(const orc_render_params *p, uint32_t pixel_key, uint32_t sample_index, uint32_t n, int two_d, float *out);
 /* MIPathTracer::Li for explicit (pixel, sample) pairs; same contract as mtsgpu_li_samples */
 void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *p,
                     const uint32_t *pix_samples, uint32_t n, float *out);

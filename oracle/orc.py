@@ -34,12 +34,23 @@ class Random(C.Structure):
     _fields_ = [("mt", C.c_uint64 * 312), ("mti", C.c_int)]
 
 
+_variant = "liboracle.so"
+
+
+def use_native_build():
+    """bench.py's cpu_baseline leg: the same sources with -O3 -march=native, compiled on the machine that runs it
+    (oracle/Makefile).  Must be called before the first lib()."""
+    global _variant
+    assert _lib is None, "the oracle library is already loaded"
+    _variant = "liboracle_native.so"
+
+
 def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+    so = os.path.join(_HERE, _variant)
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     srcs.append(os.path.join(_HERE, "..", "include", "mtsgpu.h"))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", _variant], stdout=subprocess.DEVNULL)
     return so
 
 
@@ -93,6 +104,7 @@ def lib():
                                   C.c_int, C.c_int, C.c_int, C.c_int, f32p, C.POINTER(abi.Stats)]
     L.orc_li_samples.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(RenderParams),
                                  u32p, C.c_uint32, f32p]
+    L.orc_sampler_values.argtypes = [C.POINTER(RenderParams), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, f32p]
     L.orc_render_rect_mt.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), C.POINTER(RenderParams),
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
     L.orc_tabulate_filter.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(TabFilter)]
@@ -177,6 +189,13 @@ def li_samples(scene_ptr, cam, params, pix_samples):
     ps = np.ascontiguousarray(pix_samples, dtype=np.uint32).reshape(-1, 3)
     out = np.zeros((ps.shape[0], 8), dtype=np.float32)
     lib().orc_li_samples(scene_ptr, C.byref(cam), C.byref(params), abi.ptr(ps, abi.u32p), ps.shape[0], abi.ptr(out, abi.f32p))
+    return out
+
+
+def sampler_values(params, pixel_key, sample_index, n, two_d=False):
+    """generate() for the pixel, then n x next1D() (or next2D()) of camera sample `sample_index`"""
+    out = np.zeros((n, 2) if two_d else (n,), dtype=np.float32)
+    lib().orc_sampler_values(C.byref(params), int(pixel_key), int(sample_index), int(n), int(bool(two_d)), abi.ptr(out, abi.f32p))
     return out
 
 

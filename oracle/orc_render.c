@@ -1946,10 +1946,10 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 	tabfilter_t filter; tabfilter_box(&filter);
 	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED || prm->sampler_kind == MTSGPU_SAMPLER_STRATIFIED_KEYED;     /* per-pixel tables */
 	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
-	uint64_t nClosest = 0, nShadow = 0;
+	uint64_t nClosest = 0, nShadow = 0, nDepth = 0;
 #ifdef _OPENMP
 	int nthreads = prm->n_threads > 0 ? prm->n_threads : omp_get_max_threads();
-#pragma omp parallel num_threads(nthreads) reduction(+:nClosest,nShadow)
+#pragma omp parallel num_threads(nthreads) reduction(+:nClosest,nShadow,nDepth)
 #endif
 	{
 		uint32_t *scr = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 3 * (size_t) depth) : NULL;
@@ -1978,6 +1978,7 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 					camera_generate_ray(cam, sample, lens, &eyeRay);
 					li_result res;
 					integrator_li(sc, prm, &eyeRay, &smp, &res, &st);
+					nDepth += (uint64_t) res.depth;          /* avgPathLength += rRec.depth (path.cpp:212-213) */
 					put_sample(film, W, H, &filter, sample[0], sample[1], res.Li, res.alpha);
 				}
 			}
@@ -1988,7 +1989,32 @@ void orc_render_rect(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc
 	if (stats) {
 		stats->camera_samples += (uint64_t) (x1 - x0) * (uint64_t) (y1 - y0) * spp;
 		stats->rays_closest += nClosest; stats->rays_shadow += nShadow;
+		stats->path_length_sum += nDepth;
 	}
+}
+
+/* What a Sampler hands out for camera sample `j` of a pixel: generate() for the pixel (keyed stream where the
+ * sampler draws random numbers), then n calls of next1D() (two_d == 0: out[n]) or next2D() (out[2n]).  For halton /
+ * hammersley these are the reference's own values (src/tests/test_samplers.cpp:33-78). */
+void orc_sampler_values(const orc_render_params *prm, uint32_t pixelKey, uint32_t j, uint32_t n, int two_d, float *out) {
+	(void) orc_prime(0);
+	const uint32_t spp = effective_spp(prm);
+	const int isLD = prm->sampler_kind == MTSGPU_SAMPLER_LD_KEYED || prm->sampler_kind == MTSGPU_SAMPLER_STRATIFIED_KEYED;
+	const int depth = prm->ld_depth > 0 ? prm->ld_depth : 3;
+	uint32_t *scr = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 3 * (size_t) depth) : NULL;
+	uint32_t *perm = isLD ? (uint32_t *) malloc(sizeof(uint32_t) * 2 * (size_t) depth * spp) : NULL;
+	sample_arrays arrays; const int hasArrays = arrays_init(&arrays, prm, spp);
+	if (isLD || hasArrays) sampler_generate_tables(prm, pixelKey, spp, depth, scr, perm, &arrays);
+	sampler_t smp; memset(&smp, 0, sizeof(smp));
+	sampler_bind_arrays(&smp, &arrays);
+	smp.kind = sampler_kind_of(prm);
+	smp.stream = orc_keyed_init(prm->seed, pixelKey, 1 + (uint64_t) j);
+	smp.depth = depth; smp.spp = spp; smp.index = j; smp.scr = scr; smp.perm = perm; smp.resolution = isqrt_u32(spp);
+	for (uint32_t i = 0; i < n; ++i) {
+		if (two_d) sampler_next2d(&smp, out + 2 * (size_t) i);
+		else out[i] = sampler_next1d(&smp);
+	}
+	free(scr); free(perm); arrays_free(&arrays);
 }
 
 void orc_li_samples(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *prm,
@@ -2151,6 +2177,14 @@ void orc_tabulate_filter(int kind, float half_size, float p0, float p1, orc_tabf
 
 typedef struct { float L[3], alpha, sx, sy; int valid; } tsample_t;
 
+/* which part renders tile (tx, ty): bits of tx and ty interleaved, tx lowest (mtsgpu_set_tiles, include/mtsgpu.h) */
+static uint32_t tile_morton(uint32_t tx, uint32_t ty) {
+	uint32_t m = 0;
+	for (int b = 0; b < 16; ++b)
+		m |= ((tx >> b) & 1u) << (2 * b) | ((ty >> b) & 1u) << (2 * b + 1);
+	return m;
+}
+
 void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const orc_render_params *prm,
                       const orc_tabfilter *filter, int bs, int part, int n_parts, int hq_edges,
                       float *film, mtsgpu_stats *stats) {
@@ -2185,7 +2219,7 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 #pragma omp for schedule(dynamic, 1)
 #endif
 		for (int t = 0; t < nTiles; ++t) {
-			if (t % n_parts != part) continue;
+			if (tile_morton((uint32_t) (t % tx), (uint32_t) (t / tx)) % (uint32_t) n_parts != (uint32_t) part) continue;   /* mtsgpu_set_tiles */
 			const int x0 = off + (t % tx) * bs, y0 = off + (t / tx) * bs;
 			const int w = (x0 + bs <= off + RW ? bs : off + RW - x0), h = (y0 + bs <= off + RH ? bs : off + RH - y0);
 			/* 1. the camera samples of the tile (integrator.cpp:150-169) */

@@ -1,6 +1,7 @@
 """N>1 path on CPU: world_size-2 gloo.  Each rank fills a full-frame film for its ImageBlock tiles
-(the oracle stands in for the GPU kernel here), the films are summed with filmreduce.reduce_film
-and the result must equal the unsharded film bit for bit."""
+(the oracle stands in for the GPU kernel here: there is no GPU in this tier), the films are summed with
+filmreduce.reduce_film and the result must equal the unsharded film bit for bit.  The product's own world > 1
+branch (bench.py: set_tiles, the shared film buffer, the reduce) runs in tests/test_gpu_round2.py on the GPU box."""
 import os
 import sys
 import numpy as np
@@ -25,7 +26,9 @@ def _worker(rank, world, port, W, H, out_path):
     bs = 32
     tx = (W + bs - 1) // bs
     keys = pkg.filmreduce.tiles_of_rank(W, H, bs, rank, world)
-    for t in sorted(set(((k // W) // bs) * tx + ((k % W) // bs) for k in keys.tolist())):
+    tiles = sorted(set(((k // W) // bs) * tx + ((k % W) // bs) for k in keys.tolist()))
+    assert all(pkg.filmreduce.tile_morton(t % tx, t // tx) % world == rank for t in tiles)
+    for t in tiles:
         x0, y0 = (t % tx) * bs, (t // tx) * bs
         part, _ = orc.render(fs.scene, cam, prm, rect=(x0, y0, min(x0 + bs, W), min(y0 + bs, H)))
         film += part
@@ -41,7 +44,10 @@ def test_two_rank_film_reduce_is_exact(tmp_path, mts, orc):
     import torch.multiprocessing as mp
     W, H = 80, 48
     out = str(tmp_path / "film.npy")
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:                  # a free port, not one derived from the pid (parallel test runs collide)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     mp.spawn(_worker, args=(2, port, W, H, out), nprocs=2, join=True)
     got = np.load(out)
     sd = mts.scenes.cornell_c1()

@@ -133,6 +133,47 @@ def test_tiles_of_rank_partition(mts):
     assert len(allp) == W * H and len(np.unique(allp)) == W * H
 
 
+def test_tile_ownership_is_a_balanced_2d_lattice(mts, orc):
+    """mtsgpu_set_tiles: tile (tx, ty) belongs to part morton(tx, ty) % n.  At 1024^2 / 32 every part of 2, 4 or 8 owns
+    the same number of tiles and every 4 x 2 group of tiles holds all 8 parts; the oracle's tile renderer uses the same
+    rule (one sample per pixel, box filter: the weight channel marks the owned pixels)"""
+    fr = mts.filmreduce
+    assert [fr.tile_morton(x, y) for x, y in ((0, 0), (1, 0), (0, 1), (1, 1), (2, 0), (3, 5))] == [0, 1, 2, 3, 4, 39]
+    for n in (2, 4, 8):
+        owner = np.array([[fr.tile_morton(x, y) % n for x in range(32)] for y in range(32)])
+        assert set(np.bincount(owner.reshape(-1), minlength=n)) == {1024 // n}
+    owner = np.array([[fr.tile_morton(x, y) % 8 for x in range(32)] for y in range(32)])
+    for y in range(0, 32, 2):
+        for x in range(0, 32, 4):
+            assert sorted(owner[y:y + 2, x:x + 4].reshape(-1)) == list(range(8))
+    sd = mts.scenes.cornell_c1()
+    fs = orc.FlatScene(sd)
+    W, H, bs = 70, 50, 16
+    cam = orc.make_camera(sd, W, H)
+    prm = orc.render_params(1, sampler=0, spp=1)
+    box = orc.tabulate_filter("box")
+    for r in range(3):
+        film, _ = orc.render_tiles(fs.scene, cam, prm, box, block_size=bs, part=r, n_parts=3)
+        mine = np.flatnonzero(film[..., 4].reshape(-1) > 0)
+        assert np.array_equal(np.sort(fr.tiles_of_rank(W, H, bs, r, 3)), mine)
+
+
+def test_bench_helpers():
+    """bench.py without a GPU: the CPU count it reports honours the cgroup quota, the kernel-source hash is stable"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    n, visible, quota = bench.usable_cpus()
+    assert 1 <= n <= visible == len(os.sched_getaffinity(0))
+    if quota is not None:
+        assert n <= max(1, int(quota + 0.5))
+    h = bench.kernel_source_hash()
+    assert len(h) == 16 and h == bench.kernel_source_hash()
+    assert bench.free_port() > 0
+    st = dict(rays_closest=10, rays_shadow=5, n_inner=100, n_leaf=20, n_idx=30, n_tri_tested=30)
+    assert bench.algorithmic_bytes(st) == 8 * 100 + 8 * 20 + 52 * 30 + 48 * 15
+
+
 def test_serialized_mesh_loader(mts, tmp_path):
     """mtsgpu_load_serialized == TriMesh::TriMesh(Stream *, int) (src/librender/trimesh.cpp:156-236): on files written
     by an independent Python implementation of the format (tests/serialized_io.py) and, where the reference checkout

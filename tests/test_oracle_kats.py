@@ -56,14 +56,24 @@ PRIMES = [2, 3, 5, 7, 11]
 
 
 def test_halton_hammersley_kats(orc):
-    """test_samplers.cpp:33-78: sample i, dimension j == radicalInverse(prime_j, i) (eps 1e-7)"""
+    """test_samplers.cpp:33-78 through the oracle's SAMPLERS (generate(), then next1D() per dimension, advance()):
+    Halton sample i, dimension j == radicalInverse(prime_j, i); Hammersley: i / sampleCount first, then those (eps 1e-7)"""
     L = orc.lib()
     for i in range(5):
         for j in range(5):
             assert abs(L.orc_radical_inverse(PRIMES[j], i) - HALTON[i * 5 + j]) <= 1e-7
-    # Hammersley: first dimension i/N, then the Halton dimensions
+    table = np.array(HALTON).reshape(5, 5)
+    halton = orc.render_params(4, sampler=2, spp=5)
+    hammersley = orc.render_params(4, sampler=3, spp=5)
     for i in range(5):
-        assert abs(np.float32(i) / np.float32(5) - [0.0, 1 / 5, 2 / 5, 3 / 5, 4 / 5][i]) <= 1e-7
+        for key in (0, 12345):                      # the QMC samplers restart at every pixel (halton.cpp:58-61)
+            got = orc.sampler_values(halton, key, i, 5)
+            assert np.abs(got.astype(np.float64) - table[i]).max() <= 1e-7
+            got = orc.sampler_values(hammersley, key, i, 6)
+            assert np.abs(got.astype(np.float64) - np.concatenate([[i / 5.0], table[i]])).max() <= 1e-7
+    # next2D() draws two consecutive dimensions, x first
+    got = orc.sampler_values(halton, 0, 3, 2, two_d=True)
+    assert np.abs(got.reshape(-1).astype(np.float64) - table[3, :4]).max() <= 1e-7
 
 
 def test_radical_inverse_incremental(orc):
