@@ -141,7 +141,8 @@ def test_avg_path_length_statistic(gpu_lib, mts, orc):
     scene, cam, it = _ctx(mts, sd, 48, 40, "ldsampler", 8, max_depth=4)
     assert it.render()
     st = it.stats()
-    _, ost = orc.render(orc.FlatScene(sd).scene, orc.make_camera(sd, 48, 40), orc.render_params(4, sampler=1, spp=8))
+    oscene = orc.FlatScene(sd)                                           # keep it alive: .scene points into it
+    _, ost = orc.render(oscene.scene, orc.make_camera(sd, 48, 40), orc.render_params(4, sampler=1, spp=8))
     assert st["path_length_sum"] == ost.path_length_sum > st["camera_samples"]
     assert 1.0 < st["avg_path_length"] <= 4.0
     it.set_rfilter("gaussian"); it.clear_film(); assert it.render()
@@ -171,7 +172,11 @@ def test_c4_one_of_eight_shards_at_4096_spp(gpu_lib, mts, orc, c3_full):
     assert st["camera_samples"] == len(keys) * 4096 and len(keys) == 8 * 32 * 32
     own = np.zeros(W * H, dtype=bool); own[keys] = True
     own = own.reshape(H, W)
-    assert (film[~own] == 0).all() and (film[own][:, 4] == 4096).all()
+    # 4096 samples per owned pixel; a (0,2)-sequence value that rounds to exactly 1.0f (ldsampler.cpp:111) puts its
+    # sample into the neighbouring pixel, which may belong to another shard's tile
+    wown = film[own][:, 4]
+    assert np.abs(wown - 4096).max() <= 2 and abs(float(wown.sum()) - 4096.0 * own.sum()) <= 64
+    assert film[~own][:, 4].sum() <= 64
     oscene = orc.FlatScene(sd)
     ocam = orc.make_camera(sd, W, H)
     op = orc.render_params(sd.max_depth, rr_depth=sd.rr_depth, sampler=mts.abi.SAMPLER_LD_KEYED, spp=4096, seed=0x5EED)

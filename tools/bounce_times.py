@@ -1,0 +1,25 @@
+"""Per-bounce kernel times of one C3 frame (MTSGPU_DEBUG=1 prints them): python3 tools/bounce_times.py [spp] [res] [knob=value ...]"""
+import os, sys, time
+os.environ["MTSGPU_DEBUG"] = "1"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import _pkgload
+pkg = _pkgload.load()
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+knobs = dict(a.split("=") for a in sys.argv[3:])
+sd = pkg.scenes.cornell_c3()
+scene = pkg.Scene(sd, None, gpu_binning=True)
+cam = pkg.PerspectiveCamera.for_description(sd, res, res)
+it = pkg.MIPathTracer(maxDepth=sd.max_depth)
+it.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp, seed=0x5EED)
+if knobs:
+    it.set_tuning(**{k: int(v) for k, v in knobs.items()})
+it.set_options(time_kernels=True)
+assert it.render()                      # warm-up (allocations)
+sys.stderr.write("---- frame ----\n")
+t0 = time.perf_counter()
+assert it.render()
+dt = (time.perf_counter() - t0) * 1e3
+st = it.stats()
+print("wall %.2f ms  total(dev) %.2f ms  trace %.2f ms  shade %.2f ms  launches %d  rays %d+%d" % (
+    dt, st["total_ms"], st["trace_ms"], st["shade_ms"], st["trace_launches"], st["rays_closest"], st["rays_shadow"]))
