@@ -213,6 +213,9 @@ typedef struct mtsgpu_stats {
 	uint64_t path_length_sum;
 	/* closest-hit launches repeated with static ray dealing because a material-queue segment overflowed */
 	uint64_t bin_overflow_retries;
+	/* time during which at least one traversal launch was running (the shadow rays of a bounce run next to the
+	 * closest-hit launch of the following one when `overlap` is on: trace_ms then counts that time twice) */
+	double trace_union_ms;
 } mtsgpu_stats;
 
 typedef struct mtsgpu_ctx mtsgpu_ctx;
@@ -266,7 +269,11 @@ int  mtsgpu_set_options(mtsgpu_ctx *ctx, uint64_t max_paths, int count_traversal
  *   refill_min / desc_min / leaf_min (1..64)  lane thresholds of k_trace
  *   batch (1..64, 0 = rule)                   rays per wave and batch
  *   dyn_div (0 = 4)                           1/dyn_div of a large launch's rounds are claimed dynamically
- *   sync_free (-1 rule, 0 off, 1 on)          bounce loop without host round trips (device-side counts)
+ *   sync_free (-1 rule, 0 off, 1 on)          bounce loop without host round trips (device-side counts); the rule
+ *                                             turns it on for passes of at most 8 Mi paths
+ *   chunk (1..1024, default 8)                bounces enqueued between two looks at the queue size (sync_free)
+ *   overlap (0/1)                             host-driven loop: shadow rays of bounce b on a second stream, next to
+ *                                             the closest-hit launch of bounce b + 1
  *   test_retry (0/1)                          treat every first closest-hit launch as overflowed (exercises the retry) */
 int  mtsgpu_set_tuning(mtsgpu_ctx *ctx, const char *key, long value);
 

@@ -19,7 +19,8 @@ import numpy as np
 from . import abi, scenes, filmreduce  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtsgpu.so")
+# MTSGPU_LIB selects an experiment build (tools/build_variant.sh); the product is libmtsgpu.so next to this file
+LIB_PATH = os.environ.get("MTSGPU_LIB") or os.path.join(_HERE, "libmtsgpu.so")
 
 EXPORTS = [
     "mtsgpu_create", "mtsgpu_destroy", "mtsgpu_last_error", "mtsgpu_abi_version", "mtsgpu_abi_sizeof", "mtsgpu_set_stream",

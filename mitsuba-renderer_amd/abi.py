@@ -59,6 +59,7 @@ class Stats(C.Structure):
         ("trace_launches", C.c_uint64),
         ("trace_ms", C.c_double), ("shade_ms", C.c_double), ("total_ms", C.c_double),
         ("path_length_sum", C.c_uint64), ("bin_overflow_retries", C.c_uint64),
+        ("trace_union_ms", C.c_double),
     ]
 
     def as_dict(self):

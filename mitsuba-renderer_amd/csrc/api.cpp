@@ -108,10 +108,14 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	c->q.bin_seg_cap = (uint32_t) segCap;
 	rc |= devAlloc(c, &c->queueA, cap, o); rc |= devAlloc(c, &c->queueB, cap, o);
 	rc |= devAlloc(c, &c->q.shadow, cap, o);
-	rc |= devAlloc(c, &c->q.counters, kNumCounters * kCounterStride, o);
+	rc |= devAlloc(c, &c->counterSets, (size_t) kCounterSets * kNumCounters * kCounterStride, o);
+	rc |= devAlloc(c, &c->viewsDev, kNumBins, o);
+	rc |= devAlloc(c, &c->devStats, kNumDevStats, o);
 	rc |= devAlloc(c, &c->q.trace_counts, 8, o);
-	rc |= devAlloc(c, &c->q.spill, (size_t) gridBlocksMax * kTraceBlock * trace_spill_levels(), o);
+	rc |= devAlloc(c, &c->spillClosest, (size_t) gridBlocksMax * kTraceBlock * trace_spill_levels(), o);
+	rc |= devAlloc(c, &c->spillShadow, (size_t) gridBlocksMax * kTraceBlock * trace_spill_levels(), o);
 	if (rc) return rc;
+	c->q.counters = c->counterSets; c->q.spill = c->spillClosest; c->q.dev_stats = nullptr;
 	c->q.spill_stride = gridBlocksMax * kTraceBlock;
 	c->q.n_cus = c->nCUs; c->q.force_static = 0;
 	applyTuning(c);
@@ -308,44 +312,155 @@ int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatil
 	return 0;
 }
 
+uint32_t *counterSet(mtsgpu_ctx *c, int bounce) { return c->counterSets + (size_t) (bounce & 1) * kNumCounters * kCounterStride; }
+
+long tuningOr(const mtsgpu_ctx *c, const char *key, long dflt) {
+	auto it = c->tuning.find(key);
+	return it == c->tuning.end() ? dflt : it->second;
+}
+
+// Device-driven bounces: the whole chain of launches is enqueued without a single read-back of a queue size.
+// k_trace reads its ray count from the counter the previous stage left in device memory, k_prep turns the shard
+// counters of the closest-hit launch into the per-bin views k_shade reads, grids are sized for the upper bound
+// (the number of paths of the pass) and surplus workgroups exit at once.  This is for frames whose launches are too
+// short to hide a host round trip (a 1-spp frame: ~0.1-0.6 ms per launch, 2 round trips per bounce otherwise); large
+// frames keep the host-sized grids of runBounces.  The host looks at a queue size once per chunk of bounces, to stop.
+int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile const int *cancel) {
+	hipStream_t s1 = c->stream, s2 = c->stream2;
+	const size_t setBytes = (size_t) kNumCounters * kCounterStride * sizeof(uint32_t);
+	HIPCHK(c, hipMemsetAsync(c->counterSets, 0, kCounterSets * setBytes, s1));
+	c->q.dev_stats = c->devStats;        // cleared by the caller (one frame may take several passes)
+	c->devStatsUsed = true;
+	// MIPathTracer traces at most maxDepth rays per path (path.cpp:87), the one-sample direct integrator two
+	const int limit = cfg.integrator == 1 ? 2 : (cfg.max_depth > 0 ? cfg.max_depth : 0x7FFFFFFF);
+	const int chunk = (int) tuningOr(c, "chunk", 8);
+	uint32_t *cur = c->queueA, *nxt = c->queueB;
+	uint32_t upper = nPaths;                   // what the host knows about the queue sizes
+	bool shadowPending = false;
+	int b = 0;
+	auto timed = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used, hipStream_t s, int which) -> int {
+		if (!c->timeKernels) return 0;
+		hipEvent_t *ev = which == 0 ? nextEventPair(c, pool, used) : &pool[used - 1].first;
+		if (!ev) return fail(c, MTSGPU_EHIP, "hipEventCreate failed");
+		HIPCHK(c, hipEventRecord(ev[which], s));
+		return 0;
+	};
+	while (b < limit && upper > 0) {
+		if (cancel && *cancel) { c->q.dev_stats = nullptr; return fail(c, MTSGPU_ECANCEL, "render cancelled"); }
+		const int end = (int) std::min<long long>((long long) b + chunk, limit);
+		for (; b < end; ++b) {
+			uint32_t *set = counterSet(c, b), *prev = counterSet(c, b - 1);
+			c->q.counters = set; c->q.next = nxt; c->q.spill = c->spillClosest;
+			int rc = timed(c->traceEvents, c->traceEvUsed, s1, 0); if (rc) return rc;
+			launch_trace(s1, 0, c->countTraversal, true, c->dsc, c->paths, c->q, cur, upper, b == 0,
+			             b == 0 ? nullptr : prev + (size_t) kCntNext * kCounterStride);
+			rc = timed(c->traceEvents, c->traceEvUsed, s1, 1); if (rc) return rc;
+			// the shading of this bounce adds to Li after the shadow rays of the previous one have (path.cpp:124 before :80)
+			if (shadowPending) HIPCHK(c, hipStreamWaitEvent(s1, c->evShadow[(b - 1) & 1], 0));
+			rc = timed(c->shadeEvents, c->shadeEvUsed, s1, 0); if (rc) return rc;
+			launch_prep(s1, set, prev, c->viewsDev, c->q.bin_seg_cap, c->devStats);
+			BinView none{};
+			for (int bin = 0; bin < kNumBins; ++bin)
+				if (c->binMask & (1u << bin))
+					launch_shade(s1, bin, c->dsc, c->paths, cfg, c->q, none, c->viewsDev, upper);
+			rc = timed(c->shadeEvents, c->shadeEvUsed, s1, 1); if (rc) return rc;
+			HIPCHK(c, hipGetLastError());
+			HIPCHK(c, hipEventRecord(c->evShade[b & 1], s1));
+			// shadow rays of this bounce on the second stream, next to the closest-hit launch of the next bounce
+			HIPCHK(c, hipStreamWaitEvent(s2, c->evShade[b & 1], 0));
+			DQueues q2 = c->q; q2.spill = c->spillShadow;
+			rc = timed(c->traceEvents, c->traceEvUsed, s2, 0); if (rc) return rc;
+			launch_trace(s2, 1, c->countTraversal, false, c->dsc, c->paths, q2, c->q.shadow, upper, b == 0,
+			             set + (size_t) kCntShadow * kCounterStride);
+			rc = timed(c->traceEvents, c->traceEvUsed, s2, 1); if (rc) return rc;
+			HIPCHK(c, hipGetLastError());
+			HIPCHK(c, hipEventRecord(c->evShadow[b & 1], s2));
+			shadowPending = true;
+			std::swap(cur, nxt);
+		}
+		// how many paths are left: the one read-back of the chunk
+		uint32_t *hostNext = &c->hostCounters[kNumCounters * kCounterStride + 2];
+		HIPCHK(c, hipMemcpyAsync(hostNext, counterSet(c, b - 1) + (size_t) kCntNext * kCounterStride, sizeof(uint32_t), hipMemcpyDeviceToHost, s1));
+		HIPCHK(c, hipEventRecord(c->evCount, s1));
+		HIPCHK(c, hipEventSynchronize(c->evCount));
+		upper = *hostNext;
+	}
+	if (shadowPending) HIPCHK(c, hipStreamWaitEvent(s1, c->evShadow[(b - 1) & 1], 0));
+	c->q.dev_stats = nullptr; c->q.counters = c->counterSets; c->q.spill = c->spillClosest;
+	return 0;
+}
+
+// the statistics a device-driven frame kept on the device (the host-driven loop counts on the host)
+int collectDeviceStats(mtsgpu_ctx *c) {
+	if (!c->devStatsUsed) return 0;
+	c->devStatsUsed = false;
+	unsigned long long h[kNumDevStats];
+	HIPCHK(c, hipMemcpy(h, c->devStats, sizeof(h), hipMemcpyDeviceToHost));
+	c->stats.rays_closest += h[kStatClosest]; c->stats.rays_shadow += h[kStatShadow]; c->stats.trace_launches += h[kStatLaunches];
+	if (h[kStatOverflow]) return fail(c, MTSGPU_EHIP, "internal: bin segment overflow in a device-driven frame");
+	return 0;
+}
+
 // One wavefront pass: all bounces of the paths already generated into queueA[0..nPaths)
 int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile const int *cancel) {
+	c->q.counters = c->counterSets; c->q.spill = c->spillClosest; c->q.dev_stats = nullptr;
 	if (cfg.integrator == 1 && (cfg.n_lum > 1 || cfg.n_bsdf > 1))
 		return runDirectRounds(c, cfg, nPaths, cancel);
+	{
+		// frames of few paths are chains of launches too short to hide a host round trip
+		const long sf = tuningOr(c, "sync_free", -1);
+		if (sf == 1 || (sf < 0 && nPaths <= (8u << 20)))
+			return runBouncesDevice(c, cfg, nPaths, cancel);
+	}
+	// measured on the 64-spp frame: two chip-filling persistent grids at once run 15 % slower than one after the other
+	// (they evict each other's working set), so the overlap is reserved for the short launches of device-driven frames
+	const bool overlap = tuningOr(c, "overlap", 0) != 0;
 	uint32_t nQ = nPaths;
 	uint32_t *cur = c->queueA, *nxt = c->queueB;
 	bool first = true;       // camera rays and their shadow rays are coherent: plain 64-ray batches win there
-	hipStream_t s = c->stream;
-	while (nQ > 0) {
+	hipStream_t s = c->stream, s2 = overlap ? c->stream2 : c->stream;
+	const size_t setBytes = (size_t) kNumCounters * kCounterStride * sizeof(uint32_t);
+	bool shadowPending = false;
+	int b = 0;
+	for (; nQ > 0; ++b) {
 		if (cancel && *cancel)
 			return fail(c, MTSGPU_ECANCEL, "render cancelled");
-		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, kNumCounters * kCounterStride * sizeof(uint32_t), s));
+		// the counter set of this bounce; its last users (bounce b - 2) are done: the shading of bounce b - 1 waited for them
+		c->q.counters = counterSet(c, b); c->q.spill = c->spillClosest;
+		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, setBytes, s));
 		c->q.next = nxt;
 		// closest hit + material sort
 		BinView views[kNumBins];
 		int rc = traceAndBin(c, cur, nQ, first, views); if (rc) return rc;
 		c->stats.rays_closest += nQ;
+		// the shading of this bounce adds to Li after the shadow rays of the previous one have (path.cpp:124 before :80)
+		if (shadowPending && overlap) HIPCHK(c, hipStreamWaitEvent(s, c->evShadow[(b - 1) & 1], 0));
 		// shade, one launch per BSDF type
 		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
 		if (sev) HIPCHK(c, hipEventRecord(sev[0], s));
-		for (int b = 0; b < kNumBins; ++b)
-			launch_shade(s, b, c->dsc, c->paths, cfg, c->q, views[b]);
+		for (int bin = 0; bin < kNumBins; ++bin)
+			launch_shade(s, bin, c->dsc, c->paths, cfg, c->q, views[bin]);
 		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
 		HIPCHK(c, hipGetLastError());
-		HIPCHK(c, hipMemcpyAsync(c->hostCounters, c->q.counters, kNumCounters * kCounterStride * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-		HIPCHK(c, hipStreamSynchronize(s));
-		const uint32_t nNext = c->hostCounters[kNumBins * kBinShards * kCounterStride], nShadow = c->hostCounters[(kNumBins * kBinShards + 1) * kCounterStride];
-		// shadow rays of this bounce (adds the direct-light term before the next bounce adds its own)
+		rc = readCounters(c); if (rc) return rc;
+		const uint32_t nNext = c->hostCounters[kCntNext * kCounterStride], nShadow = c->hostCounters[kCntShadow * kCounterStride];
+		// shadow rays of this bounce (they add the direct-light term before the next bounce adds its own); on the second
+		// stream, so that the closest-hit launch of the next bounce runs next to them -- the shading above has completed
 		if (nShadow) {
+			DQueues q2 = c->q; q2.spill = c->spillShadow;
 			hipEvent_t *ev2 = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
-			if (ev2) HIPCHK(c, hipEventRecord(ev2[0], s));
-			launch_trace(s, 1, c->countTraversal, false, c->dsc, c->paths, c->q, c->q.shadow, nShadow, first);
-			if (ev2) HIPCHK(c, hipEventRecord(ev2[1], s));
+			if (ev2) HIPCHK(c, hipEventRecord(ev2[0], s2));
+			launch_trace(s2, 1, c->countTraversal, false, c->dsc, c->paths, q2, c->q.shadow, nShadow, first);
+			if (ev2) HIPCHK(c, hipEventRecord(ev2[1], s2));
 			HIPCHK(c, hipGetLastError());
+			if (overlap) HIPCHK(c, hipEventRecord(c->evShadow[b & 1], s2));
+			shadowPending = true;
 			c->stats.rays_shadow += nShadow; c->stats.trace_launches++;
+		} else {
+			shadowPending = false;
 		}
 		if (getenv("MTSGPU_DEBUG")) {
-			HIPCHK(c, hipStreamSynchronize(s));
+			HIPCHK(c, hipStreamSynchronize(s)); HIPCHK(c, hipStreamSynchronize(s2));
 			float a = 0, b2 = 0, c2 = 0;
 			if (c->timeKernels) {
 				const size_t ti = c->traceEvUsed - (nShadow ? 2 : 1);
@@ -360,6 +475,8 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		nQ = nNext;
 		first = false;
 	}
+	if (shadowPending && overlap) HIPCHK(c, hipStreamWaitEvent(s, c->evShadow[(b - 1) & 1], 0));
+	c->q.counters = c->counterSets;
 	return 0;
 }
 
@@ -373,8 +490,23 @@ int checkReady(mtsgpu_ctx *c) {
 
 void collectTimings(mtsgpu_ctx *c) {
 	float ms;
-	for (size_t i = 0; i < c->traceEvUsed; ++i)
-		if (hipEventElapsedTime(&ms, c->traceEvents[i].first, c->traceEvents[i].second) == hipSuccess) c->stats.trace_ms += ms;
+	// traversal launches may overlap (two streams): their summed durations and the length of the union of their intervals
+	std::vector<std::pair<float, float>> iv;
+	for (size_t i = 0; i < c->traceEvUsed; ++i) {
+		if (hipEventElapsedTime(&ms, c->traceEvents[i].first, c->traceEvents[i].second) != hipSuccess) continue;
+		c->stats.trace_ms += ms;
+		float t0 = 0;
+		if (i == 0 || hipEventElapsedTime(&t0, c->traceEvents[0].first, c->traceEvents[i].first) == hipSuccess)
+			iv.emplace_back(t0, t0 + ms);
+	}
+	std::sort(iv.begin(), iv.end());
+	float curA = 0, curB = -1;
+	for (auto &p : iv) {
+		if (curB < curA) { curA = p.first; curB = p.second; }
+		else if (p.first <= curB) curB = std::max(curB, p.second);
+		else { c->stats.trace_union_ms += curB - curA; curA = p.first; curB = p.second; }
+	}
+	if (curB >= curA) c->stats.trace_union_ms += curB - curA;
 	for (size_t i = 0; i < c->shadeEvUsed; ++i)
 		if (hipEventElapsedTime(&ms, c->shadeEvents[i].first, c->shadeEvents[i].second) == hipSuccess) c->stats.shade_ms += ms;
 	c->traceEvUsed = c->shadeEvUsed = 0;
@@ -429,6 +561,13 @@ int mtsgpu_create(int device, mtsgpu_ctx **out) {
 	c->nCUs = (uint32_t) std::max(1, prop.multiProcessorCount);
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(nullptr, MTSGPU_EHIP, "hipStreamCreate failed"); }
 	c->ownStream = true;
+	{
+		bool ok = hipStreamCreate(&c->stream2) == hipSuccess && hipEventCreateWithFlags(&c->evCount, hipEventDisableTiming) == hipSuccess;
+		for (int i = 0; i < 2 && ok; ++i)
+			ok = hipEventCreateWithFlags(&c->evShade[i], hipEventDisableTiming) == hipSuccess
+			  && hipEventCreateWithFlags(&c->evShadow[i], hipEventDisableTiming) == hipSuccess;
+		if (!ok) { mtsgpu_destroy(c); return fail(nullptr, MTSGPU_EHIP, "stream / event creation failed"); }
+	}
 	if (hipHostMalloc((void **) &c->hostCounters, (kNumCounters * kCounterStride + 4) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
 		(void) hipStreamDestroy(c->stream); delete c; return fail(nullptr, MTSGPU_EHIP, "hipHostMalloc failed");
 	}
@@ -476,6 +615,8 @@ void mtsgpu_destroy(mtsgpu_ctx *c) {
 	for (auto &e : c->traceEvents) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
 	for (auto &e : c->shadeEvents) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
 	if (c->ownStream && c->stream) (void) hipStreamDestroy(c->stream);
+	if (c->stream2) (void) hipStreamDestroy(c->stream2);
+	for (hipEvent_t e : { c->evShade[0], c->evShade[1], c->evShadow[0], c->evShadow[1], c->evCount }) if (e) (void) hipEventDestroy(e);
 	delete c;
 }
 
@@ -721,6 +862,10 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	d.n_lums = sc->n_lums; d.n_nodes = sc->n_nodes; d.n_tris = sc->n_tris; d.n_shapes = sc->n_shapes;
 	for (int a = 0; a < 3; ++a) { d.aabb_min[a] = sc->aabb_min[a]; d.aabb_max[a] = sc->aabb_max[a]; }
 	c->dsc = d; c->nTris = sc->n_tris;
+	// material queues that can ever be non-empty: the BSDF types of shapes that have one, and the "terminal" bin
+	c->binMask = 1u << kNumBsdfTypes;
+	for (uint32_t sIdx = 0; sIdx < sc->n_shapes; ++sIdx)
+		if (sc->shape_bsdf[sIdx] >= 0) c->binMask |= 1u << (sc->bsdf_type[sc->shape_bsdf[sIdx]] & 0xFFu);
 	c->haveScene = true;
 	return 0;
 }
@@ -839,7 +984,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);
@@ -931,6 +1076,8 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	DConfig cfg = makeConfig(c, false);
 	cfg.pix_w = keyW; cfg.pix_off = off;
 	HIPCHK(c, hipMemsetAsync(c->pathLen, 0, sizeof(unsigned long long), c->stream));
+	HIPCHK(c, hipMemsetAsync(c->devStats, 0, kNumDevStats * sizeof(unsigned long long), c->stream));
+	c->devStatsUsed = false;
 	const size_t fullBlock = (size_t) (bs + 2 * c->filtBorder) * (bs + 2 * c->filtBorder) * 5;
 	if (wideFilter) {
 		rc = ensureBuf(c, &c->tileMeta, &c->tileMetaCap, tiles.size()); if (rc) return rc;
@@ -994,6 +1141,7 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	HIPCHK(c, hipEventElapsedTime(&ms, t0, t1));
 	c->stats.total_ms = ms;
 	collectTimings(c);
+	rc = collectDeviceStats(c); if (rc) return rc;
 	if (c->countTraversal) { rc = fetchTraceCounts(c); if (rc) return rc; }
 	return 0;
 }
@@ -1137,6 +1285,8 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 	}
 	launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList, n, c->explicitSamples, n, c->queueA);
 	HIPCHK(c, hipGetLastError());
+	HIPCHK(c, hipMemsetAsync(c->devStats, 0, kNumDevStats * sizeof(unsigned long long), c->stream));
+	c->devStatsUsed = false;
 	rc = runBounces(c, cfg, n, nullptr); if (rc) return rc;
 	std::vector<float> Li(4 * (size_t) n), thr(4 * (size_t) n), spos(4 * (size_t) n);
 	const size_t pitch = kPathSlots * sizeof(float4);
@@ -1152,7 +1302,7 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 		o[4] = spos[4 * i]; o[5] = spos[4 * i + 1]; o[6] = (float) depth; o[7] = 0.0f;
 	}
 	collectTimings(c);
-	return 0;
+	return collectDeviceStats(c);
 }
 
 // --- host-side flattening ------------------------------------------------------

@@ -12,6 +12,10 @@ struct mtsgpu_ctx {
 	uint32_t nCUs = 256;                   // hipDeviceProp_t::multiProcessorCount
 	hipStream_t stream = nullptr;
 	bool ownStream = false;
+	// second stream: the shadow rays of bounce b are traced on it while `stream` already traces the closest hits of
+	// bounce b + 1 (both only depend on the shading of bounce b); evShade / evShadow order the two
+	hipStream_t stream2 = nullptr;
+	hipEvent_t evShade[2] = { nullptr, nullptr }, evShadow[2] = { nullptr, nullptr }, evCount = nullptr;
 	std::string error;
 
 	// scene
@@ -53,6 +57,12 @@ struct mtsgpu_ctx {
 	uint16_t *primes = nullptr;        // primeTable (util.cpp:64-122) on the device
 	uint32_t *explicitSamples = nullptr; size_t explicitCap = 0;
 	uint32_t *hostCounters = nullptr;       // pinned
+	uint32_t *counterSets = nullptr;        // kCounterSets x kNumCounters lines, used by alternate bounces
+	uint32_t *spillClosest = nullptr, *spillShadow = nullptr;   // the two traversal kernels run concurrently
+	mg::BinView *viewsDev = nullptr;        // device-driven bounces: per-bin views written by k_prep
+	unsigned long long *devStats = nullptr; // kStat* counters of a device-driven frame
+	bool devStatsUsed = false;              // a device-driven pass ran since the statistics were cleared
+	uint32_t binMask = 0x1FFu;              // bins that can be non-empty with the uploaded scene (BSDF types present + terminal)
 	unsigned long long *pathLen = nullptr;  // device: sum of the final path depths of a render (avgPathLength)
 	std::vector<void *> pathAllocs;
 

@@ -16,7 +16,17 @@ constexpr int kLumStride = 32;        // MTSGPU_LUM_NPARAMS
 constexpr int kCounterStride = 32;    // one 128-byte line per queue counter (atomics on one line serialise)
 constexpr int kBinShards = 16;        // the closest-hit kernel appends to bins[b] through 16 independent segments
 constexpr int kNumCounters = kNumBins * kBinShards + 4;   // bins x shards, next, shadow, dynamic heads of the two traversal launches
-constexpr int kShadeBlock = 512;
+// Two sets of counters, used by alternate bounces: the shadow rays of bounce b are traced (second stream) while the
+// closest-hit launch of bounce b + 1 already fills the next set
+constexpr int kCounterSets = 2;
+constexpr int kCntNext = kNumBins * kBinShards, kCntShadow = kCntNext + 1, kCntDynClosest = kCntNext + 2, kCntDynShadow = kCntNext + 3;
+#ifndef MG_SHADE_BLOCK
+#define MG_SHADE_BLOCK 512
+#endif
+constexpr int kShadeBlock = MG_SHADE_BLOCK;
+// device-side frame statistics (u64): rays of the closest-hit / shadow launches, segment-overflow flag, non-empty
+// traversal launches -- what the host counts itself when it reads the queue sizes back every bounce
+enum { kStatClosest = 0, kStatShadow = 1, kStatOverflow = 2, kStatLaunches = 3, kNumDevStats = 4 };
 
 // Scene in HBM (all pointers are device pointers); see DESIGN.md section 3
 struct DScene {
@@ -129,22 +139,64 @@ struct DQueues {
 	uint32_t bin_seg_cap;
 	uint32_t *next;               // paths that continue (input of the next closest-hit launch)
 	uint32_t *shadow;             // paths with a pending shadow ray
-	uint32_t *counters;           // [i * kCounterStride]: i = b * kBinShards + shard for the bins, then next, shadow
+	uint32_t *counters;           // the counter set of this bounce, [i * kCounterStride]: i = b * kBinShards + shard for the bins, then kCnt*
 	unsigned long long *trace_counts;  // n_inner, n_leaf, n_idx, n_tri_tested + lane slots of the three loops and batches (u64 x 8)
-	uint32_t *spill;              // traversal stack overflow: [level][thread]
+	unsigned long long *dev_stats;     // kStat* (may be NULL)
+	uint32_t *spill;              // traversal stack overflow: [level][thread]; one buffer per traversal mode (the two run concurrently)
 	uint32_t spill_stride;
 	uint32_t desc_min;                 // k_trace leaves its descent loop when fewer lanes than this are on inner nodes (>= 1)
 	uint32_t leaf_min;                 // ... and its primitive loop when fewer lanes than this have leaf entries left (>= 1)
-	uint32_t static_n, dyn_slot;       // k_trace: statically dealt queue prefix; counter (line index) of the dynamic head
 	uint32_t refill_min;               // k_trace refills its idle lanes once this many are idle (1..64)
-	uint32_t batch;                    // k_trace: rays per wave and batch (64; fewer when the launch cannot fill the chip)
+	uint32_t coherent;                 // the rays of this launch are camera rays / their shadow rays: plain 64-ray batches
 	uint32_t n_cus;                    // hipDeviceProp_t::multiProcessorCount: the persistent grids are sized from it
-	uint32_t force_static;             // k_trace launcher: deal the whole queue statically (retry after a bin segment overflow)
-	// experiment knobs of the k_trace launcher (mtsgpu_set_tuning; 0 = the default rule)
+	uint32_t force_static;             // deal the whole queue statically (retry after a bin segment overflow; device-driven bounces)
+	// experiment knobs of the k_trace schedule (mtsgpu_set_tuning; 0 = the default rule)
 	uint32_t tune_batch;               // rays per wave and batch, 1..64
 	uint32_t tune_dyn_div;             // 1/x of the rounds of a large launch are claimed dynamically (default 4)
 	uint32_t tune_refill;              // refill threshold for coherent launches too (default: 64 there)
 };
+
+// How one traversal launch over n rays is scheduled.  A pure function of (n, mode, q): the host evaluates it to size
+// the grid when it knows n, the kernel evaluates it again -- with n read from device memory when the host does not
+// know it (device-driven bounces) -- so both agree on who owns which batch.
+struct TracePlan {
+	uint32_t batch;        // rays per wave and batch (64; fewer when the launch cannot fill the chip)
+	uint32_t blocks;       // workgroups that take part (the rest of a worst-case grid exits at once)
+	uint32_t static_n;     // statically dealt queue prefix: whole rounds of the grid, or the whole queue
+	uint32_t refill_min, desc_min, leaf_min;
+};
+__host__ __device__ inline TracePlan trace_plan(uint32_t n, int mode, const DQueues &q) {
+	TracePlan p;
+	const uint32_t wavesPerBlock = kTraceBlock / 64;
+	const uint32_t maxBlocks = q.n_cus * trace_blocks_per_cu(mode);
+	// rays per wave: 64, or the smallest power of two (>= 8) with which the launch still fits into one round of the
+	// persistent grid -- a launch that cannot fill the lanes of the chip trades idle lanes for shorter waves
+	uint32_t batch = 64;
+	if (!q.coherent) while (batch > 8u && (unsigned long long) (batch / 2) * wavesPerBlock * maxBlocks >= n) batch /= 2;
+	if (q.tune_batch >= 1 && q.tune_batch <= 64) batch = q.tune_batch;
+	p.batch = batch;
+	const uint32_t need = (uint32_t) (((unsigned long long) n + batch * wavesPerBlock - 1) / (batch * wavesPerBlock));
+	p.blocks = need < maxBlocks ? need : maxBlocks;
+	// static share of the queue: whole rounds of the grid; the last quarter of the rounds and the remainder are
+	// claimed dynamically (one atomic per 64-ray batch, far below the ~88 / us a single counter sustains)
+	const uint32_t perRound = p.blocks * wavesPerBlock * batch;
+	const uint32_t rounds = perRound ? n / perRound : 0u;
+	const uint32_t dynDiv = q.tune_dyn_div ? q.tune_dyn_div : 4u;
+	// small launches stay fully static: their waves finish together and would hit the counter in one burst
+	const bool dynamic = rounds >= 8u && !q.force_static;
+	uint32_t dynRounds = dynamic ? rounds / dynDiv : 0u;
+	if (dynamic && dynRounds < 1u) dynRounds = 1u;
+	p.static_n = dynamic ? (rounds - dynRounds) * perRound : n;
+	// the early loop exits trade the latency of a few straggling rays for throughput; with only a few
+	// batches per wave the stragglers are the critical path, so small launches run the plain loops
+	p.desc_min = q.desc_min; p.leaf_min = q.leaf_min; p.refill_min = q.refill_min;
+	if (n < 8u * (q.n_cus * kTraceBlocksPerCuMax) * kTraceBlock || q.coherent)
+		p.desc_min = p.leaf_min = 1;
+	if (q.coherent && !q.tune_refill)
+		p.refill_min = 64;       // neighbouring camera samples finish together: refilling would only mix batches
+	if (p.refill_min > batch) p.refill_min = batch;
+	return p;
+}
 
 // --- launchers (kernels.hip) -------------------------------------------------
 // state_out (may be NULL): where the generate() stream of each slot stands after its tables
@@ -160,12 +212,20 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 // mode 0: closest hit over ps.ray_* (writes ps.hit, bins ids by material)
 // mode 1: shadow rays over ps.sh_* (adds ps.nee to ps.Li when unoccluded)
 // mode 2: any-hit over ps.ray_* (writes ps.hit.w = occluded) -- test/benchmark API
+// n_dev == NULL: n rays, grid sized for them.  n_dev != NULL: the count is read from device memory by the kernel and n
+// is only its upper bound (device-driven bounces: the host never learns the queue sizes)
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
-                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent);
+                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *n_dev = nullptr);
 // prefix[s] = number of entries of the bin in segments < s (prefix[kBinShards] = total)
 struct BinView { uint32_t prefix[kBinShards + 1]; };
+// views_dev == NULL: the bin has view.prefix[kBinShards] entries.  Otherwise the view is views_dev[bin] (written by
+// k_prep on the device) and n_bound bounds its size
 void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
-                  const DQueues &q, const BinView &view);
+                  const DQueues &q, const BinView &view, const BinView *views_dev = nullptr, uint32_t n_bound = 0);
+// device-driven bounces: per-bin views from the shard counters of the closest-hit launch that just ran (`cur`), and
+// the counter set of the next bounce zeroed
+void launch_prep(hipStream_t s, const uint32_t *cur, uint32_t *next_set, BinView *views_dev, uint32_t bin_seg_cap,
+                 unsigned long long *dev_stats);
 // path_len (may be NULL): u64 sum of the final path depths (the avgPathLength statistic, path.cpp:212-213)
 void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,
                        uint32_t spp_per_slot, float *film, unsigned long long *path_len);

@@ -455,8 +455,8 @@ size_t trace_stack_levels() { return kStackLDS + kSpillLevels; }
 // `first` is the queue index of the wave's first batch, `stride` the distance to its next one, `static_n` the
 // statically dealt prefix of the queue.
 template <int MODE, bool COUNT, bool BIN>
-__device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n,
-                                           const uint32_t first, const uint32_t stride, const uint32_t static_n,
+__device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, const DQueues &q, const TracePlan &plan,
+                                           const uint32_t *queue, uint32_t n, const uint32_t first, const uint32_t stride,
                                            uint32_t (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock]) {
 	const uint32_t tid = threadIdx.x;
 	const uint32_t gtid = blockIdx.x * kTraceBlock + tid;     // spill slot of this lane
@@ -467,7 +467,7 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 	uint32_t w_inner = 0, w_leaf = 0, w_outer = 0, w_batch = 0;   // COUNT: lane slots issued per loop (64 per wave iteration)
 #define MG_WSLOT(w) do { if (COUNT && lane == (uint32_t) __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) (w) += 64u; } while (0)
 
-	// Ray supply of a wave.  The first q.static_n queue entries are dealt out statically: the wave owns the batches
+	// Ray supply of a wave.  The first plan.static_n queue entries are dealt out statically: the wave owns the batches
 	// (64 consecutive entries) wave_id, wave_id + n_waves, ... and walks them without any atomic.  The rest of the
 	// queue (about a quarter) is claimed batch by batch through ONE counter once the static share is used up, which
 	// evens out the finishing times of the waves (measured: the mean wave used to live 0.90-0.94 of the kernel).
@@ -475,12 +475,12 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 	// finished rays are retired together (one hit store + one binning step) and the idle lanes take new rays.
 	// A launch with fewer rays than the chip has lanes runs B < 64 rays per wave (lanes >= B stay idle): a wave lasts
 	// as long as its slowest ray, and with the wave slots to spare narrower batches shorten that critical path.
-	const uint32_t B = q.batch;
+	const uint32_t B = plan.batch, static_n = plan.static_n;
 	const uint64_t limitMask = (B >= 64u) ? ~0ull : ((1ull << B) - 1ull);
 	uint32_t next_static = first;           // queue index of this wave's next static batch (uniform)
 	uint32_t sup_base = 0, sup_left = 0;    // the chunk being handed out: queue[sup_base .. sup_base + sup_left)
 	bool dyn_done = static_n >= n;          // nothing (left) to claim dynamically
-	const uint32_t refill_min = q.refill_min, desc_min = q.desc_min, leaf_min = q.leaf_min;
+	const uint32_t refill_min = plan.refill_min, desc_min = plan.desc_min, leaf_min = plan.leaf_min;
 
 	uint32_t id = 0;
 	float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, rx = 1, ry = 1, rz = 1;
@@ -506,7 +506,7 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 				sup_base = next_static; sup_left = (static_n - next_static < B) ? static_n - next_static : B; next_static += stride;
 			} else if (!dyn_done) {
 				uint32_t b = 0;
-				if (lane == 0) b = atomicAdd(&q.counters[q.dyn_slot * kCounterStride], 1u);
+				if (lane == 0) b = atomicAdd(&q.counters[(MODE == 0 ? kCntDynClosest : kCntDynShadow) * kCounterStride], 1u);
 				b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
 				const unsigned long long base = (unsigned long long) static_n + (unsigned long long) B * b;
 				if (base < n) { sup_base = (uint32_t) base; sup_left = (n - sup_base < B) ? n - sup_base : B; }
@@ -813,13 +813,45 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 
 template <int MODE, bool COUNT, bool BIN>
 __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trace(DScene sc, DPaths ps, DQueues q,
-                                                          const uint32_t *queue, uint32_t n) {
+                                                          const uint32_t *queue, uint32_t n_host, const uint32_t *n_dev) {
 	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
 	__shared__ uint32_t s_mbox[8][kTraceBlock];
-	const uint32_t first = (blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6)) * q.batch;
-	const uint32_t stride = gridDim.x * (kTraceBlock / 64u) * q.batch;      // queue entries per round of the grid
-	// q.static_n: whole rounds of the grid (or the whole queue of a small launch)
-	trace_body<MODE, COUNT, BIN>(sc, ps, q, queue, n, first, stride, q.static_n, s_stack, s_mbox);
+	// the number of rays: known to the host, or left in device memory by the kernel that filled the queue
+	const uint32_t n = n_dev ? (uint32_t) __builtin_amdgcn_readfirstlane((int) *n_dev) : n_host;
+	const TracePlan plan = trace_plan(n, MODE, q);
+	if (blockIdx.x >= plan.blocks)
+		return;                            // a grid sized for the worst case: nothing left for this workgroup
+	if (q.dev_stats && blockIdx.x == 0 && threadIdx.x == 0) {
+		atomicAdd(&q.dev_stats[MODE == 0 ? kStatClosest : kStatShadow], (unsigned long long) n);
+		atomicAdd(&q.dev_stats[kStatLaunches], 1ull);
+	}
+	const uint32_t first = (blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6)) * plan.batch;
+	const uint32_t stride = plan.blocks * (kTraceBlock / 64u) * plan.batch;      // queue entries per round of the grid
+	trace_body<MODE, COUNT, BIN>(sc, ps, q, plan, queue, n, first, stride, s_stack, s_mbox);
+}
+
+// Device-driven bounces: the per-bin views k_shade needs, from the shard counters the closest-hit launch left in `cur`
+// (what the host computes from a read-back otherwise), and the counter set of the NEXT bounce cleared.  One workgroup.
+__global__ __launch_bounds__(256) void k_prep(const uint32_t *cur, uint32_t *next_set, BinView *views, uint32_t bin_seg_cap,
+                                              unsigned long long *dev_stats) {
+	__shared__ uint32_t s_cnt[kNumBins * kBinShards];
+	const uint32_t t = threadIdx.x;
+	if (t < (uint32_t) (kNumBins * kBinShards)) {
+		const uint32_t c = cur[t * kCounterStride];
+		s_cnt[t] = c;
+		if (c > bin_seg_cap && dev_stats) atomicAdd(&dev_stats[kStatOverflow], 1ull);
+	}
+	if (t < (uint32_t) kNumCounters) next_set[t * kCounterStride] = 0u;
+	__syncthreads();
+	if (t < (uint32_t) kNumBins) {
+		uint32_t acc = 0;
+		for (int k = 0; k < kBinShards; ++k) {
+			views[t].prefix[k] = acc;
+			const uint32_t c = s_cnt[t * kBinShards + k];
+			acc += c < bin_seg_cap ? c : bin_seg_cap;      // entries beyond the capacity were dropped (and flagged)
+		}
+		views[t].prefix[kBinShards] = acc;
+	}
 }
 
 // ===========================================================================
@@ -831,9 +863,9 @@ struct Its {
 };
 
 // fillIntersectionRecord<true> (include/mitsuba/render/skdtree.h:352-432)
-__device__ __forceinline__ void fill_its(const DScene &sc, V3 rayO, V3 rayD, float t, uint32_t prim, float u, float v, Its &its) {
-	const float4 *TP = sc.tri_pos + kTriStride * (size_t) prim;
-	const float4 t0 = TP[0], t1 = TP[1], t2 = TP[2];
+// t0, t1, t2: the first three chunks of the primitive's gather record (sc.tri_pos), fetched by the caller
+__device__ __forceinline__ void fill_its(const DScene &sc, V3 rayO, V3 rayD, float t, uint32_t prim, float u, float v,
+                                         const float4 t0, const float4 t1, const float4 t2, Its &its) {
 	V3 sS, sT;
 	if (__float_as_uint(t2.w) & 0x80000000u) {
 		// Sphere::fillIntersectionRecord (src/shapes/sphere.cpp:136-178): its.p = ray(t), frame from dpdu / dpdv
@@ -1664,34 +1696,26 @@ __device__ __forceinline__ float mi_weight(float pdfA, float pdfB) {     // path
 // one-sample direct integrator run the one without that code
 // The iteration for ONE path (id): what it leaves behind in registers is whether the path continues and its pending
 // direct-light term with the shadow ray that guards it.
+// The path's 128-byte record is staged in LDS by k_shade (`row`, slot k = record slot k): ro / rd / h / T4 / L4 were
+// read from it already and, for a valid hit, slots 0, 1, 3 now hold the primitive's position chunks (see k_shade).
+// What changes is written back to `row`: ray_o, ray_d, bsdf when the path continues; thr, Li, misc always.
 template <int BT, bool ROUNDS>
 __device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, const DConfig &cfg, const uint32_t id,
-                                           bool &continues, bool &wantShadow, V3 &neeV, V3 &shO, V3 &shD) {
+                                           const float4 ro, const float4 rd, const uint4 h, const float4 T4, const float4 L4,
+                                           float4 *row, bool &continues, bool &wantShadow, V3 &neeV, V3 &shO, V3 &shD) {
 	{
 		// rounds of MIDirectIntegrator (DConfig::dr_mode): later BSDF samples start again from the camera hit
 		const int mode = ROUNDS ? cfg.dr_mode : 0;
 		const bool skipToNee = ROUNDS && mode == 1 && cfg.dr_index > 0, skipToBsdf = ROUNDS && mode == 2;
-		float4 ro, rd; uint4 h;
-		if (skipToBsdf && cfg.dr_index > 0) {
-			ro = ps.prim[3 * (size_t) id]; rd = ps.prim[3 * (size_t) id + 1];
-			h = reinterpret_cast<const uint4 &>(ps.prim[3 * (size_t) id + 2]);
-		} else {
-			ro = ps.ray_o(id); rd = ps.ray_d(id); h = ps.hit(id);
-			if (skipToBsdf && cfg.n_bsdf > 1) {
-				ps.prim[3 * (size_t) id] = ro; ps.prim[3 * (size_t) id + 1] = rd;
-				ps.prim[3 * (size_t) id + 2] = reinterpret_cast<const float4 &>(h);
-			}
-		}
 		const V3 rayO(ro.x, ro.y, ro.z), rayD(rd.x, rd.y, rd.z);
 		const bool valid = h.w != kNoPrim;
-		float4 T4 = ps.thr(id), L4 = ps.Li(id);
 		V3 thr(T4.x, T4.y, T4.z), Li(L4.x, L4.y, L4.z);
 		int depth = __float_as_int(T4.w);
 		uint32_t flags = __float_as_uint(L4.w);
 		PathSampler smp;
 		uint2 misc_zw;
 		{
-			const uint4 r = ps.misc(id);
+			const uint4 r = reinterpret_cast<const uint4 &>(row[6]);
 			smp.stream = (uint64_t) r.x | ((uint64_t) r.y << 32);
 			smp.slot = cfg.slot_per_path ? id : (id / cfg.spp);
 			smp.j = r.z;
@@ -1701,7 +1725,7 @@ __device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, c
 		const bool direct = cfg.integrator == 1;
 		Its its;
 		if (valid)
-			fill_its(sc, rayO, rayD, __uint_as_float(h.x), h.w, __uint_as_float(h.y), __uint_as_float(h.z), its);
+			fill_its(sc, rayO, rayD, __uint_as_float(h.x), h.w, __uint_as_float(h.y), __uint_as_float(h.z), row[0], row[1], row[3], its);
 		const int shapeLum = valid ? sc.shape_lum[its.shape] : -1;
 
 		do {
@@ -1717,7 +1741,7 @@ __device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, c
 					break;
 			} else {
 				// ---- tail of the previous iteration (path.cpp:147-208) ----
-				const float4 B4 = ps.bsdf(id);
+				const float4 B4 = row[5];
 				const V3 bsdfVal(B4.x, B4.y, B4.z);
 				const float bsdfPdf = B4.w;
 				const uint32_t sampledType = flags >> F_ST_SHIFT;
@@ -1849,39 +1873,105 @@ __device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, c
 			if (woDotGeoN * woL.z <= 0 && strict)
 				break;
 			// ray = Ray(its.p, wo, time): mint = Epsilon, maxt = inf
-			ps.ray_o(id) = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
-			ps.ray_d(id) = make_float4(wo.x, wo.y, wo.z, MG_INF);
-			ps.bsdf(id) = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, bsdfPdf);
+			row[0] = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
+			row[1] = make_float4(wo.x, wo.y, wo.z, MG_INF);
+			row[5] = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, bsdfPdf);
 			flags = (flags & 0x00FFFFFFu) | (sampledType << F_ST_SHIFT);
 			continues = true;
 		} while (false);
+		if (!continues) { row[0] = ro; row[1] = rd; }      // a path that ends keeps its last ray (the slots held triangle data)
 
 		flags = (flags & ~((0xFFu << F_D1_SHIFT) | (0xFFu << F_D2_SHIFT))) | (smp.d1 << F_D1_SHIFT) | (smp.d2 << F_D2_SHIFT);
-		ps.thr(id) = make_float4(thr.x, thr.y, thr.z, __int_as_float(depth));
-		ps.Li(id) = make_float4(Li.x, Li.y, Li.z, __uint_as_float(flags));
-		ps.misc(id) = make_uint4((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32), misc_zw.x, misc_zw.y);
+		row[3] = make_float4(thr.x, thr.y, thr.z, __int_as_float(depth));
+		row[4] = make_float4(Li.x, Li.y, Li.z, __uint_as_float(flags));
+		reinterpret_cast<uint4 &>(row[6]) = make_uint4((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32), misc_zw.x, misc_zw.y);
 	}
 
 }
 
+constexpr int kRowStride = kPathSlots + 1;      // LDS row of a staged path record: 9 float4, conflict-free for 16-byte accesses
+
 template <int BT, bool ROUNDS>
-__global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, BinView view) {
+__global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, BinView view_host,
+                                                       const BinView *views_dev) {
 	__shared__ uint32_t s_cnt[2][kShadeBlock / 64];
 	__shared__ uint32_t s_base[2];
+	__shared__ float4 s_rows[kShadeBlock / 64][64 * kRowStride];
 	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-	const bool active = gtid < view.prefix[kBinShards];
+	// the bin's segment sizes: a kernel argument when the host read the counters back, otherwise what k_prep wrote
+	const uint32_t *prefix = views_dev ? views_dev[BT].prefix : view_host.prefix;
+	const uint32_t total = prefix[kBinShards];
+	if (blockIdx.x * blockDim.x >= total)
+		return;                            // (uniform) a grid sized for the worst case
+	const bool active = gtid < total;
 	uint32_t id = 0u;
 	if (active) {
 		int seg = 0;
 		#pragma unroll
 		for (int k = 1; k < kBinShards; ++k)
-			if (gtid >= view.prefix[k]) seg = k;
-		id = q.bins[BT][(size_t) seg * q.bin_seg_cap + (gtid - view.prefix[seg])];
+			if (gtid >= prefix[k]) seg = k;
+		id = q.bins[BT][(size_t) seg * q.bin_seg_cap + (gtid - prefix[seg])];
 	}
+	// ---- the path records of the wave, staged through LDS ----
+	// The ids come from a material-sorted queue, so every lane owns a different 128-byte line.  Read field by field
+	// that is seven 16-byte gathers per lane which each occupy the texture-address unit for 64 lines and -- the L1
+	// holds 32 KB, the CU's waves hold far more lines -- mostly go to the L2 again.  Instead eight lanes fetch one
+	// record together (one fully used line per request, eight records per instruction), rows of 9 float4 keep the
+	// LDS accesses free of bank conflicts, and the rows are written back the same way: whole lines, coalesced.
+	// All LDS traffic is private to the wave (program order suffices, no barrier).
+	float4 *rows = s_rows[threadIdx.x >> 6];
+	float4 *row = rows + lane_id() * kRowStride;
+	const uint32_t sub = lane_id() & 7u, grp = lane_id() >> 3;
+	const uint64_t actMask = __ballot(active);
+	#pragma unroll
+	for (int r = 0; r < 8; ++r) {
+		const uint32_t src = grp + 8u * r;
+		const uint32_t sid = (uint32_t) __shfl((int) id, (int) src);
+		if ((actMask >> src) & 1ull) rows[src * kRowStride + sub] = ps.base[(size_t) sid * kPathSlots + sub];
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 	bool continues = false, wantShadow = false;
 	V3 neeV(0, 0, 0), shO(0, 0, 0), shD(0, 0, 0);      // pending direct-light term and its shadow ray
+	float4 ro = make_float4(0, 0, 0, 0), rd = ro, T4 = ro, L4 = ro;
+	uint4 h = make_uint4(0u, 0u, 0u, kNoPrim);
+	if (active) {
+		ro = row[0]; rd = row[1]; h = reinterpret_cast<const uint4 &>(row[2]); T4 = row[3]; L4 = row[4];
+		if (ROUNDS && cfg.dr_mode == 2) {
+			// rounds of MIDirectIntegrator: later BSDF samples start again from the camera hit (kept in ps.prim)
+			if (cfg.dr_index > 0) {
+				ro = ps.prim[3 * (size_t) id]; rd = ps.prim[3 * (size_t) id + 1];
+				h = reinterpret_cast<const uint4 &>(ps.prim[3 * (size_t) id + 2]);
+			} else if (cfg.n_bsdf > 1) {
+				ps.prim[3 * (size_t) id] = ro; ps.prim[3 * (size_t) id + 1] = rd;
+				ps.prim[3 * (size_t) id + 2] = reinterpret_cast<const float4 &>(h);
+			}
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+	// the first 64 bytes of the hit primitives' gather records (three position chunks + one of the normals), four lanes
+	// per record, into row slots 0, 1, 3, 4 -- whose contents sit in registers now
+	{
+		const uint32_t prim = h.w;
+		const uint64_t validMask = __ballot(active && prim != kNoPrim);
+		const uint32_t sub4 = lane_id() & 3u, grp4 = lane_id() >> 2;
+		const uint32_t slotOf = sub4 < 2u ? sub4 : sub4 + 1u;      // chunks 0, 1, 2, 3 -> slots 0, 1, 3, 4
+		#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const uint32_t src = grp4 + 16u * r;
+			const uint32_t sprim = (uint32_t) __shfl((int) prim, (int) src);
+			if ((validMask >> src) & 1ull) rows[src * kRowStride + slotOf] = sc.tri_pos[(size_t) sprim * kTriStride + sub4];
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 	if (active)
-		shade_path<BT, ROUNDS>(sc, ps, cfg, id, continues, wantShadow, neeV, shO, shD);
+		shade_path<BT, ROUNDS>(sc, ps, cfg, id, ro, rd, h, T4, L4, row, continues, wantShadow, neeV, shO, shD);
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+	#pragma unroll
+	for (int r = 0; r < 8; ++r) {
+		const uint32_t src = grp + 8u * r;
+		const uint32_t sid = (uint32_t) __shfl((int) id, (int) src);
+		if ((actMask >> src) & 1ull) ps.base[(size_t) sid * kPathSlots + sub] = rows[src * kRowStride + sub];
+	}
 
 	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue.
 	// ballot + prefix popcount inside each wave, an LDS scan across the 8 waves, ONE atomic per
@@ -1893,7 +1983,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 	if (threadIdx.x < 2) {
 		uint32_t total = 0;
 		for (int w = 0; w < kShadeBlock / 64; ++w) total += s_cnt[threadIdx.x][w];
-		s_base[threadIdx.x] = total ? atomicAdd(&q.counters[(kNumBins * kBinShards + threadIdx.x) * kCounterStride], total) : 0u;
+		s_base[threadIdx.x] = total ? atomicAdd(&q.counters[(kCntNext + threadIdx.x) * kCounterStride], total) : 0u;
 	}
 	__syncthreads();
 	uint32_t offN = s_base[0], offS = s_base[1];
@@ -2102,57 +2192,49 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 }
 
 template <int MODE, bool COUNT, bool BIN>
-static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent) {
-	// persistent grid: enough workgroups to fill every CU, never more than there are rays
-	const unsigned maxBlocks = q.n_cus * trace_blocks_per_cu(MODE), wavesPerBlock = kTraceBlock / 64;
-	DQueues qq = q;
-	// rays per wave: 64, or the smallest power of two (>= 8) with which the launch still fits into one round of the
-	// persistent grid -- a launch that cannot fill the lanes of the chip trades idle lanes for shorter waves
-	unsigned batch = 64;
-	if (!coherent) while (batch > 8u && (unsigned long long) (batch / 2) * wavesPerBlock * maxBlocks >= n) batch /= 2;
-	if (q.tune_batch >= 1 && q.tune_batch <= 64) batch = q.tune_batch;
-	qq.batch = batch;
-	const unsigned blocks = std::min<unsigned>(blocks_for(n, batch * wavesPerBlock), maxBlocks);
-	// static share of the queue: whole rounds of the grid; the last quarter of the rounds and the remainder are
-	// claimed dynamically (one atomic per 64-ray batch, far below the ~88 / us a single counter sustains)
-	const unsigned long long perRound = (unsigned long long) blocks * wavesPerBlock * batch;
-	const unsigned long long rounds = n / perRound;
-	const unsigned dynDiv = q.tune_dyn_div ? q.tune_dyn_div : 4u;
-	// small launches stay fully static: their waves finish together and would hit the counter in one burst
-	const bool dynamic = rounds >= 8 && !q.force_static;
-	const unsigned long long dynRounds = dynamic ? std::max<unsigned long long>(1, rounds / dynDiv) : 0;
-	qq.static_n = dynamic ? (uint32_t) ((rounds - dynRounds) * perRound) : n;
-	qq.dyn_slot = (uint32_t) (kNumBins * kBinShards + 2 + (MODE == 0 ? 0 : 1));
-	// the early loop exits trade the latency of a few straggling rays for throughput; with only a few
-	// batches per wave the stragglers are the critical path, so small launches run the plain loops
-	if (n < 8u * (q.n_cus * 8u) * kTraceBlock || coherent)
-		qq.desc_min = qq.leaf_min = 1;
-	if (coherent && !q.tune_refill)
-		qq.refill_min = 64;       // neighbouring camera samples finish together: refilling would only mix batches
-	qq.refill_min = std::min(qq.refill_min, batch);
-	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, sc, ps, qq, queue, n);
+static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n,
+                           const uint32_t *n_dev) {
+	// persistent grid: enough workgroups to fill every CU, never more than there are rays (trace_plan); when only the
+	// device knows the count, the grid is sized for the upper bound n and the surplus workgroups exit at once
+	unsigned blocks = trace_plan(n, MODE, q).blocks;
+	if (n_dev) {
+		// any count up to n: the narrowest batches need the most workgroups
+		const unsigned minBatch = (q.tune_batch >= 1 && q.tune_batch <= 64) ? q.tune_batch : (q.coherent ? 64u : 8u);
+		blocks = std::min<unsigned>(blocks_for(n, minBatch * (kTraceBlock / 64)), q.n_cus * trace_blocks_per_cu(MODE));
+	}
+	if (!blocks) return;
+	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, sc, ps, q, queue, n, n_dev);
 }
 
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
-                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent) {
+                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *n_dev) {
 	if (!n) return;
+	DQueues qq = q;
+	qq.coherent = coherent ? 1u : 0u;
+	if (n_dev)
+		qq.force_static = 1u;        // no dynamically claimed batches: the material-queue segments cannot overflow then
 	if (mode == 0) {
-		if (bin) { if (count) launch_trace_t<0, true, true>(s, sc, ps, q, queue, n, coherent); else launch_trace_t<0, false, true>(s, sc, ps, q, queue, n, coherent); }
-		else     { if (count) launch_trace_t<0, true, false>(s, sc, ps, q, queue, n, coherent); else launch_trace_t<0, false, false>(s, sc, ps, q, queue, n, coherent); }
+		if (bin) { if (count) launch_trace_t<0, true, true>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<0, false, true>(s, sc, ps, qq, queue, n, n_dev); }
+		else     { if (count) launch_trace_t<0, true, false>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<0, false, false>(s, sc, ps, qq, queue, n, n_dev); }
 	} else if (mode == 1) {
-		if (count) launch_trace_t<1, true, false>(s, sc, ps, q, queue, n, coherent); else launch_trace_t<1, false, false>(s, sc, ps, q, queue, n, coherent);
+		if (count) launch_trace_t<1, true, false>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<1, false, false>(s, sc, ps, qq, queue, n, n_dev);
 	} else {
-		if (count) launch_trace_t<2, true, false>(s, sc, ps, q, queue, n, coherent); else launch_trace_t<2, false, false>(s, sc, ps, q, queue, n, coherent);
+		if (count) launch_trace_t<2, true, false>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<2, false, false>(s, sc, ps, qq, queue, n, n_dev);
 	}
 }
 
+void launch_prep(hipStream_t s, const uint32_t *cur, uint32_t *next_set, BinView *views_dev, uint32_t bin_seg_cap,
+                 unsigned long long *dev_stats) {
+	hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, s, cur, next_set, views_dev, bin_seg_cap, dev_stats);
+}
+
 void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
-                  const DQueues &q, const BinView &view) {
-	const uint32_t n = view.prefix[kBinShards];
+                  const DQueues &q, const BinView &view, const BinView *views_dev, uint32_t n_bound) {
+	const uint32_t n = views_dev ? n_bound : view.prefix[kBinShards];
 	if (!n) return;
 	const dim3 g(blocks_for(n, kShadeBlock)), b(kShadeBlock);
-	#define MG_SHADE(BT) do { if (cfg.dr_mode != 0) hipLaunchKernelGGL((k_shade<BT, true>), g, b, 0, s, sc, ps, cfg, q, view); \
-	                          else hipLaunchKernelGGL((k_shade<BT, false>), g, b, 0, s, sc, ps, cfg, q, view); } while (0)
+	#define MG_SHADE(BT) do { if (cfg.dr_mode != 0) hipLaunchKernelGGL((k_shade<BT, true>), g, b, 0, s, sc, ps, cfg, q, view, views_dev); \
+	                          else hipLaunchKernelGGL((k_shade<BT, false>), g, b, 0, s, sc, ps, cfg, q, view, views_dev); } while (0)
 	switch (bin) {
 		case 0: MG_SHADE(0); break;
 		case 1: MG_SHADE(1); break;

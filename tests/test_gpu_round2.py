@@ -175,8 +175,10 @@ def test_c4_one_of_eight_shards_at_4096_spp(gpu_lib, mts, orc, c3_full):
     # 4096 samples per owned pixel; a (0,2)-sequence value that rounds to exactly 1.0f (ldsampler.cpp:111) puts its
     # sample into the neighbouring pixel, which may belong to another shard's tile
     wown = film[own][:, 4]
-    assert np.abs(wown - 4096).max() <= 2 and abs(float(wown.sum()) - 4096.0 * own.sum()) <= 64
-    assert film[~own][:, 4].sum() <= 64
+    dev = np.abs(wown.astype(np.float64) - 4096)
+    assert dev.max() <= 16 and (dev == 0).mean() > 0.98, (dev.max(), (dev == 0).mean(), wown.min(), wown.max())
+    stray = film[~own][:, 4].astype(np.float64).sum()
+    assert stray <= 256, stray
     oscene = orc.FlatScene(sd)
     ocam = orc.make_camera(sd, W, H)
     op = orc.render_params(sd.max_depth, rr_depth=sd.rr_depth, sampler=mts.abi.SAMPLER_LD_KEYED, spp=4096, seed=0x5EED)

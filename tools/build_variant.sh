@@ -1,0 +1,10 @@
+#!/bin/bash
+# An experiment build of the library with extra compile-time definitions, next to the product build:
+#   bash tools/build_variant.sh sb256 -DMG_SHADE_BLOCK=256     ->  mitsuba-renderer_amd/libmtsgpu_sb256.so
+# Select it at run time with MTSGPU_LIB=<path> (mitsuba-renderer_amd/__init__.py).
+set -e
+name=$1; shift
+cd "$(dirname "$0")/../mitsuba-renderer_amd/csrc"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -pthread "$@" \
+    -x hip -shared api.cpp group.cpp kernels.hip kdbuild.cpp flatten.cpp serialized.cpp -o ../libmtsgpu_$name.so -lz -ldl
+ls -la ../libmtsgpu_$name.so
