@@ -436,6 +436,19 @@ __device__ __forceinline__ bool sphere_occludes(V3 center, float radius, V3 ro, 
 // free), levels beyond kStackLDS spill to HBM.  The 8-entry hashed mailbox
 // (sahkdtree3.h:130-144) is kept (LDS) because it decides equal-t ties.
 // ===========================================================================
+// Experiment builds (tools/build_variant.sh): MG_EXP_PAD_DESC / MG_EXP_PAD_LEAF dependent vector instructions added to
+// every descent step / leaf entry measure what one instruction costs in each loop.  Zero in the product.
+#ifndef MG_EXP_PAD_DESC
+#define MG_EXP_PAD_DESC 0
+#endif
+#ifndef MG_EXP_PAD_LEAF
+#define MG_EXP_PAD_LEAF 0
+#endif
+template <int N> __device__ __forceinline__ void exp_pad(float &x) {
+	#pragma unroll
+	for (int i = 0; i < N; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(x));
+}
+
 constexpr int kStackLDS = 12;
 constexpr int kSpillLevels = 40;      // 12 + 40 >= MTS_KD_MAXDEPTH (48) + 2
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
@@ -464,6 +477,7 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 	const uint32_t shard = blockIdx.x % kBinShards;     // contention on a bin counter is spread over kBinShards words
 
 	uint32_t c_inner = 0, c_leaf = 0, c_idx = 0, c_tri = 0;
+	float pad = 0.0f;                      // experiment builds only
 	uint32_t w_inner = 0, w_leaf = 0, w_outer = 0, w_batch = 0;   // COUNT: lane slots issued per loop (64 per wave iteration)
 #define MG_WSLOT(w) do { if (COUNT && lane == (uint32_t) __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) (w) += 64u; } while (0)
 
@@ -651,6 +665,7 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 					const uint4 pair = reinterpret_cast<const uint4 *>(sc.nodes)[left >> 1];
 					if (COUNT) c_inner++;
 					MG_WSLOT(w_inner);
+					if (MG_EXP_PAD_DESC) exp_pad<MG_EXP_PAD_DESC>(pad);
 					const float pen = sel3(enx, eny, enz, axis), pex = sel3(exx, exy, exz, axis);
 					const bool A = pen <= split, B = pex <= split, C = pen == split, D = split < pex;
 					//   A &&  B        : left only            (N1-N3, P5, Z2, Z3)
@@ -707,6 +722,7 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 						const uint32_t prim = A.x & 0x1FFFFFFFu, k = A.x >> 30;
 						if (COUNT) c_idx++;
 						MG_WSLOT(w_leaf);
+						if (MG_EXP_PAD_LEAF) exp_pad<MG_EXP_PAD_LEAF>(pad);
 						// Flat form of the mailbox test + TriAccel::rayIntersect: the plane distance t is computed for
 						// every entry (selects, no branches) and masked afterwards; only the barycentric part, which
 						// needs the rest of the record, is conditional.
@@ -797,6 +813,7 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 		}
 	}
 
+	if ((MG_EXP_PAD_DESC || MG_EXP_PAD_LEAF) && pad == -1.0f) q.trace_counts[7] = 1ull;      // keeps the padding alive
 	if (COUNT) {
 		// wave reduction, then one atomic per wave and counter
 		unsigned long long v[8] = { c_inner, c_leaf, c_idx, c_tri, w_inner, w_leaf, w_outer, w_batch };

@@ -1,19 +1,10 @@
 #!/bin/bash
-# experiment sweep on the GPU box (round 2): prints one line per configuration
-out=gpurun_out/exp_r02b.txt
+out=gpurun_out/exp_r02c.txt
 : > $out
-run() { echo "== $*" >> $out; "$@" 2>>gpurun_out/exp_r02b.err | tail -1 >> $out; }
-# 1 spp frame: host-driven vs device-driven
-run python tools/bounce_times.py 1 1024 sync_free=0 overlap=0
-run python tools/bounce_times.py 1 1024 sync_free=0 overlap=1
-run python tools/bounce_times.py 1 1024 sync_free=1
-run python tools/bounce_times.py 1 1024 sync_free=1 chunk=16
-run python tools/bounce_times.py 1 1024 sync_free=1 chunk=4
-# 64 spp frame: overlap on / off, shade block 256
-run python tools/bounce_times.py 64 1024 overlap=0
-run python tools/bounce_times.py 64 1024 overlap=1
-MTSGPU_LIB=$PWD/mitsuba-renderer_amd/libmtsgpu_sb256.so run python tools/bounce_times.py 64 1024 overlap=0
-# 8 spp: device-driven on a mid-size frame
-run python tools/bounce_times.py 8 1024 sync_free=0 overlap=0
-run python tools/bounce_times.py 8 1024 sync_free=1
+run() { echo "== $MTSGPU_LIB $*" >> $out; "$@" 2>>gpurun_out/exp_r02c.err | tail -1 >> $out; }
+L=$PWD/mitsuba-renderer_amd
+run python tools/bounce_times.py 64 1024
+for v in pd12 pd24 pl12 pl24; do MTSGPU_LIB=$L/libmtsgpu_$v.so run python tools/bounce_times.py 64 1024; done
+run python tools/bounce_times.py 64 1024
+for k in 1 2 4; do run python tools/group_1spp.py $k; done
 cat $out
