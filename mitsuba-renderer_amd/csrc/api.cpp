@@ -66,6 +66,8 @@ void applyTuning(mtsgpu_ctx *c) {
 	c->q.tune_refill = c->tuning.count("refill_min") ? 1u : 0u;
 	c->q.tune_batch = (uint32_t) get("batch", 0);
 	c->q.tune_dyn_div = (uint32_t) get("dyn_div", 0);
+	c->q.tune_xcd = (uint32_t) get("xcd_segments", 0);
+	if (c->q.tune_xcd) c->q.force_static = 1u;
 }
 
 // size of the full film the crop window lies in (film.cpp:33-41); without a crop window the film itself
@@ -104,7 +106,9 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	// traceAndBin() repeats such a launch with static dealing, for which the bound holds by construction.
 	const unsigned gridBlocksMax = c->nCUs * kTraceBlocksPerCuMax;
 	const size_t segCap = cap / kBinShards + cap / (4 * kBinShards) + (size_t) kTraceBlock * (gridBlocksMax / kBinShards + 2);
-	for (int b = 0; b < kNumBins; ++b) rc |= devAlloc(c, &c->q.bins[b], segCap * kBinShards, o);
+	rc |= devAlloc(c, &c->q.bins_base, segCap * kBinShards * kNumBins, o);
+	c->q.bin_stride = (uint32_t) (segCap * kBinShards);
+	if (segCap * kBinShards > 0xFFFFFFFFull) return fail(c, MTSGPU_EINVAL, "pass too large");
 	c->q.bin_seg_cap = (uint32_t) segCap;
 	rc |= devAlloc(c, &c->queueA, cap, o); rc |= devAlloc(c, &c->queueB, cap, o);
 	rc |= devAlloc(c, &c->q.shadow, cap, o);
@@ -297,15 +301,13 @@ int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatil
 		rc = timedTrace(0, false, c->queueB, nNext, false); if (rc) return rc;
 		c->stats.rays_closest += nNext;
 		// what the sampled rays hit: the material-independent tail of the shading kernel over the ray queue
-		DQueues tailQ = c->q;
-		tailQ.bins[kNumBsdfTypes] = c->queueB;
 		BinView tail;
 		tail.prefix[0] = 0;
 		for (int k = 1; k <= kBinShards; ++k) tail.prefix[k] = nNext;
 		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
 		if (sev) HIPCHK(c, hipEventRecord(sev[0], s));
 		cfg.dr_mode = 3; cfg.dr_index = j;
-		launch_shade(s, kNumBsdfTypes, c->dsc, c->paths, cfg, tailQ, tail);
+		launch_shade(s, kNumBsdfTypes, c->dsc, c->paths, cfg, c->q, tail, nullptr, 0, c->queueB);
 		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
 		HIPCHK(c, hipGetLastError());
 	}
@@ -827,6 +829,12 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	rc |= upload(c, &d.shape_lum, sc->shape_lum, sc->n_shapes);
 	rc |= upload(c, &d.shape_flags, sc->shape_flags, sc->n_shapes);
 	{
+		std::vector<uint32_t> bin(sc->n_shapes + 1, (uint32_t) kNumBsdfTypes);
+		for (uint32_t sIdx = 0; sIdx < sc->n_shapes; ++sIdx)
+			if (sc->shape_bsdf[sIdx] >= 0) bin[sIdx] = sc->bsdf_type[sc->shape_bsdf[sIdx]] & 0xFFu;
+		rc |= upload(c, &d.shape_bin, bin.data(), bin.size());
+	}
+	{
 		std::vector<uint32_t> st(sc->n_shapes + 1, (uint32_t) MTSGPU_SHAPE_TRIMESH);
 		std::vector<float> sp((size_t) MTSGPU_SHAPE_NPARAMS * (sc->n_shapes + 1), 0.0f);
 		if (sc->shape_type) {
@@ -984,7 +992,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "xcd_segments", 0, 1 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);

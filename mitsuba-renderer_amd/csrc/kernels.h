@@ -40,6 +40,7 @@ struct DScene {
 	const float4   *tri_pos;
 	const float4   *tri_nrm;
 	const int32_t  *shape_bsdf, *shape_lum;
+	const uint32_t *shape_bin;    // per shape: the material queue of its hits = BSDF type, or kNumBsdfTypes without a BSDF
 	const uint32_t *shape_type;   // MTSGPU_SHAPE_*
 	const float    *shape_params; // [n_shapes][24]
 	// environment map (level 0 of the MIPMap, RGB) and its sampling density (envmap.cpp:95-110)
@@ -60,6 +61,21 @@ struct DScene {
 	uint32_t n_lums, n_nodes, n_tris, n_shapes;
 	float aabb_min[3], aabb_max[3];
 };
+
+// What k_trace needs of the scene (a kernel argument: the fewer scalar registers it pins, the fewer get spilled)
+struct DTraceScene {
+	const uint2 *nodes;
+	const uint4 *leaf_ta;
+	const uint32_t *shape_bin;
+	uint32_t has_shapes;
+	float aabb_min[3], aabb_max[3];
+};
+inline DTraceScene trace_scene(const DScene &sc) {
+	DTraceScene t;
+	t.nodes = sc.nodes; t.leaf_ta = sc.leaf_ta; t.shape_bin = sc.shape_bin; t.has_shapes = sc.has_shapes;
+	for (int i = 0; i < 3; ++i) { t.aabb_min[i] = sc.aabb_min[i]; t.aabb_max[i] = sc.aabb_max[i]; }
+	return t;
+}
 
 // Per-path state, indexed by path id (paths never move; queues hold ids).
 // One 128-byte record per path = one cache line, so that the id-indexed gathers of the shading and
@@ -135,8 +151,12 @@ struct DConfig {
 };
 
 struct DQueues {
-	uint32_t *bins[kNumBins];     // per-material queues written by the closest-hit kernel: kBinShards segments of bin_seg_cap
+	// per-material queues written by the closest-hit kernel: bin b = bins_base + b * bin_stride, kBinShards segments of
+	// bin_seg_cap entries each (one base pointer instead of nine keeps the kernels' scalar registers free)
+	uint32_t *bins_base;
+	uint32_t bin_stride;
 	uint32_t bin_seg_cap;
+	__host__ __device__ uint32_t *bin(int b) const { return bins_base + (size_t) b * bin_stride; }
 	uint32_t *next;               // paths that continue (input of the next closest-hit launch)
 	uint32_t *shadow;             // paths with a pending shadow ray
 	uint32_t *counters;           // the counter set of this bounce, [i * kCounterStride]: i = b * kBinShards + shard for the bins, then kCnt*
@@ -154,6 +174,7 @@ struct DQueues {
 	uint32_t tune_batch;               // rays per wave and batch, 1..64
 	uint32_t tune_dyn_div;             // 1/x of the rounds of a large launch are claimed dynamically (default 4)
 	uint32_t tune_refill;              // refill threshold for coherent launches too (default: 64 there)
+	uint32_t tune_xcd;                 // experiment: XCD x (workgroups with blockIdx % 8 == x) takes the x-th eighth of the queue
 };
 
 // How one traversal launch over n rays is scheduled.  A pure function of (n, mode, q): the host evaluates it to size
@@ -220,8 +241,10 @@ void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &s
 struct BinView { uint32_t prefix[kBinShards + 1]; };
 // views_dev == NULL: the bin has view.prefix[kBinShards] entries.  Otherwise the view is views_dev[bin] (written by
 // k_prep on the device) and n_bound bounds its size
+// bin_ids: the bin's id segments (q.bin(bin) unless the caller shades another queue)
 void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
-                  const DQueues &q, const BinView &view, const BinView *views_dev = nullptr, uint32_t n_bound = 0);
+                  const DQueues &q, const BinView &view, const BinView *views_dev = nullptr, uint32_t n_bound = 0,
+                  const uint32_t *bin_ids = nullptr);
 // device-driven bounces: per-bin views from the shard counters of the closest-hit launch that just ran (`cur`), and
 // the counter set of the next bounce zeroed
 void launch_prep(hipStream_t s, const uint32_t *cur, uint32_t *next_set, BinView *views_dev, uint32_t bin_seg_cap,

@@ -436,6 +436,33 @@ __device__ __forceinline__ bool sphere_occludes(V3 center, float radius, V3 ro, 
 // free), levels beyond kStackLDS spill to HBM.  The 8-entry hashed mailbox
 // (sahkdtree3.h:130-144) is kept (LDS) because it decides equal-t ties.
 // ===========================================================================
+// MG_NT: non-temporal hints on data that is touched once per launch -- bit 0: path records, ray
+// and id queues in k_trace; bit 1: leaf records in k_trace; bit 2: records and queues in k_shade -- so that they do not
+// push the tree out of the L1 / L2
+#ifndef MG_NT
+#define MG_NT 4      // measured (64-spp C3 frame): bit 0 +12 ms, bit 1 +120 ms (the leaf records live in the L2), bit 2 -3.6 ms
+#endif
+typedef uint32_t nt_u4 __attribute__((ext_vector_type(4)));
+template <int BIT, typename T> __device__ __forceinline__ T ld_stream(const T *p) {
+	if (MG_NT & BIT) {
+		static_assert(sizeof(T) == 16 || sizeof(T) == 4, "16-byte or 4-byte objects");
+		T out;
+		if (sizeof(T) == 16) { const nt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4 *>(p)); __builtin_memcpy(&out, &v, 16); }
+		else { const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p)); __builtin_memcpy(&out, &v, 4); }
+		return out;
+	}
+	return *p;
+}
+template <int BIT, typename T> __device__ __forceinline__ void st_stream(T *p, const T &v) {
+	if (MG_NT & BIT) {
+		static_assert(sizeof(T) == 16 || sizeof(T) == 4, "16-byte or 4-byte objects");
+		if (sizeof(T) == 16) { nt_u4 x; __builtin_memcpy(&x, &v, 16); __builtin_nontemporal_store(x, reinterpret_cast<nt_u4 *>(p)); }
+		else { uint32_t x; __builtin_memcpy(&x, &v, 4); __builtin_nontemporal_store(x, reinterpret_cast<uint32_t *>(p)); }
+	} else {
+		*p = v;
+	}
+}
+
 // Experiment builds (tools/build_variant.sh): MG_EXP_PAD_DESC / MG_EXP_PAD_LEAF dependent vector instructions added to
 // every descent step / leaf entry measure what one instruction costs in each loop.  Zero in the product.
 #ifndef MG_EXP_PAD_DESC
@@ -468,7 +495,7 @@ size_t trace_stack_levels() { return kStackLDS + kSpillLevels; }
 // `first` is the queue index of the wave's first batch, `stride` the distance to its next one, `static_n` the
 // statically dealt prefix of the queue.
 template <int MODE, bool COUNT, bool BIN>
-__device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, const DQueues &q, const TracePlan &plan,
+__device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &ps, const DQueues &q, const TracePlan &plan,
                                            const uint32_t *queue, uint32_t n, const uint32_t first, const uint32_t stride,
                                            uint32_t (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock]) {
 	const uint32_t tid = threadIdx.x;
@@ -504,6 +531,7 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 	uint32_t ex_node = kNullNode, ex_ref = kSentinel, cur = 0;
 	float best_t = MG_INF, best_u = 0, best_v = 0;
 	uint32_t best_prim = kNoPrim, best_shape = 0;
+	// best_shape: shape index of the accepted hit (dword 10 of its record), read while the record is at hand
 	uint32_t e_cont = kNoPrim;              // position inside an interrupted leaf
 	uint2 nd = make_uint2(0u, 0u);          // sc.nodes[cur], fetched as soon as cur is known
 	bool found = false;
@@ -533,12 +561,11 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 			if (MODE == 0) {
 				int bin = -1;
 				if (done) {
-					ps.hit(id) = make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim);
+					st_stream<1>(&ps.hit(id), make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim));
 					if (BIN) {
 						bin = kNumBins - 1;
 						if (found) {
-							const int b = sc.shape_bsdf[sc.leaf_ta[3 * (size_t) best_shape + 2].z];   // shape of the hit record
-							if (b >= 0) bin = (int) (sc.bsdf_type[b] & 0xFFu);
+							bin = (int) sc.shape_bin[best_shape];      // BSDF type of the hit shape, or the terminal bin (one lookup)
 						}
 					}
 				}
@@ -560,9 +587,8 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 					// can in principle exceed it: the entry is dropped then, the counter still counts it, and the host
 					// repeats the launch with static dealing when it sees a count above the capacity
 					const uint32_t pos = base + rank;
-					#pragma unroll
-					for (int b = 0; b < kNumBins; ++b)
-						if (bin == b && pos < q.bin_seg_cap) q.bins[b][(size_t) shard * q.bin_seg_cap + pos] = id;
+					if (bin >= 0 && pos < q.bin_seg_cap)
+						st_stream<1>(&q.bins_base[(size_t) bin * q.bin_stride + (size_t) shard * q.bin_seg_cap + pos], id);
 				}
 			} else if (MODE == 1) {
 				// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
@@ -589,14 +615,14 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 			sup_base += taken; sup_left -= taken;
 			MG_WSLOT(w_batch);
 			if (take) {
-				id = (MODE == 1) ? my : queue[my];       // shadow rays are addressed by their queue position
+				id = (MODE == 1) ? my : ld_stream<1>(&queue[my]);       // shadow rays are addressed by their queue position
 				float4 a, b;
 				float rmint, rmaxt;
 				if (MODE == 1) {
-					a = ps.shq_o[my]; b = ps.shq_d[my];
+					a = ld_stream<1>(&ps.shq_o[my]); b = ld_stream<1>(&ps.shq_d[my]);
 					rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
 				} else {
-					a = ps.ray_o(id); b = ps.ray_d(id);
+					a = ld_stream<1>(&ps.ray_o(id)); b = ld_stream<1>(&ps.ray_d(id));
 					rmint = a.w; rmaxt = b.w;
 				}
 				ox = a.x; oy = a.y; oz = a.z; dx = b.x; dy = b.y; dz = b.z;
@@ -713,12 +739,12 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 					// are only fetched for primitives whose t lies inside [mint, maxt] (triaccel.h:141-149).
 					uint4 A;
 					more = e != last;
-					if (more) A = sc.leaf_ta[3 * (size_t) e];
+					if (more) A = ld_stream<2>(&sc.leaf_ta[3 * (size_t) e]);
 					// like the descent, the primitive loop stops when fewer than q.leaf_min lanes have entries left;
 					// those lanes keep their position (e_cont) and go on in the next round
 					do { if (more) {
 						uint4 An = A;
-						if (e + 1 != last) An = sc.leaf_ta[3 * (size_t) (e + 1)];      // next record's head in flight
+						if (e + 1 != last) An = ld_stream<2>(&sc.leaf_ta[3 * (size_t) (e + 1)]);      // next record's head in flight
 						const uint32_t prim = A.x & 0x1FFFFFFFu, k = A.x >> 30;
 						if (COUNT) c_idx++;
 						MG_WSLOT(w_leaf);
@@ -742,7 +768,8 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 								float ts;
 								if (sphere_intersect(ctr, rad, V3(ox, oy, oz), V3(dx, dy, dz), mint, maxt, ts)) {
 									maxt = ts;
-									best_t = ts; best_u = 0.0f; best_v = 0.0f; best_prim = prim; best_shape = e;
+									best_t = ts; best_u = 0.0f; best_v = 0.0f; best_prim = prim;
+									best_shape = sc.leaf_ta[3 * (size_t) e + 2].z;
 								}
 							}
 						}
@@ -753,8 +780,8 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 						const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
 						const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
 						if (ok && !(t < mint || t > maxt)) {
-							const uint4 B = sc.leaf_ta[3 * (size_t) e + 1];
-							const uint2 C = *reinterpret_cast<const uint2 *>(sc.leaf_ta + 3 * (size_t) e + 2);
+							const uint4 B = ld_stream<2>(&sc.leaf_ta[3 * (size_t) e + 1]);
+							const uint4 C = ld_stream<2>(&sc.leaf_ta[3 * (size_t) e + 2]);         // c_nu, c_nv, shape index, -
 							const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
 							const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
 							const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
@@ -765,7 +792,7 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 							if (u >= 0 && v >= 0 && u + v <= 1.0f) {
 								if (MODE != 0) hitShadow = true;
 								maxt = t;      // a later hit with equal t replaces this one (t > maxt rejects)
-								best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = e;
+								best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = C.z;
 							}
 						}
 						*mslot = prim;         // (re)writing an entry that is already there changes nothing
@@ -829,7 +856,7 @@ __device__ __forceinline__ void trace_body(const DScene &sc, const DPaths &ps, c
 }
 
 template <int MODE, bool COUNT, bool BIN>
-__global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trace(DScene sc, DPaths ps, DQueues q,
+__global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trace(DTraceScene sc, DPaths ps, DQueues q,
                                                           const uint32_t *queue, uint32_t n_host, const uint32_t *n_dev) {
 	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
 	__shared__ uint32_t s_mbox[8][kTraceBlock];
@@ -842,9 +869,20 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 		atomicAdd(&q.dev_stats[MODE == 0 ? kStatClosest : kStatShadow], (unsigned long long) n);
 		atomicAdd(&q.dev_stats[kStatLaunches], 1ull);
 	}
-	const uint32_t first = (blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6)) * plan.batch;
-	const uint32_t stride = plan.blocks * (kTraceBlock / 64u) * plan.batch;      // queue entries per round of the grid
-	trace_body<MODE, COUNT, BIN>(sc, ps, q, plan, queue, n, first, stride, s_stack, s_mbox);
+	TracePlan p2 = plan;
+	uint32_t lo = 0, hi = n, bi = blockIdx.x, nb = plan.blocks;
+	if (q.tune_xcd && (plan.blocks & 7u) == 0u) {
+		// experiment: contiguous eighths of the queue per XCD (workgroups are dealt to the XCDs round robin), so that a
+		// queue sorted by where its rays end keeps the deep part of the tree of one region in ONE L2
+		const uint32_t xcd = blockIdx.x & 7u;
+		const uint32_t seg = (((n + 7u) / 8u) + plan.batch - 1u) / plan.batch * plan.batch;
+		lo = xcd * seg < n ? xcd * seg : n; hi = lo + seg < n ? lo + seg : n;
+		bi = blockIdx.x >> 3; nb = plan.blocks >> 3;
+		p2.static_n = hi;
+	}
+	const uint32_t first = lo + (bi * (kTraceBlock / 64u) + (threadIdx.x >> 6)) * plan.batch;
+	const uint32_t stride = nb * (kTraceBlock / 64u) * plan.batch;      // queue entries per round of the grid
+	trace_body<MODE, COUNT, BIN>(sc, ps, q, p2, queue, hi, first, stride, s_stack, s_mbox);
 }
 
 // Device-driven bounces: the per-bin views k_shade needs, from the shard counters the closest-hit launch left in `cur`
@@ -1910,7 +1948,7 @@ constexpr int kRowStride = kPathSlots + 1;      // LDS row of a staged path reco
 
 template <int BT, bool ROUNDS>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, BinView view_host,
-                                                       const BinView *views_dev) {
+                                                       const BinView *views_dev, const uint32_t *bin_ids) {
 	__shared__ uint32_t s_cnt[2][kShadeBlock / 64];
 	__shared__ uint32_t s_base[2];
 	__shared__ float4 s_rows[kShadeBlock / 64][64 * kRowStride];
@@ -1927,7 +1965,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 		#pragma unroll
 		for (int k = 1; k < kBinShards; ++k)
 			if (gtid >= prefix[k]) seg = k;
-		id = q.bins[BT][(size_t) seg * q.bin_seg_cap + (gtid - prefix[seg])];
+		id = bin_ids[(size_t) seg * q.bin_seg_cap + (gtid - prefix[seg])];
 	}
 	// ---- the path records of the wave, staged through LDS ----
 	// The ids come from a material-sorted queue, so every lane owns a different 128-byte line.  Read field by field
@@ -1944,7 +1982,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 	for (int r = 0; r < 8; ++r) {
 		const uint32_t src = grp + 8u * r;
 		const uint32_t sid = (uint32_t) __shfl((int) id, (int) src);
-		if ((actMask >> src) & 1ull) rows[src * kRowStride + sub] = ps.base[(size_t) sid * kPathSlots + sub];
+		if ((actMask >> src) & 1ull) rows[src * kRowStride + sub] = ld_stream<4>(&ps.base[(size_t) sid * kPathSlots + sub]);
 	}
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 	bool continues = false, wantShadow = false;
@@ -1987,7 +2025,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 	for (int r = 0; r < 8; ++r) {
 		const uint32_t src = grp + 8u * r;
 		const uint32_t sid = (uint32_t) __shfl((int) id, (int) src);
-		if ((actMask >> src) & 1ull) ps.base[(size_t) sid * kPathSlots + sub] = rows[src * kRowStride + sub];
+		if ((actMask >> src) & 1ull) st_stream<4>(&ps.base[(size_t) sid * kPathSlots + sub], rows[src * kRowStride + sub]);
 	}
 
 	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue.
@@ -2010,9 +2048,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 	if (wantShadow) {
 		// the shadow ray lives in queue order (coalesced for both kernels); the path id rides in nee.w
 		const uint32_t pos = offS + (uint32_t) __popcll(mS & below);
-		ps.shq_o[pos] = make_float4(shO.x, shO.y, shO.z, 0.0f);
-		ps.shq_d[pos] = make_float4(shD.x, shD.y, shD.z, 0.0f);
-		ps.shq_nee[pos] = make_float4(neeV.x, neeV.y, neeV.z, __uint_as_float(id));
+		st_stream<4>(&ps.shq_o[pos], make_float4(shO.x, shO.y, shO.z, 0.0f));
+		st_stream<4>(&ps.shq_d[pos], make_float4(shD.x, shD.y, shD.z, 0.0f));
+		st_stream<4>(&ps.shq_nee[pos], make_float4(neeV.x, neeV.y, neeV.z, __uint_as_float(id)));
 	}
 }
 
@@ -2220,7 +2258,7 @@ static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, co
 		blocks = std::min<unsigned>(blocks_for(n, minBatch * (kTraceBlock / 64)), q.n_cus * trace_blocks_per_cu(MODE));
 	}
 	if (!blocks) return;
-	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, sc, ps, q, queue, n, n_dev);
+	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, trace_scene(sc), ps, q, queue, n, n_dev);
 }
 
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
@@ -2246,12 +2284,13 @@ void launch_prep(hipStream_t s, const uint32_t *cur, uint32_t *next_set, BinView
 }
 
 void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
-                  const DQueues &q, const BinView &view, const BinView *views_dev, uint32_t n_bound) {
+                  const DQueues &q, const BinView &view, const BinView *views_dev, uint32_t n_bound, const uint32_t *bin_ids) {
 	const uint32_t n = views_dev ? n_bound : view.prefix[kBinShards];
 	if (!n) return;
+	if (!bin_ids) bin_ids = q.bin(bin);
 	const dim3 g(blocks_for(n, kShadeBlock)), b(kShadeBlock);
-	#define MG_SHADE(BT) do { if (cfg.dr_mode != 0) hipLaunchKernelGGL((k_shade<BT, true>), g, b, 0, s, sc, ps, cfg, q, view, views_dev); \
-	                          else hipLaunchKernelGGL((k_shade<BT, false>), g, b, 0, s, sc, ps, cfg, q, view, views_dev); } while (0)
+	#define MG_SHADE(BT) do { if (cfg.dr_mode != 0) hipLaunchKernelGGL((k_shade<BT, true>), g, b, 0, s, sc, ps, cfg, q, view, views_dev, bin_ids); \
+	                          else hipLaunchKernelGGL((k_shade<BT, false>), g, b, 0, s, sc, ps, cfg, q, view, views_dev, bin_ids); } while (0)
 	switch (bin) {
 		case 0: MG_SHADE(0); break;
 		case 1: MG_SHADE(1); break;

@@ -47,3 +47,35 @@ for g in (8, 16, 64, 256):
     key2 = (cell[:, 0] * g + cell[:, 1]) * g + cell[:, 2]
     run(np.argsort(key2, kind="stable"), "grid %d^3 only" % g)
 run(np.argsort(octant, kind="stable"), "octant only")
+
+# --- destination-based order: where the ray leaves the scene box decides which deep part of the tree it visits ---
+lo, hi = np.array([-1.0, 0.0, -1.0]), np.array([1.0, 2.0, 1.0])
+with np.errstate(divide="ignore", invalid="ignore"):
+    tfar = np.where(d > 0, (hi - o) / d, np.where(d < 0, (lo - o) / d, np.inf))
+axis = np.argmin(tfar, axis=1)
+texit = tfar[np.arange(n), axis]
+p = o + texit[:, None] * d
+face = axis * 2 + (d[np.arange(n), axis] > 0)
+def dest_key(g):
+    a = (axis + 1) % 3; b = (axis + 2) % 3
+    ca = np.clip(((p[np.arange(n), a] - lo[a]) / (hi[a] - lo[a]) * g).astype(np.int64), 0, g - 1)
+    cb = np.clip(((p[np.arange(n), b] - lo[b]) / (hi[b] - lo[b]) * g).astype(np.int64), 0, g - 1)
+    return (face * g + ca) * g + cb
+for g in (1, 4, 16, 64):
+    order = np.argsort(dest_key(g), kind="stable")
+    for xcd in (0, 1):
+        it.set_tuning(xcd_segments=xcd)
+        run(order, "exit face + %dx%d cells, xcd=%d" % (g, g, xcd))
+it.set_tuning(xcd_segments=1)
+run(None, "random order, xcd=1")
+g = 16
+cell = np.clip(((o + [1, 0, 1]) / 2 * g).astype(np.int64), 0, g - 1)
+run(np.argsort((cell[:, 0] * g + cell[:, 1]) * g + cell[:, 2], kind="stable"), "origin grid 16^3, xcd=1")
+# balanced version: equal-count segments are what contiguous eighths give; shuffle inside each eighth to separate
+# the effect of the L2 (per XCD) from that of coherent waves
+order = np.argsort(dest_key(16), kind="stable")
+seg = (n + 7) // 8
+sh = order.copy()
+for k in range(8):
+    s_ = sh[k * seg:(k + 1) * seg]; rng.shuffle(s_)
+run(sh, "exit 16x16 per XCD, shuffled inside, xcd=1")
