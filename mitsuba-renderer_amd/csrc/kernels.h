@@ -174,6 +174,7 @@ struct DQueues {
 	uint32_t tune_batch;               // rays per wave and batch, 1..64
 	uint32_t tune_dyn_div;             // 1/x of the rounds of a large launch are claimed dynamically (default 4)
 	uint32_t tune_refill;              // refill threshold for coherent launches too (default: 64 there)
+	uint32_t tune_blocks_per_cu;       // experiment: fewer resident workgroups per CU than the kernel allows (0 = all)
 	uint32_t tune_xcd;                 // experiment: XCD x (workgroups with blockIdx % 8 == x) takes the x-th eighth of the queue
 };
 
@@ -189,7 +190,9 @@ struct TracePlan {
 __host__ __device__ inline TracePlan trace_plan(uint32_t n, int mode, const DQueues &q) {
 	TracePlan p;
 	const uint32_t wavesPerBlock = kTraceBlock / 64;
-	const uint32_t maxBlocks = q.n_cus * trace_blocks_per_cu(mode);
+	uint32_t perCu = trace_blocks_per_cu(mode);
+	if (q.tune_blocks_per_cu && q.tune_blocks_per_cu < perCu) perCu = q.tune_blocks_per_cu;
+	const uint32_t maxBlocks = q.n_cus * perCu;
 	// rays per wave: 64, or the smallest power of two (>= 8) with which the launch still fits into one round of the
 	// persistent grid -- a launch that cannot fill the lanes of the chip trades idle lanes for shorter waves
 	uint32_t batch = 64;

@@ -2255,7 +2255,9 @@ static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, co
 	if (n_dev) {
 		// any count up to n: the narrowest batches need the most workgroups
 		const unsigned minBatch = (q.tune_batch >= 1 && q.tune_batch <= 64) ? q.tune_batch : (q.coherent ? 64u : 8u);
-		blocks = std::min<unsigned>(blocks_for(n, minBatch * (kTraceBlock / 64)), q.n_cus * trace_blocks_per_cu(MODE));
+		unsigned perCu = trace_blocks_per_cu(MODE);
+		if (q.tune_blocks_per_cu && q.tune_blocks_per_cu < perCu) perCu = q.tune_blocks_per_cu;
+		blocks = std::min<unsigned>(blocks_for(n, minBatch * (kTraceBlock / 64)), q.n_cus * perCu);
 	}
 	if (!blocks) return;
 	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, trace_scene(sc), ps, q, queue, n, n_dev);

@@ -1,9 +1,6 @@
 #!/bin/bash
-out=gpurun_out/exp_r02d.txt
+out=gpurun_out/exp_r02e.txt
 : > $out
-run() { echo "== $MTSGPU_LIB $*" >> $out; "$@" 2>>gpurun_out/exp_r02d.err | tail -1 >> $out; }
-L=$PWD/mitsuba-renderer_amd
-run python tools/bounce_times.py 64 1024
-for v in nt1 nt3 nt4 nt7; do MTSGPU_LIB=$L/libmtsgpu_$v.so run python tools/bounce_times.py 64 1024; done
-run python tools/bounce_times.py 64 1024
+run() { echo "== $MTSGPU_LIB $*" >> $out; "$@" 2>>gpurun_out/exp_r02e.err | tail -1 >> $out; }
+for b in 0 6 5 4 3; do run python tools/bounce_times.py 64 1024 blocks_per_cu=$b; done
 cat $out

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profile passes for one round (run on the GPU box from the repo root):  bash tools/profile_round.sh <tag>
 # 1) kernel trace + stats of the bench command, 2..4) separate PMC passes over one untimed 64-spp C3 frame.
-tag=${1:-r01}
+tag=${1:-r02}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
@@ -14,5 +14,6 @@ rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TC
 cd $root
 for d in pmc_fetch pmc_write pmc_sq pmc_mem; do echo "== $d"; python3 tools/pmc_summary.py $out/$d 2>&1 | grep -A12 "k_trace\|k_shade"; done > $out/pmc_summary.txt
 find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
+python3 tools/make_traffic.py $tag $out > $out/traffic.log 2>&1; cp profiles/${tag}_traffic.json $out/ 2>/dev/null
 find $out -name "*.db" -delete; find $out -name "*_agent_info.csv" -delete
 ls -la $out
