@@ -4,8 +4,8 @@
 Workload (BASELINE.json configs[2]/[3], SURVEY.md 8d "C3/C4"): procedural Cornell variant with one
 1 024 000-triangle displaced walls TriMesh (lambertian), a 20 480-triangle dielectric icosphere and
 an area luminaire; `path` integrator maxDepth=16, rrDepth=10; 1024x1024, low-discrepancy sampler.
-A "step" is one full-frame render.  Every GPU renders its share of the ImageBlock tiles (bit-reversal
-shuffled, mtsgpu_set_tiles) into a full-frame film; the films are summed once per step with a reduce over
+A "step" is one full-frame render.  Every GPU renders its share of the ImageBlock tiles (Morton index of the
+tile modulo N, mtsgpu_set_tiles) into a full-frame film; the films are summed once per step with a reduce over
 RCCL/xGMI (Film::putImageBlock).  Scene upload is excluded, the film reduce is included.
 value = total camera samples / wall time.
 
@@ -46,6 +46,15 @@ def algorithmic_bytes(st):
     n_tri counted without mailbox credit (= index entries visited)."""
     rays = st["rays_closest"] + st["rays_shadow"]
     return 8 * st["n_inner"] + 8 * st["n_leaf"] + 4 * st["n_idx"] + 48 * st["n_idx"] + 48 * rays
+
+
+def algorithmic_requests(st):
+    """Lane-level vector-memory requests the traversal algorithm itself needs: one 16-byte
+    sibling-pair fetch per inner node, one 16-byte record head per index entry, two 8-byte node fetches per pop (a ray
+    pops once per leaf but the last), the ray (2 x 16 B) and the hit (16 B).  The plane-test tails, queue ids and stack
+    spills come on top in the real kernel (PMC: TCP_TOTAL_CACHE_ACCESSES is ~1.25 x this)."""
+    rays = st["rays_closest"] + st["rays_shadow"]
+    return st["n_inner"] + st["n_idx"] + 2 * max(st["n_leaf"] - rays, 0) + 3 * rays
 
 
 def shade_algorithmic_bytes(st):
@@ -314,6 +323,9 @@ def main():
         achieved = bytes_per_step * args.steps / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         rays = counts["rays_closest"] + counts["rays_shadow"]
         triad = pkg.hbm_triad_gbs(device)
+        gather = pkg.gather_roof(device, 4)
+        req_per_step = algorithmic_requests(counts)
+        req_rate = req_per_step * args.steps / (trace_ms * 1e-3) if trace_ms > 0 else 0.0
         sh_bytes = shade_algorithmic_bytes(counts)
         sh_achieved = sh_bytes * args.steps / (shade_ms * 1e-3) / 1e9 if shade_ms > 0 else 0.0
         out = {
@@ -328,7 +340,7 @@ def main():
                                ("%d spp per frame (strong scaling)" % spp_total) if strong
                                else ("%d spp per GPU (%d per frame, weak scaling)" % (args.spp, spp_total))),
                 "triangles": int(scene.sc.n_tris), "kd_nodes": int(scene.sc.n_nodes), "kd_indices": int(scene.sc.n_indices),
-                "parallelism": "ImageBlock tiles, bit-reversed tile index %% %d + one RCCL film reduce per frame" % world,
+                "parallelism": "ImageBlock tiles, morton(tx, ty) %% %d + one RCCL film reduce per frame" % world,
                 "host_flatten_s": flatten_s,
             },
             "time_to_1spp_frame_ms": one_spp_ms,
@@ -345,6 +357,13 @@ def main():
                 "shade_ms_per_step": shade_ms / args.steps,
                 "n_inner_per_ray": counts["n_inner"] / max(rays, 1), "n_leaf_per_ray": counts["n_leaf"] / max(rays, 1),
                 "n_idx_per_ray": counts["n_idx"] / max(rays, 1), "n_tri_tested_per_ray": counts["n_tri_tested"] / max(rays, 1),
+            },
+            "roofline_requests": {
+                "kernel": "k_trace", "bound": "vector-memory request rate (TA / TCP): 16-byte gathers, one cache line per lane",
+                "achieved": req_rate / 1e9, "peak": gather / 1e9 if gather else None, "unit": "G lane-requests/s",
+                "frac": req_rate / gather if gather else None,
+                "peak_source": "mtsgpu_gather_roof: random 16-byte loads over a 4 MiB footprint, measured in this run",
+                "algorithmic_requests_per_ray": req_per_step / max(rays, 1),
             },
             "roofline_shade": {
                 "kernel": "k_shade (one Li iteration per path: emitter hit, MIS, RR, NEE sample, BSDF sample) + k_generate + k_accumulate",

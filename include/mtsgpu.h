@@ -321,6 +321,11 @@ int  mtsgpu_group_last_reduce_kind(const mtsgpu_group *g);
  * launches): the practical bandwidth roof next to the 8 TB/s specification.  GB/s in *gbs. */
 int  mtsgpu_hbm_triad(int device, size_t bytes, int iters, double *gbs);
 
+/* Vector-memory request roof: lane-level 16-byte loads per second when every lane of every wave gathers its own random
+ * element from `footprint_bytes` (a power of two; 4 MiB sits in the L2 like the upper kd-tree), with k_trace's grid
+ * shape.  The traversal kernel is bound by this rate, not by DRAM bytes. */
+int  mtsgpu_gather_roof(int device, size_t footprint_bytes, double *lane_requests_per_s);
+
 /* --- standalone kernels exposed for parity tests and the traversal benchmark */
 /* ShapeKDTree::rayIntersect(ray, its) / (ray) on n host rays.
  * rays: [n][8] f32 = o.xyz, mint, d.xyz, maxt.   hits: [n][4] u32 = t(f32 bits), u, v, prim

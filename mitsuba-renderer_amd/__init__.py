@@ -29,7 +29,7 @@ EXPORTS = [
     "mtsgpu_read_film", "mtsgpu_clear_film", "mtsgpu_get_stats", "mtsgpu_trace_rays", "mtsgpu_ld_tables",
     "mtsgpu_li_samples", "mtsgpu_flatten", "mtsgpu_flat_scene_get", "mtsgpu_flat_scene_free",
     "mtsgpu_flat_scene_kdstats", "mtsgpu_make_camera", "mtsgpu_make_camera_ortho", "mtsgpu_load_serialized", "mtsgpu_loaded_mesh_free",
-    "mtsgpu_make_camera_crop", "mtsgpu_hbm_triad", "mtsgpu_sampler_values", "mtsgpu_set_tuning",
+    "mtsgpu_make_camera_crop", "mtsgpu_hbm_triad", "mtsgpu_sampler_values", "mtsgpu_set_tuning", "mtsgpu_gather_roof",
     "mtsgpu_create_multi", "mtsgpu_group_destroy", "mtsgpu_group_size", "mtsgpu_group_ctx", "mtsgpu_group_last_error",
     "mtsgpu_group_upload_scene", "mtsgpu_group_set_camera", "mtsgpu_group_set_integrator", "mtsgpu_group_set_sampler",
     "mtsgpu_group_set_rfilter", "mtsgpu_group_render", "mtsgpu_group_last_reduce_kind",
@@ -110,6 +110,7 @@ def lib():
     L.mtsgpu_load_serialized.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(abi.Mesh)]
     L.mtsgpu_loaded_mesh_free.argtypes = [vp]; L.mtsgpu_loaded_mesh_free.restype = None
     L.mtsgpu_make_camera_crop.argtypes = [f32p, f32p, f32p, C.c_float] + [C.c_int] * 6 + [C.POINTER(abi.Camera)]
+    L.mtsgpu_gather_roof.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_double)]
     L.mtsgpu_set_tuning.argtypes = [vp, C.c_char_p, C.c_long]
     L.mtsgpu_sampler_values.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, f32p]
     L.mtsgpu_hbm_triad.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
@@ -457,6 +458,13 @@ def hbm_triad_gbs(device=0, gib=1.0, iters=5):
     """measured HBM triad bandwidth in GB/s (the practical roof next to the 8 TB/s specification), None on failure"""
     out = C.c_double(0)
     rc = lib().mtsgpu_hbm_triad(int(device), int(gib * (1 << 30)), int(iters), C.byref(out))
+    return float(out.value) if rc == 0 and out.value > 0 else None
+
+
+def gather_roof(device=0, footprint_mib=4):
+    """measured lane-level 16-byte gather requests per second (the roof of the traversal kernel), None on failure"""
+    out = C.c_double(0)
+    rc = lib().mtsgpu_gather_roof(int(device), int(footprint_mib) << 20, C.byref(out))
     return float(out.value) if rc == 0 and out.value > 0 else None
 
 

@@ -291,6 +291,45 @@ int mtsgpu_hbm_triad(int device, size_t bytes, int iters, double *gbs) {
 	return rc;
 }
 
+int mtsgpu_gather_roof(int device, size_t footprint_bytes, double *lane_requests_per_s) {
+	if (!lane_requests_per_s || footprint_bytes < 4096 || (footprint_bytes & (footprint_bytes - 1)) != 0 || footprint_bytes > (1ull << 32))
+		return gfail(nullptr, MTSGPU_EINVAL, "footprint must be a power of two between 4 KiB and 4 GiB");
+	*lane_requests_per_s = 0;
+	int nd = 0;
+	if (hipGetDeviceCount(&nd) != hipSuccess || device < 0 || device >= nd) return gfail(nullptr, MTSGPU_ENODEV, "no such HIP device");
+	GHIP(nullptr, hipSetDevice(device));
+	hipDeviceProp_t prop;
+	GHIP(nullptr, hipGetDeviceProperties(&prop, device));
+	const unsigned blocks = (unsigned) prop.multiProcessorCount * 7u;
+	const int iters = 1000;
+	uint4 *data = nullptr; uint32_t *sink = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr; hipStream_t s = nullptr;
+	int rc = 0;
+	do {
+		if (hipMalloc((void **) &data, footprint_bytes) != hipSuccess || hipMalloc((void **) &sink, 4) != hipSuccess || hipStreamCreate(&s) != hipSuccess
+		    || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { rc = gfail(nullptr, MTSGPU_EHIP, "gather roof: allocation failed"); break; }
+		(void) hipMemsetAsync(data, 1, footprint_bytes, s);
+		const uint32_t mask = (uint32_t) (footprint_bytes / 16 - 1);
+		launch_gather_roof(s, data, mask, iters, blocks, sink);           // warm-up
+		float best = 1e30f;
+		for (int i = 0; i < 3; ++i) {
+			(void) hipEventRecord(e0, s);
+			launch_gather_roof(s, data, mask, iters, blocks, sink);
+			(void) hipEventRecord(e1, s);
+			if (hipEventSynchronize(e1) != hipSuccess) { rc = gfail(nullptr, MTSGPU_EHIP, "gather roof: kernel failed"); break; }
+			float ms = 0; (void) hipEventElapsedTime(&ms, e0, e1);
+			if (ms > 0 && ms < best) best = ms;
+		}
+		if (!rc && best < 1e29f) *lane_requests_per_s = (double) blocks * 256.0 * iters / (best * 1e-3);
+	} while (false);
+	if (e0) (void) hipEventDestroy(e0);
+	if (e1) (void) hipEventDestroy(e1);
+	if (s) (void) hipStreamDestroy(s);
+	if (data) (void) hipFree(data);
+	if (sink) (void) hipFree(sink);
+	return rc;
+}
+
 int mtsgpu_make_camera_crop(const float origin[3], const float target[3], const float up[3], float fov_deg,
                             int film_width, int film_height, int crop_x, int crop_y, int crop_width, int crop_height,
                             mtsgpu_camera *out) {

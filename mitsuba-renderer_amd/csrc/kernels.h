@@ -258,6 +258,8 @@ void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint
 void launch_path_lengths(hipStream_t s, const DPaths &ps, uint32_t n_paths, unsigned long long *path_len);
 // a[i] = b[i] + s * c[i] over n float4
 void launch_triad(hipStream_t s, float4 *a, const float4 *b, const float4 *c, float scale, size_t n);
+// random 16-byte gathers, one element per lane and iteration, over (mask_elems + 1) elements
+void launch_gather_roof(hipStream_t s, const uint4 *data, uint32_t mask_elems, int iters, unsigned blocks, uint32_t *sink);
 // dst[i] += src[i] over n floats (the ordered film sum of a device group)
 void launch_add_film(hipStream_t s, float *dst, const float *src, size_t n);
 // ImageBlock tiles of one context: rect, first sampler slot of the tile inside its pass, block index

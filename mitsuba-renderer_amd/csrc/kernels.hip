@@ -2124,6 +2124,19 @@ __global__ void k_triad(float4 *a, const float4 *b, const float4 *c, float s, si
 	}
 }
 
+// the vector-memory request roof (mtsgpu_gather_roof): every lane loads 16 bytes from its own random element of a
+// footprint that fits the L2, the way k_trace walks the kd-tree; same grid shape as k_trace (7 workgroups of 256 per CU)
+__global__ __launch_bounds__(256, 7) void k_gather_roof(const uint4 *data, uint32_t mask_elems, int iters, uint32_t *sink) {
+	const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	uint32_t acc = 0, x = gw * 0x9E3779B9u + (threadIdx.x & 63u) * 0x85EBCA6Bu + 12345u;
+	for (int i = 0; i < iters; ++i) {
+		x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+		const uint4 v = data[x & mask_elems];
+		acc += v.x ^ v.w;
+	}
+	if (acc == 0xDEADBEEFu) sink[0] = acc;
+}
+
 __global__ void k_add_film(float *dst, const float *src, size_t n) {
 	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) dst[i] += src[i];
@@ -2316,6 +2329,9 @@ void launch_path_lengths(hipStream_t s, const DPaths &ps, uint32_t n_paths, unsi
 }
 void launch_triad(hipStream_t s, float4 *a, const float4 *b, const float4 *c, float scale, size_t n) {
 	if (n) hipLaunchKernelGGL(k_triad, dim3(256 * 16), dim3(256), 0, s, a, b, c, scale, n);
+}
+void launch_gather_roof(hipStream_t s, const uint4 *data, uint32_t mask_elems, int iters, unsigned blocks, uint32_t *sink) {
+	hipLaunchKernelGGL(k_gather_roof, dim3(blocks), dim3(256), 0, s, data, mask_elems, iters, sink);
 }
 void launch_add_film(hipStream_t s, float *dst, const float *src, size_t n) {
 	if (n) hipLaunchKernelGGL(k_add_film, dim3(blocks_for(n, 256)), dim3(256), 0, s, dst, src, n);
