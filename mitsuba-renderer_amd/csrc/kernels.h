@@ -174,6 +174,8 @@ struct DQueues {
 	uint32_t tune_batch;               // rays per wave and batch, 1..64
 	uint32_t tune_dyn_div;             // 1/x of the rounds of a large launch are claimed dynamically (default 4)
 	uint32_t tune_refill;              // refill threshold for coherent launches too (default: 64 there)
+	uint32_t tune_plain_below;         // launches of fewer rays run the plain loops (0 = 8 rounds of the largest grid)
+	uint32_t tune_step_cap;            // experiment builds (MG_EXP_STEP_CAP): leaf visits after which a ray is cut off
 	uint32_t tune_blocks_per_cu;       // experiment: fewer resident workgroups per CU than the kernel allows (0 = all)
 	uint32_t tune_xcd;                 // experiment: XCD x (workgroups with blockIdx % 8 == x) takes the x-th eighth of the queue
 };
@@ -214,7 +216,8 @@ __host__ __device__ inline TracePlan trace_plan(uint32_t n, int mode, const DQue
 	// the early loop exits trade the latency of a few straggling rays for throughput; with only a few
 	// batches per wave the stragglers are the critical path, so small launches run the plain loops
 	p.desc_min = q.desc_min; p.leaf_min = q.leaf_min; p.refill_min = q.refill_min;
-	if (n < 8u * (q.n_cus * kTraceBlocksPerCuMax) * kTraceBlock || q.coherent)
+	const uint32_t plainBelow = q.tune_plain_below ? q.tune_plain_below : 8u * (q.n_cus * kTraceBlocksPerCuMax) * kTraceBlock;
+	if (n < plainBelow || q.coherent)
 		p.desc_min = p.leaf_min = 1;
 	if (q.coherent && !q.tune_refill)
 		p.refill_min = 64;       // neighbouring camera samples finish together: refilling would only mix batches

@@ -125,15 +125,17 @@ __global__ void k_sample_arrays(DConfig cfg, uint32_t n_slots, const unsigned lo
 	}
 }
 
-// The same tables with the permutations shuffled in LDS ([entry][lane ^ entry]: the XOR swizzle keeps both the
-// per-lane shuffle accesses and the transposed write-out free of bank conflicts without padding) and written out
-// in coalesced 128-byte rows: the serial chain of a shuffle is ~2 dependent memory accesses per step, which LDS
-// serves an order of magnitude faster than the L2.  One wave per workgroup; used while spp * 128 B fits in 64 KB.
-__global__ __launch_bounds__(64) void k_ld_tables_lds(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_slots,
+// The same tables with the permutations shuffled in LDS and written out in coalesced rows: the serial chain of a
+// shuffle is ~2 dependent memory accesses per step, which LDS serves an order of magnitude faster than the L2.  One
+// wave per workgroup; L = `lanes` of its lanes (a power of two, as many as fit: L * spp * 2 B <= 64 KB) shuffle one
+// pixel each, all 64 lanes write the rows out.  Layout [entry][lane ^ entry mod L]: the XOR swizzle keeps both the
+// per-lane shuffle accesses and the transposed write-out free of bank conflicts without padding.
+__global__ __launch_bounds__(64) void k_ld_tables_lds(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_slots, uint32_t lanes,
                                                       uint32_t *scr, uint16_t *perm, unsigned long long *state_out) {
 	extern __shared__ uint16_t s_p[];
-	const uint32_t lane = threadIdx.x, slot0 = blockIdx.x * 64u, slot = slot0 + lane;
-	const bool active = slot < n_slots;
+	const uint32_t L = lanes, lm = L - 1u;
+	const uint32_t lane = threadIdx.x, slot0 = blockIdx.x * L, slot = slot0 + lane;
+	const bool active = lane < L && slot < n_slots;
 	const uint32_t spp = cfg.spp;
 	const int depth = cfg.ld_depth;
 	const bool ld = cfg.sampler_kind == 1;
@@ -151,19 +153,19 @@ __global__ __launch_bounds__(64) void k_ld_tables_lds(DConfig cfg, const uint32_
 					s[i * 3 + 2] = (uint32_t) (q >> 32);
 				}
 			}
-			for (uint32_t k = 0; k < spp; ++k) s_p[k * 64u + (lane ^ (k & 63u))] = (uint16_t) k;
+			for (uint32_t k = 0; k < spp; ++k) s_p[k * L + ((lane ^ k) & lm)] = (uint16_t) k;
 			for (uint32_t it = spp - 1; it > 0; --it) {
 				const uint32_t other = (uint32_t) keyedNextSize(st, it);
-				const uint32_t ia = it * 64u + (lane ^ (it & 63u)), ib = other * 64u + (lane ^ (other & 63u));
+				const uint32_t ia = it * L + ((lane ^ it) & lm), ib = other * L + ((lane ^ other) & lm);
 				const uint16_t a = s_p[ia], b = s_p[ib];
 				s_p[ia] = b; s_p[ib] = a;
 			}
 		}
 		__syncthreads();
-		const uint32_t rows = (n_slots - slot0 < 64u) ? n_slots - slot0 : 64u;
+		const uint32_t rows = (n_slots - slot0 < L) ? n_slots - slot0 : L;
 		for (uint32_t r = 0; r < rows; ++r) {
 			uint16_t *dst = perm + ((size_t) (slot0 + r) * 2 * depth + arr) * spp;
-			for (uint32_t k = lane; k < spp; k += 64u) dst[k] = s_p[k * 64u + (r ^ (k & 63u))];
+			for (uint32_t k = lane; k < spp; k += 64u) dst[k] = s_p[k * L + ((r ^ k) & lm)];
 		}
 		__syncthreads();
 	}
@@ -468,6 +470,12 @@ template <int BIT, typename T> __device__ __forceinline__ void st_stream(T *p, c
 #ifndef MG_EXP_PAD_DESC
 #define MG_EXP_PAD_DESC 0
 #endif
+#ifndef MG_EXP_STEP_CAP
+#define MG_EXP_STEP_CAP 0
+#endif
+#ifndef MG_EXP_COUNT_SPILL
+#define MG_EXP_COUNT_SPILL 0      // counting build: the 8th counter holds stack pushes that went to the HBM spill area
+#endif
 #ifndef MG_EXP_PAD_LEAF
 #define MG_EXP_PAD_LEAF 0
 #endif
@@ -505,6 +513,9 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 
 	uint32_t c_inner = 0, c_leaf = 0, c_idx = 0, c_tri = 0;
 	float pad = 0.0f;                      // experiment builds only
+#if MG_EXP_STEP_CAP
+	uint32_t n_visits = 0;
+#endif
 	uint32_t w_inner = 0, w_leaf = 0, w_outer = 0, w_batch = 0;   // COUNT: lane slots issued per loop (64 per wave iteration)
 #define MG_WSLOT(w) do { if (COUNT && lane == (uint32_t) __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) (w) += 64u; } while (0)
 
@@ -613,7 +624,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 			const uint32_t taken = (B - nlive < remaining) ? B - nlive : remaining;
 			const uint32_t my = sup_base + r;
 			sup_base += taken; sup_left -= taken;
-			MG_WSLOT(w_batch);
+			if (!MG_EXP_COUNT_SPILL) MG_WSLOT(w_batch);
 			if (take) {
 				id = (MODE == 1) ? my : ld_stream<1>(&queue[my]);       // shadow rays are addressed by their queue position
 				float4 a, b;
@@ -655,6 +666,9 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				if (rmaxt < maxt) maxt = rmaxt;
 				if (!(maxt > mint)) go = false;
 				best_t = MG_INF; best_u = 0; best_v = 0; best_prim = kNoPrim; best_shape = 0;
+#if MG_EXP_STEP_CAP
+				n_visits = 0;
+#endif
 				found = false;
 				done = !go;       // a ray that misses the scene's box is finished at once
 				has = go;
@@ -708,7 +722,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					if (push) {
 						// push the current exit point's reference; (cur, far child) becomes the exit point
 						if (sp < kStackLDS) s_stack[sp][tid] = ex_ref;
-						else q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref;
+						else { q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref; if (COUNT && MG_EXP_COUNT_SPILL) w_batch++; }
 						++sp;
 						const uint32_t farRight = A ? 1u : 0u;
 						const float distToSplit = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
@@ -834,6 +848,11 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						}
 					}
 				}
+#if MG_EXP_STEP_CAP
+				// experiment (WRONG RESULTS, timing only): rays are cut off after q.tune_step_cap leaf visits, to see how
+				// much of a short launch is the tail of its few longest rays
+				if (q.tune_step_cap && ++n_visits > q.tune_step_cap) finished = true;
+#endif
 				if (finished) { has = false; done = true; found = (MODE == 0) ? (best_prim != kNoPrim) : hitShadow; }
 				}
 			}
@@ -2235,9 +2254,13 @@ void launch_iota(hipStream_t s, uint32_t *p, uint32_t n) {
 void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_keys, uint32_t n_slots,
                       uint32_t *scr, uint16_t *perm, unsigned long long *state_out) {
 	if (!n_slots) return;
-	const size_t lds = (size_t) cfg.spp * 64 * sizeof(uint16_t);
+	// The LDS kernel pays while all 64 lanes of a wave shuffle (up to 512 samples per pixel).  With fewer lanes per wave
+	// (8 at 4096 samples, measured on the C4 frame) the chip holds too few shuffling lanes and the global-memory kernel,
+	// which hides its latency behind 64 lanes per wave, is 6 % faster on the whole frame.
+	const uint32_t lanes = 64;
+	const size_t lds = (size_t) cfg.spp * lanes * sizeof(uint16_t);
 	if (lds <= 64 * 1024)
-		hipLaunchKernelGGL(k_ld_tables_lds, dim3(blocks_for(n_slots, 64)), dim3(64), lds, s, cfg, pixel_keys, n_slots, scr, perm, state_out);
+		hipLaunchKernelGGL(k_ld_tables_lds, dim3(blocks_for(n_slots, lanes)), dim3(64), lds, s, cfg, pixel_keys, n_slots, lanes, scr, perm, state_out);
 	else
 		hipLaunchKernelGGL(k_ld_tables, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, cfg, pixel_keys, n_slots, scr, perm, state_out);
 }

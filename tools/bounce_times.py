@@ -8,6 +8,7 @@ res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 knobs = dict(a.split("=") for a in sys.argv[3:])
 if knobs.pop("debug", "0") == "1":
     os.environ["MTSGPU_DEBUG"] = "1"
+count = knobs.pop("count", "0") == "1"
 sd = pkg.scenes.cornell_c3()
 scene = pkg.Scene(sd, None, gpu_binning=True)
 cam = pkg.PerspectiveCamera.for_description(sd, res, res)
@@ -15,7 +16,7 @@ it = pkg.MIPathTracer(maxDepth=sd.max_depth)
 it.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp, seed=0x5EED)
 if knobs:
     it.set_tuning(**{k: int(v) for k, v in knobs.items()})
-it.set_options(time_kernels=True)
+it.set_options(time_kernels=True, count_traversal=count)
 assert it.render()                      # warm-up (allocations)
 sys.stderr.write("---- frame ----\n")
 if "quiet" not in os.environ.get("MTSGPU_BT", ""):
