@@ -1963,6 +1963,10 @@ __device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, c
 
 }
 
+#ifndef MG_SHADE_ALL_SLOTS
+#define MG_SHADE_ALL_SLOTS 1      // whole 128-byte lines in both directions; 0 (only the slots needed: 7 read, 6 written, 3 of the
+                                  // triangle) was measured at 66 ms instead of 44 ms per frame: partial lines cost a read-modify-write
+#endif
 constexpr int kRowStride = kPathSlots + 1;      // LDS row of a staged path record: 9 float4, conflict-free for 16-byte accesses
 
 template <int BT, bool ROUNDS>
@@ -2001,7 +2005,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 	for (int r = 0; r < 8; ++r) {
 		const uint32_t src = grp + 8u * r;
 		const uint32_t sid = (uint32_t) __shfl((int) id, (int) src);
-		if ((actMask >> src) & 1ull) rows[src * kRowStride + sub] = ld_stream<4>(&ps.base[(size_t) sid * kPathSlots + sub]);
+		// slot 7 (the raster position) is only read by the film kernels
+		if (((actMask >> src) & 1ull) && (MG_SHADE_ALL_SLOTS || sub != 7u)) rows[src * kRowStride + sub] = ld_stream<4>(&ps.base[(size_t) sid * kPathSlots + sub]);
 	}
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 	bool continues = false, wantShadow = false;
@@ -2033,7 +2038,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 		for (int r = 0; r < 4; ++r) {
 			const uint32_t src = grp4 + 16u * r;
 			const uint32_t sprim = (uint32_t) __shfl((int) prim, (int) src);
-			if ((validMask >> src) & 1ull) rows[src * kRowStride + slotOf] = sc.tri_pos[(size_t) sprim * kTriStride + sub4];
+			if (((validMask >> src) & 1ull) && (MG_SHADE_ALL_SLOTS || sub4 != 3u)) rows[src * kRowStride + slotOf] = sc.tri_pos[(size_t) sprim * kTriStride + sub4];
 		}
 	}
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -2044,7 +2049,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 	for (int r = 0; r < 8; ++r) {
 		const uint32_t src = grp + 8u * r;
 		const uint32_t sid = (uint32_t) __shfl((int) id, (int) src);
-		if ((actMask >> src) & 1ull) st_stream<4>(&ps.base[(size_t) sid * kPathSlots + sub], rows[src * kRowStride + sub]);
+		// the hit (slot 2) and the raster position (slot 7) do not change here
+		if (((actMask >> src) & 1ull) && (MG_SHADE_ALL_SLOTS || (sub != 2u && sub != 7u))) st_stream<4>(&ps.base[(size_t) sid * kPathSlots + sub], rows[src * kRowStride + sub]);
 	}
 
 	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue.
