@@ -739,11 +739,13 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	DScene d{};
 	int rc = 0;
 	{
-		// Device node order: 128-byte lines (16 nodes) are filled with breadth-first pieces of
-		// subtrees ("treelets") so that one L1 miss serves several consecutive traversal steps.
+		// Device node order.  The first trace_top_nodes() slots hold the root and the sibling pairs below it in
+		// breadth-first order: k_trace keeps that prefix in LDS.  After it, 128-byte lines (16 nodes) are filled with
+		// breadth-first pieces of subtrees ("treelets") so that one L1 miss serves several consecutive traversal steps.
 		// The KDNode encoding is unchanged (siblings adjacent, relative offset to the left child,
 		// gkdtree.h:442-470); only where a node lives changes, which traversal results do not depend on.
 		const uint32_t N = sc->n_nodes;
+		const uint32_t topSlots = trace_top_nodes();
 		std::vector<uint32_t> newIndex(N, 0u);
 		std::vector<uint32_t> stack, cand;           // entries: old index of the left node of a sibling pair
 		auto leftOf = [&](uint32_t i) { return i + ((sc->kd_nodes[2 * (size_t) i] & 0x3FFFFFFCu) >> 2); };
@@ -759,13 +761,14 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 			pos += 2;
 			for (uint32_t k = 0; k < 2; ++k)
 				if (!isLeaf(l + k)) cand.push_back(leftOf(l + k));
-			if ((pos & 15u) == 0u) {
-				// line full: the remaining frontier becomes the roots of later treelets (depth-first order)
+			const bool full = pos < topSlots ? false : (pos == topSlots || (pos & 15u) == 0u);
+			if (full) {
+				// region full: the remaining frontier becomes the roots of later treelets (depth-first order)
 				for (size_t k = cand.size(); k > head; --k) stack.push_back(cand[k - 1]);
 				cand.clear(); head = 0;
 			}
 		}
-		const uint32_t total = std::max<uint32_t>(pos, 2u);
+		const uint32_t total = std::max<uint32_t>(pos, std::max(2u, topSlots));      // the LDS prefix is always there to copy
 		if (total >= (1u << 29)) return fail(c, MTSGPU_EINVAL, "kd-tree too large");
 		std::vector<uint32_t> dev(2 * (size_t) total, 0u);
 		dev[2] = 0x80000000u; dev[3] = 0u;           // padding slot: empty leaf, never referenced

@@ -274,6 +274,7 @@ void launch_add_blocks(hipStream_t s, const DConfig &cfg, const TileMeta *tiles,
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, size_t n);
 void launch_iota(hipStream_t s, uint32_t *p, uint32_t n);
 size_t trace_spill_levels();
+uint32_t trace_top_nodes();       // device nodes k_trace copies into LDS: the breadth-first top of the tree
 size_t trace_stack_levels();      // depth of the traversal stack (LDS + spill levels)
 
 } // namespace mg

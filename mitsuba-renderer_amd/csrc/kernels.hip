@@ -484,13 +484,25 @@ template <int N> __device__ __forceinline__ void exp_pad(float &x) {
 	for (int i = 0; i < N; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(x));
 }
 
-constexpr int kStackLDS = 12;
+#ifndef MG_STACK_LDS
+#define MG_STACK_LDS 10
+#endif
+#ifndef MG_TOP_PAIRS
+#define MG_TOP_PAIRS 128
+#endif
+constexpr int kStackLDS = MG_STACK_LDS;       // stack levels kept in LDS (deeper ones spill: 1 push in 10^4 at 12 levels on C3)
+// The first 2 * kTopPairs device nodes -- the root and the sibling pairs below it in breadth-first order, see
+// mtsgpu_upload_scene -- are copied into LDS by every workgroup: each ray's descent from the root starts with 8-9
+// levels that every other ray visits too, and a vector-memory request costs the CU ~0.5-1 ns per lane where an LDS
+// read costs ~0.05 (profiles/r02_ta_gather_microbench.txt).  0 switches the cache off.
+constexpr uint32_t kTopPairs = MG_TOP_PAIRS;
 constexpr int kSpillLevels = 40;      // 12 + 40 >= MTS_KD_MAXDEPTH (48) + 2
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 
 size_t trace_spill_levels() { return kSpillLevels; }
 size_t trace_stack_levels() { return kStackLDS + kSpillLevels; }
+uint32_t trace_top_nodes() { return 2u * kTopPairs; }
 
 // Persistent waves: the grid is sized to fill the chip once and every wave walks its own 64-ray
 // batches of the queue with a private cursor (no work-queue atomic: a single head word saturates at
@@ -505,7 +517,16 @@ size_t trace_stack_levels() { return kStackLDS + kSpillLevels; }
 template <int MODE, bool COUNT, bool BIN>
 __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &ps, const DQueues &q, const TracePlan &plan,
                                            const uint32_t *queue, uint32_t n, const uint32_t first, const uint32_t stride,
-                                           uint32_t (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock]) {
+                                           uint32_t (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock], const uint4 *s_top) {
+	// node fetches: from the LDS copy of the top of the tree when the index lies inside it
+	auto load_node = [&](uint32_t i) -> uint2 {
+		if (kTopPairs && i < 2u * kTopPairs) return reinterpret_cast<const uint2 *>(s_top)[i];
+		return sc.nodes[i];
+	};
+	auto load_pair = [&](uint32_t left) -> uint4 {
+		if (kTopPairs && left < 2u * kTopPairs) return s_top[left >> 1];
+		return reinterpret_cast<const uint4 *>(sc.nodes)[left >> 1];
+	};
 	const uint32_t tid = threadIdx.x;
 	const uint32_t gtid = blockIdx.x * kTraceBlock + tid;     // spill slot of this lane
 	const uint32_t lane = lane_id();
@@ -681,7 +702,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					ex_t = maxt; exx = ox + maxt * dx; exy = oy + maxt * dy; exz = oz + maxt * dz;
 					ex_node = kNullNode; ex_ref = kSentinel;
 					sp = 0; cur = 0; e_cont = kNoPrim;
-					nd = sc.nodes[0];
+					nd = load_node(0u);
 				}
 			}
 		}
@@ -702,7 +723,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					const uint32_t left = nd.x >> 2;            // device nodes hold the absolute index of the left child
 					// both children in one 16-byte load (sibling pairs are 16-byte aligned in the device order), issued
 					// before the case logic below instead of after it: the step is a chain of dependent fetches
-					const uint4 pair = reinterpret_cast<const uint4 *>(sc.nodes)[left >> 1];
+					const uint4 pair = load_pair(left);
 					if (COUNT) c_inner++;
 					MG_WSLOT(w_inner);
 					if (MG_EXP_PAD_DESC) exp_pad<MG_EXP_PAD_DESC>(pad);
@@ -829,7 +850,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						finished = true;
 					} else {
 						--sp;
-						nd = sc.nodes[cur];          // in flight together with the parent's node below
+						nd = load_node(cur);         // in flight together with the parent's node below
 						const uint32_t ref = (sp < kStackLDS) ? s_stack[sp][tid]
 						                                      : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
 						if (ref == kSentinel) {
@@ -837,7 +858,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 							ex_node = kNullNode; ex_ref = kSentinel;
 						} else {
 							const uint32_t parent = ref >> 1;
-							const uint2 pn = sc.nodes[parent];
+							const uint2 pn = load_node(parent);
 							const int axis = (int) (pn.x & 3u);
 							const float split = __uint_as_float(pn.y);
 							ex_node = (pn.x >> 2) + (ref & 1u);
@@ -879,6 +900,7 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
                                                           const uint32_t *queue, uint32_t n_host, const uint32_t *n_dev) {
 	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
 	__shared__ uint32_t s_mbox[8][kTraceBlock];
+	__shared__ uint4 s_top[kTopPairs ? kTopPairs : 1];
 	// the number of rays: known to the host, or left in device memory by the kernel that filled the queue
 	const uint32_t n = n_dev ? (uint32_t) __builtin_amdgcn_readfirstlane((int) *n_dev) : n_host;
 	const TracePlan plan = trace_plan(n, MODE, q);
@@ -901,7 +923,12 @@ __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trac
 	}
 	const uint32_t first = lo + (bi * (kTraceBlock / 64u) + (threadIdx.x >> 6)) * plan.batch;
 	const uint32_t stride = nb * (kTraceBlock / 64u) * plan.batch;      // queue entries per round of the grid
-	trace_body<MODE, COUNT, BIN>(sc, ps, q, p2, queue, hi, first, stride, s_stack, s_mbox);
+	if (kTopPairs) {
+		// the device tree is padded to at least 2 * kTopPairs nodes (mtsgpu_upload_scene)
+		for (uint32_t t = threadIdx.x; t < kTopPairs; t += kTraceBlock) s_top[t] = reinterpret_cast<const uint4 *>(sc.nodes)[t];
+		__syncthreads();
+	}
+	trace_body<MODE, COUNT, BIN>(sc, ps, q, p2, queue, hi, first, stride, s_stack, s_mbox, s_top);
 }
 
 // Device-driven bounces: the per-bin views k_shade needs, from the shard counters the closest-hit launch left in `cur`
