@@ -260,7 +260,8 @@ void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint
                        uint32_t spp_per_slot, float *film, unsigned long long *path_len);
 void launch_path_lengths(hipStream_t s, const DPaths &ps, uint32_t n_paths, unsigned long long *path_len);
 // a[i] = b[i] + s * c[i] over n float4
-void launch_triad(hipStream_t s, float4 *a, const float4 *b, const float4 *c, float scale, size_t n);
+// `blocks` workgroups of 256 stride over the arrays (0: 4096)
+void launch_triad(hipStream_t s, float4 *a, const float4 *b, const float4 *c, float scale, size_t n, unsigned blocks = 0);
 // random 16-byte gathers, one element per lane and iteration, over (mask_elems + 1) elements
 void launch_gather_roof(hipStream_t s, const uint4 *data, uint32_t mask_elems, int iters, unsigned blocks, uint32_t *sink);
 // dst[i] += src[i] over n floats (the ordered film sum of a device group)

@@ -2383,8 +2383,8 @@ void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint
 void launch_path_lengths(hipStream_t s, const DPaths &ps, uint32_t n_paths, unsigned long long *path_len) {
 	if (n_paths) hipLaunchKernelGGL(k_path_lengths, dim3(blocks_for(n_paths, 256)), dim3(256), 0, s, ps, n_paths, path_len);
 }
-void launch_triad(hipStream_t s, float4 *a, const float4 *b, const float4 *c, float scale, size_t n) {
-	if (n) hipLaunchKernelGGL(k_triad, dim3(256 * 16), dim3(256), 0, s, a, b, c, scale, n);
+void launch_triad(hipStream_t s, float4 *a, const float4 *b, const float4 *c, float scale, size_t n, unsigned blocks) {
+	if (n) hipLaunchKernelGGL(k_triad, dim3(blocks ? blocks : 256u * 16u), dim3(256), 0, s, a, b, c, scale, n);
 }
 void launch_gather_roof(hipStream_t s, const uint4 *data, uint32_t mask_elems, int iters, unsigned blocks, uint32_t *sink) {
 	hipLaunchKernelGGL(k_gather_roof, dim3(blocks), dim3(256), 0, s, data, mask_elems, iters, sink);
