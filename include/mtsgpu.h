@@ -383,8 +383,9 @@ typedef struct mtsgpu_kd_params {
 	float traversal_cost, query_cost, empty_space_bonus;
 	int32_t stop_prims, max_bad_refines, exact_prim_threshold, max_depth, min_max_bins;
 	int32_t clip, retract, n_threads;
-	/* 1: the min-max binning phase (> exact_prim_threshold primitives per node) runs on the current HIP device; the
-	 * tree is the same bit for bit.  An error if there is no device; 0 = host */
+	/* bit set -- 1: the min-max binning phase (> exact_prim_threshold primitives per node, gkdtree.h:1735-1867) runs on
+	 * the current HIP device; 2: the exact O(n log n) sweep below that threshold (gkdtree.h:1898-2345) runs there too.
+	 * The tree is the same bit for bit either way.  An error if there is no device; 0 = host */
 	int32_t gpu_binning;
 } mtsgpu_kd_params;
 

@@ -138,15 +138,15 @@ class Scene:
     """A flattened, render-ready scene: what Scene::initialize() leaves behind
     (kd-tree, TriAccel table, vertex normals, luminaire CDFs), built by mtsgpu_flatten()."""
 
-    def __init__(self, description, kd_params=None, gpu_binning=False):
+    def __init__(self, description, kd_params=None, gpu_binning=False, gpu_exact=False):
         """gpu_binning: run the min-max binning phase of the kd-tree build (nodes of more than
-        exactPrimThreshold primitives, gkdtree.h:1735-1867) on the current HIP device -- same tree, bit for bit"""
+        exactPrimThreshold primitives, gkdtree.h:1735-1867) on the current HIP device -- same tree, bit for bit.
+        gpu_exact: the exact O(n log n) sweep below that threshold (gkdtree.h:1898-2345) on the device as well."""
         self.description = description
         self._desc, self._keep = description.to_ctypes()
         self._h = C.c_void_p()
         kp = kd_params if kd_params is not None else abi.KdParams()
-        if gpu_binning:
-            kp.gpu_binning = 1
+        kp.gpu_binning = (kp.gpu_binning & ~3) | (1 if gpu_binning else 0) | (2 if gpu_exact else 0)
         rc = lib().mtsgpu_flatten(C.byref(self._desc), C.byref(kp), C.byref(self._h))
         if rc != 0:
             raise MtsGpuError("mtsgpu_flatten: %s" % lib().mtsgpu_last_error(None).decode())

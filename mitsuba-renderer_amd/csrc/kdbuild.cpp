@@ -16,11 +16,15 @@
 // the result does not depend on the sort implementation.
 #include "host.h"
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <limits>
 #include <mutex>
 #include <thread>
@@ -47,8 +51,12 @@ struct Box {
 	}
 };
 
+// std::min(a, b) = (b < a) ? b : a and std::max(a, b) = (a < b) ? b : a, usable on the device
+__host__ __device__ inline float hdMin(float a, float b) { return (b < a) ? b : a; }
+__host__ __device__ inline float hdMax(float a, float b) { return (a < b) ? b : a; }
+
 // Sutherland-Hodgman against one plane, double precision (triangle.cpp:61-106)
-int clipPlane(const double (*in)[3], int inCount, double (*out)[3], int axis, double splitPos, bool isMinimum) {
+__host__ __device__ inline int clipPlane(const double (*in)[3], int inCount, double (*out)[3], int axis, double splitPos, bool isMinimum) {
 	if (inCount < 3)
 		return 0;
 	double cur[3] = { in[0][0], in[0][1], in[0][2] };
@@ -62,26 +70,28 @@ int clipPlane(const double (*in)[3], int inCount, double (*out)[3], int axis, do
 		distance = sign * (next[axis] - splitPos);
 		const bool nextIsInside = (distance >= 0);
 		if (curIsInside && nextIsInside) {
-			std::memcpy(out[outCount++], next, sizeof(next));
+			for (int c = 0; c < 3; ++c) out[outCount][c] = next[c];
+			outCount++;
 		} else if (curIsInside != nextIsInside) {
 			const double t = (splitPos - cur[axis]) / (next[axis] - cur[axis]);
 			for (int c = 0; c < 3; ++c) out[outCount][c] = cur[c] + (next[c] - cur[c]) * t;
 			out[outCount][axis] = splitPos;
 			outCount++;
-			if (nextIsInside)
-				std::memcpy(out[outCount++], next, sizeof(next));
+			if (nextIsInside) {
+				for (int c = 0; c < 3; ++c) out[outCount][c] = next[c];
+				outCount++;
+			}
 		}
-		std::memcpy(cur, next, sizeof(next));
+		for (int c = 0; c < 3; ++c) cur[c] = next[c];
 		curIsInside = nextIsInside;
 	}
 	return outCount;
 }
 
-} // namespace
-
 // Triangle::getClippedAABB (triangle.cpp:108-158): clip in double, round outward to float
-bool clippedTriangleBox(const float *p0, const float *p1, const float *p2, const float *bmin, const float *bmax,
-                        float *omin, float *omax) {
+__host__ __device__ inline bool clippedTriangleBoxHD(const float *p0, const float *p1, const float *p2, const float *bmin, const float *bmax,
+                                                     float *omin, float *omax) {
+	const float inf = INFINITY;
 	double a[10][3], b[10][3];
 	for (int c = 0; c < 3; ++c) { a[0][c] = p0[c]; a[1][c] = p1[c]; a[2][c] = p2[c]; }
 	int n = 3;
@@ -89,23 +99,30 @@ bool clippedTriangleBox(const float *p0, const float *p1, const float *p2, const
 		n = clipPlane(a, n, b, axis, (double) bmin[axis], true);
 		n = clipPlane(b, n, a, axis, (double) bmax[axis], false);
 	}
-	for (int c = 0; c < 3; ++c) { omin[c] = kInf; omax[c] = -kInf; }
+	for (int c = 0; c < 3; ++c) { omin[c] = inf; omax[c] = -inf; }
 	for (int i = 0; i < n; ++i)
 		for (int j = 0; j < 3; ++j) {
 			const double pos_d = a[i][j];
 			const float pos_f = (float) pos_d;
 			float lo, hi;
-			if (pos_f < pos_d) { lo = pos_f; hi = nextafterf(pos_f, kInf); }
-			else if (pos_f > pos_d) { hi = pos_f; lo = nextafterf(pos_f, -kInf); }
+			if (pos_f < pos_d) { lo = pos_f; hi = nextafterf(pos_f, inf); }
+			else if (pos_f > pos_d) { hi = pos_f; lo = nextafterf(pos_f, -inf); }
 			else lo = hi = pos_f;
-			omin[j] = std::min(omin[j], lo);
-			omax[j] = std::max(omax[j], hi);
+			omin[j] = hdMin(omin[j], lo);
+			omax[j] = hdMax(omax[j], hi);
 		}
-	for (int c = 0; c < 3; ++c) { omin[c] = std::max(omin[c], bmin[c]); omax[c] = std::min(omax[c], bmax[c]); }
+	for (int c = 0; c < 3; ++c) { omin[c] = hdMax(omin[c], bmin[c]); omax[c] = hdMin(omax[c], bmax[c]); }
 	for (int c = 0; c < 3; ++c)
 		if (omax[c] < omin[c])
 			return false;
 	return true;
+}
+
+} // namespace
+
+bool clippedTriangleBox(const float *p0, const float *p1, const float *p2, const float *bmin, const float *bmax,
+                        float *omin, float *omax) {
+	return clippedTriangleBoxHD(p0, p1, p2, bmin, bmax, omin, omax);
 }
 
 namespace {
@@ -959,6 +976,650 @@ void planOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_t
 	KDHIP(hipStreamSynchronize(st));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Device exact phase: buildTree (gkdtree.h:1898-2345), the O(n log n) sweep for nodes of at most exactPrimThreshold
+// primitives, for ALL such subtrees ("jobs") at once, one tree level per round.
+//
+// The reference keeps one event list per node, sorted by (axis, position, type), and re-uses it down the tree with
+// stable partitions and merges.  Here a node is the contiguous run of its primitive instances (primitive id + the box
+// the primitive has inside the node), always in ascending primitive order, and every level
+//   1. emits the edge events of all instances (createEventList, :1490-1530) with a 58-bit key
+//      node | axis | position | type and sorts them with ONE stable radix sort (rocPRIM): events of equal key keep
+//      the instance order, i.e. the primitive order, which is the tie rule of EventLess above;
+//   2. turns the sweep (:1936-2021) into prefix sums over the sorted events: the counts in front of and up to a group
+//      of events at one position give numLeft / numRight / numPlanar of that candidate plane, its cost is evaluated by
+//      the group's last event with the reference's expressions, and an atomic minimum over (cost, event index) per node
+//      finds the candidate the sequential loop keeps (the first of the cheapest);
+//   3. lets the HOST take the decisions of :2023-2051 (leaf, bad refines) from that record with the same code path;
+//   4. classifies every instance against the plane (:2053-2103), re-clips the straddlers in binary64
+//      (Triangle::getClippedAABB, :2140-2219) and scatters the instances to the children with prefix sums (stable).
+// Leaves get their primitive order on the host from the boxes of their instances.  When the last level is done the
+// host replays the nodes depth first with the bookkeeping of buildTree (cost of the subtree, retraction :2327-2341,
+// counters) into the Context of every job, so everything downstream -- and the tree -- is what runExact produces.
+// ---------------------------------------------------------------------------------------------------------------
+struct XInst { uint32_t prim; float mn[3], mx[3]; uint32_t node; };        // 32 B
+struct XNodeDev {
+	float mn[3], mx[3];              // the node's box
+	uint32_t primCount;              // what the sweep counts numRight down from
+	uint32_t instBegin, instCount;
+	uint32_t sweep;                  // 0: a leaf before any sweep (stopPrims / maxDepth): no events
+	uint32_t isSplit, isLeaf;        // the host's decision
+	int32_t axis; float split; uint32_t planarLeft;
+	uint32_t childBase[2], childNode[2];
+};
+struct XBest { float cost, pos; int32_t axis; uint32_t numLeft, numRight, planarLeft; };
+struct XLeafItem { uint32_t prim; float mn0; uint32_t planar; };
+struct XParams { float traversalCost, queryCost, emptySpaceBonus; int clip; };
+
+constexpr uint64_t kXInvalid = ~0ull;
+constexpr uint32_t kXMaxNodes = 1u << 22;
+
+#define KXHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string("kd-tree build (device exact phase): ") + hipGetErrorString(e_)); } while (0)
+
+__device__ inline uint32_t xMono(float v) {
+	const uint32_t u = __float_as_uint(v + 0.0f);         // -0 and +0 compare equal in EventLess
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline uint32_t xOrderable(float v) {
+	const uint32_t u = __float_as_uint(v);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// the box a primitive has inside `to` (Geometry::clipped / Geometry::box); triPos = 9 floats per primitive, a
+// non-triangle primitive has NaN in its first slot and its box in genBox
+__device__ inline bool xClipped(const float *triPos, const float *genBox, uint32_t prim, const float *tmn, const float *tmx, float *omn, float *omx) {
+	const float *t = triPos + 9 * (size_t) prim;
+	if (t[0] != t[0]) {
+		const float *g = genBox + 6 * (size_t) prim;
+		for (int a = 0; a < 3; ++a) { omn[a] = hdMax(g[a], tmn[a]); omx[a] = hdMin(g[3 + a], tmx[a]); }
+		for (int a = 0; a < 3; ++a) if (omx[a] < omn[a]) return false;
+		return true;
+	}
+	return clippedTriangleBoxHD(t, t + 3, t + 6, tmn, tmx, omn, omx);
+}
+__device__ inline void xBox(const float *triPos, const float *genBox, uint32_t prim, float *omn, float *omx) {
+	const float *t = triPos + 9 * (size_t) prim;
+	if (t[0] != t[0]) {
+		const float *g = genBox + 6 * (size_t) prim;
+		for (int a = 0; a < 3; ++a) { omn[a] = g[a]; omx[a] = g[3 + a]; }
+		return;
+	}
+	for (int a = 0; a < 3; ++a) { omn[a] = INFINITY; omx[a] = -INFINITY; }
+	for (int v = 0; v < 3; ++v)
+		for (int a = 0; a < 3; ++a) { omn[a] = hdMin(omn[a], t[3 * v + a]); omx[a] = hdMax(omx[a], t[3 * v + a]); }
+}
+__device__ inline float xArea(const float *mn, const float *mx) {
+	const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+	return (float) 2.0 * (dx * dy + dx * dz + dy * dz);
+}
+
+// transitionToNLogN (gkdtree.h:1668-1704): the instances of the jobs' primitives; keep[i] = 0 drops a primitive whose
+// clipped box is empty or has no area
+__global__ void k_x_init(const float *triPos, const float *genBox, const uint32_t *prims, const uint32_t *primNode, uint32_t n,
+                         const XNodeDev *nodes, int clip, XInst *out, uint32_t *keep) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	XInst x; x.prim = prims[i]; x.node = primNode[i];
+	const XNodeDev &nd = nodes[x.node];
+	bool ok = true;
+	if (clip) ok = xClipped(triPos, genBox, x.prim, nd.mn, nd.mx, x.mn, x.mx) && xArea(x.mn, x.mx) != 0;
+	else xBox(triPos, genBox, x.prim, x.mn, x.mx);
+	out[i] = x; keep[i] = ok ? 1u : 0u;
+}
+__global__ void k_x_compact(const XInst *in, const uint32_t *keep, const uint32_t *scan, uint32_t n, XInst *out) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && keep[i]) out[scan[i] - 1u] = in[i];
+}
+// counts of up to three flags inside the instance ranges of the nodes: out[j * n + k] = scan_j[end_k - 1] - scan_j[begin_k - 1]
+// (inclusive scans)
+__global__ void k_x_range_counts(const uint32_t *s0, const uint32_t *s1, const uint32_t *s2, const XNodeDev *nodes, uint32_t n, uint32_t *out) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	const uint32_t b = nodes[k].instBegin, c = nodes[k].instCount;
+	const uint32_t *sc[3] = { s0, s1, s2 };
+	for (int j = 0; j < 3; ++j)
+		if (sc[j]) out[(size_t) j * n + k] = c ? sc[j][b + c - 1] - (b ? sc[j][b - 1] : 0u) : 0u;
+}
+
+// createEventList: two key slots per instance and axis (a planar primitive uses one)
+__global__ void k_x_emit(const XInst *inst, uint32_t n, const XNodeDev *nodes, unsigned long long *keys, uint32_t *vals) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const XInst x = inst[i];
+	const bool sweep = nodes[x.node].sweep != 0u;
+	for (int a = 0; a < 3; ++a) {
+		unsigned long long k0 = kXInvalid, k1 = kXInvalid;
+		if (sweep) {
+			const unsigned long long hi = (unsigned long long) (x.node * 4u + (uint32_t) a) << 34;
+			if (x.mn[a] == x.mx[a]) k0 = hi | ((unsigned long long) xMono(x.mn[a]) << 2) | (unsigned long long) kPlanar;
+			else {
+				k0 = hi | ((unsigned long long) xMono(x.mn[a]) << 2) | (unsigned long long) kStart;
+				k1 = hi | ((unsigned long long) xMono(x.mx[a]) << 2) | (unsigned long long) kEnd;
+			}
+		}
+		keys[6 * (size_t) i + 2 * a] = k0; keys[6 * (size_t) i + 2 * a + 1] = k1;
+		vals[6 * (size_t) i + 2 * a] = i; vals[6 * (size_t) i + 2 * a + 1] = i;
+	}
+}
+// per sorted event: its type as three counters, the (index + 1) of the event that opens its group, segment starts
+__global__ void k_x_flags(const unsigned long long *keys, uint32_t n, uint32_t *cE, uint32_t *cP, uint32_t *cS, uint32_t *head, uint32_t *segStart) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const unsigned long long k = keys[i];
+	const bool valid = k != kXInvalid;
+	const uint32_t type = (uint32_t) (k & 3ull);
+	cE[i] = valid && type == kEnd; cP[i] = valid && type == kPlanar; cS[i] = valid && type == kStart;
+	const unsigned long long prev = i ? keys[i - 1] : kXInvalid;
+	head[i] = (valid && (i == 0 || (prev >> 2) != (k >> 2))) ? i + 1u : 0u;
+	if (valid && (i == 0 || (prev >> 34) != (k >> 34))) segStart[(uint32_t) (k >> 34)] = i;
+}
+
+// the candidate plane of the group of events that ends at sorted position i (gkdtree.h:1950-2016)
+struct XCand { bool valid; float cost, pos; uint32_t numLeft, numRight, planarLeft; int axis; uint32_t node; };
+__device__ inline XCand xCandidate(uint32_t i, const unsigned long long *keys, const uint32_t *vals, const uint32_t *E, const uint32_t *P,
+                                   const uint32_t *S, const uint32_t *H, const uint32_t *segStart, const XInst *inst, const XNodeDev *nodes,
+                                   const XParams prm) {
+	XCand c; c.valid = false;
+	const unsigned long long k = keys[i];
+	const uint32_t seg = (uint32_t) (k >> 34);
+	c.node = seg >> 2; c.axis = (int) (seg & 3u);
+	const XNodeDev &nd = nodes[c.node];
+	const uint32_t h = H[i] - 1u, s0 = segStart[seg];
+	const uint32_t Eh = h ? E[h - 1] : 0u, Ph = h ? P[h - 1] : 0u, Sh = h ? S[h - 1] : 0u;
+	const uint32_t Es = s0 ? E[s0 - 1] : 0u, Ps = s0 ? P[s0 - 1] : 0u, Ss = s0 ? S[s0 - 1] : 0u;
+	const uint32_t numPlanar = P[i] - Ph;
+	const uint32_t nL = (Sh - Ss) + (Ph - Ps);                     // starts and planars of the groups in front
+	const uint32_t nR = nd.primCount - ((P[i] - Ps) + (E[i] - Es)); // minus planars and ends up to and including this group
+	// the position is that of the group's first event (ev->pos), taken from the box: the key has lost the sign of zero
+	const XInst &hx = inst[vals[h]];
+	const uint32_t htype = (uint32_t) (keys[h] & 3ull);
+	const float pos = htype == kEnd ? hx.mx[c.axis] : hx.mn[c.axis];
+	c.pos = pos;
+	const float nmn = nd.mn[c.axis], nmx = nd.mx[c.axis];
+	if (!(pos > nmn && pos < nmx)) return c;
+	// SurfaceAreaHeuristic (sahkdtree3.h:35-79)
+	const float e0 = nd.mx[0] - nd.mn[0], e1 = nd.mx[1] - nd.mn[1], e2 = nd.mx[2] - nd.mn[2];
+	const float temp = 1.0f / (e0 * e1 + e1 * e2 + e0 * e2);
+	const float t0 = (c.axis == 0 ? (e1 * e2) : c.axis == 1 ? (e0 * e2) : (e0 * e1)) * temp;
+	const float t1 = (c.axis == 0 ? (e1 + e2) : c.axis == 1 ? (e0 + e2) : (e0 + e1)) * temp;
+	const float pl = t0 + t1 * (pos - nmn), pr = t0 + t1 * (nmx - pos);
+	const float nLF = (float) nL, nRF = (float) nR;
+	if (numPlanar == 0) {
+		float cost = prm.traversalCost + prm.queryCost * (pl * nLF + pr * nRF);
+		if (nL == 0 || nR == 0) cost *= prm.emptySpaceBonus;
+		c.cost = cost; c.numLeft = nL; c.numRight = nR; c.planarLeft = 0;
+	} else {
+		float costPlanarLeft = prm.traversalCost + prm.queryCost * (pl * (float) (nL + numPlanar) + pr * nRF);
+		float costPlanarRight = prm.traversalCost + prm.queryCost * (pl * nLF + pr * (float) (nR + numPlanar));
+		if (nL + numPlanar == 0 || nR == 0) costPlanarLeft *= prm.emptySpaceBonus;
+		if (nL == 0 || nR + numPlanar == 0) costPlanarRight *= prm.emptySpaceBonus;
+		if (costPlanarLeft < costPlanarRight) { c.cost = costPlanarLeft; c.numLeft = nL + numPlanar; c.numRight = nR; c.planarLeft = 1; }
+		else { c.cost = costPlanarRight; c.numLeft = nL; c.numRight = nR + numPlanar; c.planarLeft = 0; }
+	}
+	c.valid = c.cost == c.cost;       // a NaN cost never wins "cost < best.cost"
+	return c;
+}
+__global__ void k_x_cost(const unsigned long long *keys, const uint32_t *vals, uint32_t n, const uint32_t *E, const uint32_t *P, const uint32_t *S,
+                         const uint32_t *H, const uint32_t *segStart, const XInst *inst, const XNodeDev *nodes, XParams prm,
+                         unsigned long long *nodeBest) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const unsigned long long k = keys[i];
+	if (k == kXInvalid) return;
+	const unsigned long long next = (i + 1 < n) ? keys[i + 1] : kXInvalid;
+	if (next != kXInvalid && (next >> 2) == (k >> 2)) return;          // not the last event of its group
+	const XCand c = xCandidate(i, keys, vals, E, P, S, H, segStart, inst, nodes, prm);
+	if (!c.valid) return;
+	atomicMin(&nodeBest[c.node], ((unsigned long long) xOrderable(c.cost) << 32) | (unsigned long long) i);
+}
+__global__ void k_x_best(const unsigned long long *nodeBest, uint32_t nNodes, const unsigned long long *keys, const uint32_t *vals, const uint32_t *E,
+                         const uint32_t *P, const uint32_t *S, const uint32_t *H, const uint32_t *segStart, const XInst *inst,
+                         const XNodeDev *nodes, XParams prm, XBest *out) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= nNodes) return;
+	XBest b; b.cost = INFINITY; b.pos = 0; b.axis = 0; b.numLeft = 0; b.numRight = 0; b.planarLeft = 0;
+	const unsigned long long v = nodeBest[k];
+	if (v != ~0ull) {
+		const XCand c = xCandidate((uint32_t) v, keys, vals, E, P, S, H, segStart, inst, nodes, prm);
+		b.cost = c.cost; b.pos = c.pos; b.axis = c.axis; b.numLeft = c.numLeft; b.numRight = c.numRight; b.planarLeft = c.planarLeft;
+	}
+	out[k] = b;
+}
+
+// classification wrt. the chosen plane (gkdtree.h:2053-2103) and the boxes of the straddlers inside the children
+// (perfect splits, :2140-2219)
+__global__ void k_x_classify(const XInst *inst, uint32_t n, const XNodeDev *nodes, const float *triPos, const float *genBox, int clip,
+                             uint32_t *goesL, uint32_t *goesR, uint32_t *isLeafInst, float *boxL, float *boxR, uint32_t *pruned) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const XInst x = inst[i];
+	const XNodeDev &nd = nodes[x.node];
+	uint32_t L = 0, R = 0;
+	isLeafInst[i] = nd.isLeaf;
+	if (nd.isSplit) {
+		const int a = nd.axis;
+		const float split = nd.split, mn = x.mn[a], mx = x.mx[a];
+		bool both = false;
+		if (mn == mx) {
+			if (mn < split || (mn == split && nd.planarLeft)) L = 1;
+			else if (mn > split || (mn == split && !nd.planarLeft)) R = 1;
+			else both = true;
+		} else if (mx <= split) L = 1;
+		else if (mn >= split) R = 1;
+		else both = true;
+		for (int c = 0; c < 3; ++c) { boxL[6 * (size_t) i + c] = x.mn[c]; boxL[6 * (size_t) i + 3 + c] = x.mx[c]; boxR[6 * (size_t) i + c] = x.mn[c]; boxR[6 * (size_t) i + 3 + c] = x.mx[c]; }
+		if (both) {
+			L = R = 1;
+			if (clip) {
+				float lmn[3], lmx[3], rmn[3], rmx[3], cmn[3], cmx[3];
+				for (int c = 0; c < 3; ++c) { lmn[c] = rmn[c] = nd.mn[c]; lmx[c] = rmx[c] = nd.mx[c]; }
+				lmx[a] = split; rmn[a] = split;
+				if (xClipped(triPos, genBox, x.prim, lmn, lmx, cmn, cmx) && xArea(cmn, cmx) > 0) { for (int c = 0; c < 3; ++c) { boxL[6 * (size_t) i + c] = cmn[c]; boxL[6 * (size_t) i + 3 + c] = cmx[c]; } }
+				else { L = 0; atomicAdd(&pruned[2 * x.node], 1u); }
+				if (xClipped(triPos, genBox, x.prim, rmn, rmx, cmn, cmx) && xArea(cmn, cmx) > 0) { for (int c = 0; c < 3; ++c) { boxR[6 * (size_t) i + c] = cmn[c]; boxR[6 * (size_t) i + 3 + c] = cmx[c]; } }
+				else { R = 0; atomicAdd(&pruned[2 * x.node + 1], 1u); }
+			}
+		}
+	}
+	goesL[i] = L; goesR[i] = R;
+}
+__global__ void k_x_scatter(const XInst *inst, uint32_t n, const XNodeDev *nodes, const uint32_t *goesL, const uint32_t *goesR, const uint32_t *scanL,
+                            const uint32_t *scanR, const uint32_t *isLeafInst, const uint32_t *scanLeaf, const float *boxL, const float *boxR,
+                            XInst *next, XLeafItem *leafOut) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const XInst x = inst[i];
+	const XNodeDev &nd = nodes[x.node];
+	const uint32_t b = nd.instBegin;
+	if (goesL[i]) {
+		XInst o; o.prim = x.prim; o.node = nd.childNode[0];
+		for (int c = 0; c < 3; ++c) { o.mn[c] = boxL[6 * (size_t) i + c]; o.mx[c] = boxL[6 * (size_t) i + 3 + c]; }
+		next[nd.childBase[0] + (scanL[i] - 1u - (b ? scanL[b - 1] : 0u))] = o;
+	}
+	if (goesR[i]) {
+		XInst o; o.prim = x.prim; o.node = nd.childNode[1];
+		for (int c = 0; c < 3; ++c) { o.mn[c] = boxR[6 * (size_t) i + c]; o.mx[c] = boxR[6 * (size_t) i + 3 + c]; }
+		next[nd.childBase[1] + (scanR[i] - 1u - (b ? scanR[b - 1] : 0u))] = o;
+	}
+	if (isLeafInst[i]) {
+		XLeafItem l; l.prim = x.prim; l.mn0 = x.mn[0]; l.planar = x.mn[0] == x.mx[0] ? 1u : 0u;
+		leafOut[scanLeaf[i] - 1u] = l;
+	}
+}
+
+// host view of a node of the exact phase
+struct XNode {
+	uint32_t job, depth, badRefines, primCount;
+	Box box;
+	uint32_t instBegin = 0, instCount = 0;
+	int kind = -1;                    // 0 inner, 1 leaf
+	int axis = 0; float split = 0;
+	int child[2] = { -1, -1 };
+	uint32_t pruned = 0;
+	size_t leafOffset = 0;            // its primitives in the order leafFromEvents lists them: leafStore[leafOffset ..)
+	uint32_t leafCount = 0;
+};
+
+struct XScan {
+	DevBuf<unsigned char> tmp;
+	void sum(const uint32_t *in, uint32_t *out, size_t n, hipStream_t st) {
+		size_t bytes = 0;
+		KXHIP(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<uint32_t>(), st));
+		tmp.reserve(bytes + 16);
+		KXHIP(rocprim::inclusive_scan((void *) tmp.p, bytes, in, out, n, rocprim::plus<uint32_t>(), st));
+	}
+	void max(const uint32_t *in, uint32_t *out, size_t n, hipStream_t st) {
+		size_t bytes = 0;
+		KXHIP(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::maximum<uint32_t>(), st));
+		tmp.reserve(bytes + 16);
+		KXHIP(rocprim::inclusive_scan((void *) tmp.p, bytes, in, out, n, rocprim::maximum<uint32_t>(), st));
+	}
+};
+
+// Builds the subtrees of all jobs on the current HIP device; fills job.ctx (root = node 0 of the context)
+void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_t nPrims, std::vector<std::unique_ptr<Job>> &jobs) {
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+		throw std::runtime_error("kd-tree build: the device exact phase was requested but there is no HIP device");
+	if (jobs.empty()) return;
+	hipStream_t st;
+	KXHIP(hipStreamCreate(&st));
+	struct StreamGuard { hipStream_t s; ~StreamGuard() { (void) hipStreamDestroy(s); } } guard{ st };
+	const int B = 256;
+	auto grid = [&](size_t n) { return dim3((unsigned) ((n + B - 1) / B)); };
+	const XParams prm{ p.traversalCost, p.queryCost, p.emptySpaceBonus, p.clip ? 1 : 0 };
+	const bool timing = std::getenv("MTSGPU_KDTIMING") != nullptr;
+	double tm[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };      // setup, sweep (device), decisions, classify, children, scatter + leaves, replay
+	auto now = []() { return std::chrono::steady_clock::now(); };
+	auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+	auto tPhase = now();
+	int nLevels = 0;
+
+	// geometry: nine floats per triangle (NaN marks a non-triangle primitive, whose box is in genBox)
+	DevBuf<float> dTri, dGen;
+	{
+		std::unique_ptr<float[]> tpBuf(new float[9 * (size_t) nPrims]);
+		float *tp = tpBuf.get();
+		std::atomic<bool> anyGenA(false);
+		{
+			const int T = std::max(1, std::min<int>(16, (int) std::thread::hardware_concurrency()));
+			std::vector<std::thread> pool;
+			for (int t = 0; t < T; ++t) pool.emplace_back([&, t]() {
+				for (uint32_t i = (uint32_t) ((uint64_t) nPrims * t / T); i < (uint32_t) ((uint64_t) nPrims * (t + 1) / T); ++i) {
+					const uint32_t *tr = g.tri + 3 * (size_t) i;
+					if (tr[0] == MTSGPU_KNOTRIANGLE) { for (int q = 0; q < 9; ++q) tp[9 * (size_t) i + q] = std::numeric_limits<float>::quiet_NaN(); anyGenA = true; continue; }
+					for (int v = 0; v < 3; ++v) std::memcpy(&tp[9 * (size_t) i + 3 * v], g.vtx + 3 * (size_t) tr[v], 12);
+				}
+			});
+			for (auto &th : pool) th.join();
+		}
+		const bool anyGen = anyGenA;
+		dTri.reserve(9 * (size_t) nPrims);
+		KXHIP(hipMemcpyAsync(dTri.p, tp, 9 * (size_t) nPrims * sizeof(float), hipMemcpyHostToDevice, st));
+		dGen.reserve(anyGen ? 6 * (size_t) nPrims : 6);
+		if (anyGen) KXHIP(hipMemcpyAsync(dGen.p, g.genBox, 6 * (size_t) nPrims * sizeof(float), hipMemcpyHostToDevice, st));
+		KXHIP(hipStreamSynchronize(st));
+	}
+
+	std::vector<XNode> all;                       // every node of every job, in creation order
+	std::vector<uint32_t> active;                 // the nodes of the current level (indices into `all`)
+	std::vector<uint32_t> jobRoot(jobs.size());
+	size_t nInit = 0;
+	for (size_t j = 0; j < jobs.size(); ++j) {
+		XNode n; n.job = (uint32_t) j; n.depth = jobs[j]->depth; n.badRefines = jobs[j]->badRefines; n.box = jobs[j]->nodeBox;
+		n.primCount = 0; n.instBegin = (uint32_t) nInit; n.instCount = (uint32_t) jobs[j]->prims.size();
+		nInit += jobs[j]->prims.size();
+		jobRoot[j] = (uint32_t) all.size(); active.push_back((uint32_t) all.size()); all.push_back(std::move(n));
+	}
+	if (active.size() > kXMaxNodes) throw std::runtime_error("kd-tree build (device exact phase): too many subtrees");
+	all.reserve(jobs.size() + nInit + nInit / 4);      // about 0.55 nodes per primitive in practice; untouched pages cost nothing
+
+	DevBuf<XInst> dInstA, dInstB;
+	DevBuf<XNodeDev> dNodes;
+	DevBuf<uint32_t> dU[12];
+	DevBuf<unsigned long long> dKeysA, dKeysB, dNodeBest;
+	DevBuf<uint32_t> dValsA, dValsB, dSegStart, dPruned, dCounts;
+	DevBuf<float> dBoxL, dBoxR;
+	DevBuf<XBest> dBest;
+	DevBuf<XLeafItem> dLeaf;
+	DevBuf<unsigned char> dSortTmp;
+	XScan scan;
+	std::vector<XNodeDev> hNodes;
+	auto uploadNodes = [&]() {
+		dNodes.reserve(hNodes.size());
+		KXHIP(hipMemcpyAsync(dNodes.p, hNodes.data(), hNodes.size() * sizeof(XNodeDev), hipMemcpyHostToDevice, st));
+	};
+	auto fillDev = [&](XNodeDev &d, const XNode &n) {
+		std::memset(&d, 0, sizeof(d));
+		for (int a = 0; a < 3; ++a) { d.mn[a] = n.box.mn[a]; d.mx[a] = n.box.mx[a]; }
+		d.primCount = n.primCount; d.instBegin = n.instBegin; d.instCount = n.instCount;
+	};
+	// per-node counts of up to three flag arrays (inclusive scans given; the device node table holds the ranges) -> host
+	auto rangeCounts = [&](const uint32_t *s0, const uint32_t *s1, const uint32_t *s2, std::vector<uint32_t> &out) {
+		const size_t nA = active.size();
+		dCounts.reserve(3 * nA);
+		hipLaunchKernelGGL(k_x_range_counts, grid(nA), dim3(B), 0, st, s0, s1, s2, dNodes.p, (uint32_t) nA, dCounts.p);
+		out.resize(3 * nA);
+		KXHIP(hipMemcpyAsync(out.data(), dCounts.p, 3 * nA * 4, hipMemcpyDeviceToHost, st));
+	};
+	std::vector<uint32_t> leafStore;              // the primitive lists of all leaves
+	const int nThreads = std::max(1, std::min<int>(16, (int) std::thread::hardware_concurrency()));
+	auto parallelFor = [&](size_t n, const std::function<void(size_t, size_t)> &fn) {
+		const int T = (int) std::min<size_t>((size_t) nThreads, std::max<size_t>(1, n / 4096));
+		if (T <= 1) { fn(0, n); return; }
+		std::vector<std::thread> pool;
+		for (int t = 0; t < T; ++t) pool.emplace_back([&, t]() { fn(n * t / T, n * (t + 1) / T); });
+		for (auto &th : pool) th.join();
+	};
+
+	// ---- level 0: the instances of the jobs' primitive lists, clipped to the jobs' boxes ----
+	size_t nInst = 0;
+	{
+		std::vector<uint32_t> hp(nInit), hn(nInit);
+		size_t o = 0;
+		for (size_t j = 0; j < jobs.size(); ++j)
+			for (uint32_t prim : jobs[j]->prims) { hp[o] = prim; hn[o] = (uint32_t) j; ++o; }
+		hNodes.resize(active.size());
+		for (size_t k = 0; k < active.size(); ++k) fillDev(hNodes[k], all[active[k]]);
+		uploadNodes();
+		dU[0].reserve(nInit + 1); dU[1].reserve(nInit + 1); dU[2].reserve(nInit + 1); dU[3].reserve(nInit + 1);
+		dInstA.reserve(nInit + 1); dInstB.reserve(nInit + 1);
+		KXHIP(hipMemcpyAsync(dU[0].p, hp.data(), nInit * 4, hipMemcpyHostToDevice, st));
+		KXHIP(hipMemcpyAsync(dU[1].p, hn.data(), nInit * 4, hipMemcpyHostToDevice, st));
+		if (nInit) {
+			hipLaunchKernelGGL(k_x_init, grid(nInit), dim3(B), 0, st, dTri.p, dGen.p, dU[0].p, dU[1].p, (uint32_t) nInit, dNodes.p, prm.clip, dInstB.p, dU[2].p);
+			scan.sum(dU[2].p, dU[3].p, nInit, st);
+			hipLaunchKernelGGL(k_x_compact, grid(nInit), dim3(B), 0, st, dInstB.p, dU[2].p, dU[3].p, (uint32_t) nInit, dInstA.p);
+		}
+		std::vector<uint32_t> kept;
+		rangeCounts(dU[3].p, nullptr, nullptr, kept);
+		KXHIP(hipStreamSynchronize(st));
+		for (size_t k = 0; k < active.size(); ++k) {
+			XNode &n = all[active[k]];
+			n.instBegin = (uint32_t) nInst; n.instCount = kept[k]; n.primCount = kept[k];
+			nInst += kept[k];
+		}
+	}
+
+	tm[0] = since(tPhase);
+	// ---- the levels ----
+	while (!active.empty()) {
+		++nLevels;
+		tPhase = now();
+		const size_t nA = active.size();
+		if (nA > kXMaxNodes) throw std::runtime_error("kd-tree build (device exact phase): more than 2^22 nodes in one level");
+		hNodes.resize(nA);
+		if (all.capacity() < all.size() + 2 * nA) all.reserve(std::max(all.size() + 2 * nA, 2 * all.capacity()));      // (rare: see the reserve above)
+		bool anySweep = false;
+		for (size_t k = 0; k < nA; ++k) {
+			XNode &n = all[active[k]];
+			fillDev(hNodes[k], n);
+			const bool preLeaf = n.primCount <= p.stopPrims || n.depth >= p.maxDepth;          // gkdtree.h:1903-1906
+			hNodes[k].sweep = preLeaf ? 0u : 1u;
+			if (preLeaf) { n.kind = 1; hNodes[k].isLeaf = 1; } else anySweep = true;
+		}
+		std::vector<XBest> best(nA);
+		const size_t nEv = 6 * nInst;
+		if (anySweep && nInst) {
+			uploadNodes();
+			dKeysA.reserve(nEv); dKeysB.reserve(nEv); dValsA.reserve(nEv); dValsB.reserve(nEv);
+			for (int k = 4; k < 12; ++k) dU[k].reserve(nEv + 1);
+			dSegStart.reserve(4 * nA); dNodeBest.reserve(nA); dBest.reserve(nA);
+			hipLaunchKernelGGL(k_x_emit, grid(nInst), dim3(B), 0, st, dInstA.p, (uint32_t) nInst, dNodes.p, dKeysA.p, dValsA.p);
+			const bool detail = timing && std::getenv("MTSGPU_KDTIMING")[0] == '2';
+			auto tSort = now();
+			if (detail) KXHIP(hipStreamSynchronize(st));
+			{
+				size_t bytes = 0;
+				// node | axis | position | type: 34 + 2 + the bits the node ids of this level need (unused events are all ones)
+				unsigned endBit = 36;
+				while (endBit < 58 && (nA - 1) >> (endBit - 36)) ++endBit;
+				endBit = std::min(58u, endBit + 1);      // one more so that the all-ones key of an unused slot sorts last
+				KXHIP(rocprim::radix_sort_pairs(nullptr, bytes, dKeysA.p, dKeysB.p, dValsA.p, dValsB.p, nEv, 0u, endBit, st));
+				dSortTmp.reserve(bytes + 16);
+				KXHIP(rocprim::radix_sort_pairs((void *) dSortTmp.p, bytes, dKeysA.p, dKeysB.p, dValsA.p, dValsB.p, nEv, 0u, endBit, st));
+			}
+			if (detail) { KXHIP(hipStreamSynchronize(st)); tm[7] += since(tSort); }
+			uint32_t *cE = dU[4].p, *cP = dU[5].p, *cS = dU[6].p, *hd = dU[7].p, *sE = dU[8].p, *sP = dU[9].p, *sS = dU[10].p, *sH = dU[11].p;
+			KXHIP(hipMemsetAsync(dSegStart.p, 0, 4 * nA * sizeof(uint32_t), st));
+			KXHIP(hipMemsetAsync(dNodeBest.p, 0xFF, nA * sizeof(unsigned long long), st));
+			hipLaunchKernelGGL(k_x_flags, grid(nEv), dim3(B), 0, st, dKeysB.p, (uint32_t) nEv, cE, cP, cS, hd, dSegStart.p);
+			scan.sum(cE, sE, nEv, st); scan.sum(cP, sP, nEv, st); scan.sum(cS, sS, nEv, st); scan.max(hd, sH, nEv, st);
+			hipLaunchKernelGGL(k_x_cost, grid(nEv), dim3(B), 0, st, dKeysB.p, dValsB.p, (uint32_t) nEv, sE, sP, sS, sH, dSegStart.p, dInstA.p, dNodes.p, prm, dNodeBest.p);
+			hipLaunchKernelGGL(k_x_best, grid(nA), dim3(B), 0, st, dNodeBest.p, (uint32_t) nA, dKeysB.p, dValsB.p, sE, sP, sS, sH, dSegStart.p, dInstA.p, dNodes.p, prm, dBest.p);
+			KXHIP(hipMemcpyAsync(best.data(), dBest.p, nA * sizeof(XBest), hipMemcpyDeviceToHost, st));
+			KXHIP(hipStreamSynchronize(st));
+		}
+		tm[1] += since(tPhase); tPhase = now();
+		// the decisions of gkdtree.h:2023-2051 on the host
+		std::vector<Split> chosen(nA);
+		for (size_t k = 0; k < nA; ++k) {
+			XNode &n = all[active[k]];
+			if (n.kind == 1) continue;
+			Split s; s.cost = best[k].cost; s.pos = best[k].pos; s.axis = best[k].axis; s.numLeft = best[k].numLeft; s.numRight = best[k].numRight; s.planarLeft = best[k].planarLeft != 0;
+			const float leafCost = n.primCount * p.queryCost;
+			bool leaf = false;
+			if (s.cost >= leafCost) {
+				if ((s.cost > 4 * leafCost && n.primCount < 16) || n.badRefines >= p.maxBadRefines || s.cost == kInf) leaf = true;
+				else ++n.badRefines;
+			}
+			if (leaf) { n.kind = 1; hNodes[k].isLeaf = 1; }
+			else { n.kind = 0; n.axis = s.axis; n.split = s.pos; hNodes[k].isSplit = 1; hNodes[k].axis = s.axis; hNodes[k].split = s.pos; hNodes[k].planarLeft = s.planarLeft ? 1u : 0u; }
+			chosen[k] = s;
+		}
+		tm[2] += since(tPhase); tPhase = now();
+		// classification, clipping, counts
+		std::vector<uint32_t> cnt3, hPruned(2 * nA, 0u);
+		size_t nNext = 0, nLeafItems = 0;
+		std::vector<uint32_t> nextActive;
+		if (nInst) {
+			uploadNodes();
+			for (int k = 0; k < 6; ++k) dU[k].reserve(nInst + 1);
+			dBoxL.reserve(6 * nInst); dBoxR.reserve(6 * nInst); dPruned.reserve(2 * nA);
+			KXHIP(hipMemsetAsync(dPruned.p, 0, 2 * nA * sizeof(uint32_t), st));
+			uint32_t *gL = dU[0].p, *gR = dU[1].p, *lf = dU[2].p, *sL = dU[3].p, *sR = dU[4].p, *sLf = dU[5].p;
+			hipLaunchKernelGGL(k_x_classify, grid(nInst), dim3(B), 0, st, dInstA.p, (uint32_t) nInst, dNodes.p, dTri.p, dGen.p, prm.clip, gL, gR, lf, dBoxL.p, dBoxR.p, dPruned.p);
+			scan.sum(gL, sL, nInst, st); scan.sum(gR, sR, nInst, st); scan.sum(lf, sLf, nInst, st);
+			rangeCounts(sL, sR, sLf, cnt3);
+			KXHIP(hipMemcpyAsync(hPruned.data(), dPruned.p, 2 * nA * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+			KXHIP(hipStreamSynchronize(st));
+		} else {
+			cnt3.assign(3 * nA, 0u);
+		}
+		const uint32_t *cntL = cnt3.data(), *cntR = cnt3.data() + nA, *cntLeaf = cnt3.data() + 2 * nA;
+		tm[3] += since(tPhase); tPhase = now();
+		// children (left, then right, in node order) and where their instances go
+		for (size_t k = 0; k < nA; ++k) {
+			const uint32_t id = active[k];
+			if (all[id].kind != 0) { nLeafItems += cntLeaf[k]; continue; }
+			const Split &s = chosen[k];
+			all[id].pruned = hPruned[2 * k] + hPruned[2 * k + 1];
+			for (int side = 0; side < 2; ++side) {
+				XNode c; c.job = all[id].job; c.depth = all[id].depth + 1; c.badRefines = all[id].badRefines;
+				c.box = all[id].box;
+				if (side == 0) c.box.mx[s.axis] = s.pos; else c.box.mn[s.axis] = s.pos;
+				c.primCount = (side == 0 ? s.numLeft : s.numRight) - hPruned[2 * k + side];
+				c.instCount = side == 0 ? cntL[k] : cntR[k];
+				c.instBegin = (uint32_t) nNext; nNext += c.instCount;
+				hNodes[k].childBase[side] = c.instBegin; hNodes[k].childNode[side] = (uint32_t) nextActive.size();
+				all[id].child[side] = (int) all.size();
+				nextActive.push_back((uint32_t) all.size());
+				all.push_back(std::move(c));
+			}
+		}
+		tm[4] += since(tPhase); tPhase = now();
+		if (nInst) {
+			uploadNodes();
+			dInstB.reserve(nNext + 1); dLeaf.reserve(nLeafItems + 1);
+			hipLaunchKernelGGL(k_x_scatter, grid(nInst), dim3(B), 0, st, dInstA.p, (uint32_t) nInst, dNodes.p, dU[0].p, dU[1].p, dU[3].p, dU[4].p, dU[2].p, dU[5].p,
+			                   dBoxL.p, dBoxR.p, dInstB.p, dLeaf.p);
+			std::vector<XLeafItem> items(nLeafItems);
+			if (nLeafItems) KXHIP(hipMemcpyAsync(items.data(), dLeaf.p, nLeafItems * sizeof(XLeafItem), hipMemcpyDeviceToHost, st));
+			KXHIP(hipStreamSynchronize(st));
+			// leafFromEvents: the axis-0 start / planar events in EventLess order
+			const size_t storeBase = leafStore.size();
+			leafStore.resize(storeBase + nLeafItems);
+			size_t o = 0;
+			for (size_t k = 0; k < nA; ++k) {
+				XNode &n = all[active[k]];
+				if (n.kind != 1) continue;
+				n.leafOffset = storeBase + o; n.leafCount = cntLeaf[k];
+				o += cntLeaf[k];
+			}
+			parallelFor(nA, [&](size_t lo, size_t hi) {
+				for (size_t k = lo; k < hi; ++k) {
+					const XNode &n = all[active[k]];
+					if (n.kind != 1) continue;
+					XLeafItem *first = items.data() + (n.leafOffset - storeBase), *last = first + n.leafCount;
+					std::sort(first, last, [](const XLeafItem &x, const XLeafItem &y) {
+						if (x.mn0 != y.mn0) return x.mn0 < y.mn0;
+						const uint32_t tx = x.planar ? kPlanar : kStart, ty = y.planar ? kPlanar : kStart;
+						if (tx != ty) return tx < ty;
+						return x.prim < y.prim;
+					});
+					for (uint32_t q = 0; q < n.leafCount; ++q) leafStore[n.leafOffset + q] = first[q].prim;
+				}
+			});
+		}
+		std::swap(dInstA.p, dInstB.p); std::swap(dInstA.cap, dInstB.cap);
+		nInst = nNext;
+		active.swap(nextActive);
+		tm[5] += since(tPhase);
+	}
+	tPhase = now();
+
+	// ---- replay: the bookkeeping of buildTree per job, depth first (nodes, indices, counters, retraction) ----
+	struct Emit {
+		const Builder &b; const Params &p; std::vector<XNode> &all; const std::vector<uint32_t> &leafStore;
+		float run(Context &c, uint32_t id, uint32_t node) {
+			XNode &n = all[id];
+			const float leafCost = n.primCount * p.queryCost;
+			if (n.kind == 1) {
+				PNode &pn = c.nodes[node];
+				pn.kind = 1; pn.a = (uint32_t) c.indices.size(); pn.b = pn.a + n.primCount;
+				if (n.primCount > 0) {
+					c.nonemptyLeafCount++;
+					c.indices.insert(c.indices.end(), leafStore.begin() + (ptrdiff_t) n.leafOffset, leafStore.begin() + (ptrdiff_t) (n.leafOffset + n.leafCount));
+					c.primIndexCount += n.primCount;
+				}
+				c.leafCount++;
+				return leafCost;
+			}
+			c.pruned += n.pruned;
+			const uint32_t children = c.allocNodes(2);
+			const uint32_t nodePosBefore = (uint32_t) c.nodes.size(), indexPosBefore = (uint32_t) c.indices.size();
+			const uint32_t leafBefore = c.leafCount, nonemptyBefore = c.nonemptyLeafCount, innerBefore = c.innerCount;
+			{ PNode &pn = c.nodes[node]; pn.kind = 0; pn.a = (uint32_t) n.axis; pn.b = children; pn.split = n.split; }
+			c.innerCount++;
+			const float leftCost = run(c, (uint32_t) n.child[0], children);
+			const float rightCost = run(c, (uint32_t) n.child[1], children + 1);
+			const XNode &m = all[id];
+			const SAH tch(m.box);
+			float pl, pr;
+			tch(m.axis, m.split - m.box.mn[m.axis], m.box.mx[m.axis] - m.split, pl, pr);
+			const float finalCost = p.traversalCost + (pl * leftCost + pr * rightCost);
+			if (!p.retract || finalCost < m.primCount * p.queryCost)
+				return finalCost;
+			c.nodes.resize(nodePosBefore);
+			c.retracted++;
+			c.leafCount = leafBefore; c.nonemptyLeafCount = nonemptyBefore; c.innerCount = innerBefore;
+			b.leafAfterRetraction(c, node, indexPosBefore);
+			return leafCost;
+		}
+	} emit{ b, p, all, leafStore };
+	{
+		std::atomic<size_t> nextJob(0);
+		std::exception_ptr firstError;       // an exception must not leave a std::thread (see runJobs)
+		std::mutex errorLock;
+		auto worker = [&]() {
+			try {
+				for (;;) {
+					const size_t j = nextJob.fetch_add(1);
+					if (j >= jobs.size()) break;
+					Job &job = *jobs[j];
+					job.root = job.ctx.allocNodes(1);
+					emit.run(job.ctx, jobRoot[j], job.root);
+					std::vector<uint32_t>().swap(job.prims);
+				}
+			} catch (...) {
+				std::lock_guard<std::mutex> guard(errorLock);
+				if (!firstError) firstError = std::current_exception();
+				nextJob.store(jobs.size());
+			}
+		};
+		const int T = (int) std::min<size_t>((size_t) nThreads, jobs.size());
+		std::vector<std::thread> pool;
+		for (int t = 1; t < T; ++t) pool.emplace_back(worker);
+		worker();
+		for (auto &th : pool) th.join();
+		if (firstError) std::rethrow_exception(firstError);
+	}
+	tm[6] = since(tPhase);
+	if (timing)
+		std::fprintf(stderr, "[kdbuild] device exact phase: %d levels, %zu nodes; setup %.1f, sweep %.1f, decisions %.1f, classify %.1f, children %.1f, scatter + leaves %.1f, replay %.1f ms (sort alone %.1f)\n",
+		             nLevels, all.size(), tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7]);
+}
+
 int log2i(uint32_t v) { int r = 0; while (v >>= 1) r++; return r; }
 
 } // namespace
@@ -988,7 +1649,9 @@ void buildKdTree(const float *vtx, const uint32_t *tri, uint32_t nTris, const fl
 
 	const Geometry g{ vtx, tri, genBox };
 	Builder b(g, p, nTris);
-	b.m_parallel = nTris > p.exactPrimThreshold;
+	// gpu_binning is a bit set: 1 = min-max binning phase on the device, 2 = exact phase on the device
+	const bool exactOnDev = kp && (kp->gpu_binning & 2) != 0;
+	b.m_parallel = nTris > p.exactPrimThreshold || exactOnDev;      // the device builds the exact subtrees as jobs
 	Box scene; scene.reset();
 	std::vector<uint32_t> prims(nTris);
 	for (uint32_t i = 0; i < nTris; ++i) { Box t; g.box(i, t); scene.expand(t); prims[i] = i; }
@@ -997,7 +1660,7 @@ void buildKdTree(const float *vtx, const uint32_t *tri, uint32_t nTris, const fl
 	const uint32_t prelimRoot = root.allocNodes(1);
 	const bool timing = std::getenv("MTSGPU_KDTIMING") != nullptr;
 	const auto t0 = std::chrono::steady_clock::now();
-	const bool onDevice = kp && kp->gpu_binning > 0 && b.m_parallel;
+	const bool onDevice = kp && (kp->gpu_binning & 1) != 0 && nTris > p.exactPrimThreshold;
 	if (onDevice) {
 		Plan plan;
 		std::vector<uint32_t>().swap(prims);
@@ -1007,7 +1670,8 @@ void buildKdTree(const float *vtx, const uint32_t *tri, uint32_t nTris, const fl
 		b.binned(root, 1, prelimRoot, scene, scene, prims, 0);
 	}
 	const auto t1 = std::chrono::steady_clock::now();
-	b.runJobs(nThreads);
+	if (exactOnDev) exactOnDevice(b, p, g, nTris, b.m_jobs);
+	else b.runJobs(nThreads);
 	const auto t2 = std::chrono::steady_clock::now();
 	if (timing) {
 		double mx = 0, sum = 0;

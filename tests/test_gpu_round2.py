@@ -331,3 +331,47 @@ def test_malformed_trees_are_refused(gpu_lib, mts):
     assert b"deeper than" in L.mtsgpu_last_error(it._ctx)
     # the intact scene still uploads
     assert L.mtsgpu_upload_scene(it._ctx, sc.ptr) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["c1", "c5_threshold_300", "spheres", "c3_grid60", "c3_grid60_noclip", "c3_grid60_noretract",
+                                  "bunny", "fuzz", "c3_1M"])
+def test_device_exact_phase_builds_the_same_tree(gpu_lib, mts, orc, case):
+    """the exact O(n log n) sweep of the kd-tree build (gkdtree.h:1898-2345: event lists, SAH sweep, classification,
+    perfect splits, bad refines, retraction) run level by level on the device yields the host builder's tree bit for
+    bit -- nodes, index lists, statistics, bounding box -- with and without the device binning phase above it, and
+    therefore the oracle's tree"""
+    from test_gpu_parity import _bunny_serialized, _loader
+    def params(**kw):
+        k = mts.abi.KdParams()
+        for a, b in kw.items():
+            setattr(k, a, b)
+        return k
+    kw, sds = {}, []
+    if case == "c1":
+        sds = [mts.scenes.cornell_c1()]
+    elif case == "c5_threshold_300":
+        sds = [mts.scenes.cornell_c5(sphere_subdiv=3)]; kw = dict(exact_prim_threshold=300)
+    elif case == "spheres":
+        sds = [mts.scenes.spheres()]
+    elif case.startswith("c3_grid60"):
+        sds = [mts.scenes.cornell_c3(grid=60, sphere_subdiv=3)]
+        kw = dict(clip=-1) if case.endswith("noclip") else dict(retract=-1) if case.endswith("noretract") else {}
+    elif case == "bunny":
+        sds = [mts.scenes.bunny(_bunny_serialized(), _loader())]; kw = dict(exact_prim_threshold=20000)
+    elif case == "fuzz":
+        sds = [mts.scenes.fuzz(seed) for seed in range(8)]
+    else:
+        sds = [mts.scenes.cornell_c3()]
+    for sd in sds:
+        host = mts.Scene(sd, kd_params=params(**kw))
+        ha = host.arrays()
+        for binning in (False, True):
+            dev = mts.Scene(sd, kd_params=params(**kw), gpu_binning=binning, gpu_exact=True)
+            da = dev.arrays()
+            for k in ("kd_nodes", "kd_indices", "aabb_min", "aabb_max", "triaccel"):
+                assert np.array_equal(ha[k].view(np.uint32), da[k].view(np.uint32)), (case, k, binning)
+            assert host.kdstats() == dev.kdstats()
+        if case != "c3_1M":                                                 # the oracle's own builder, same parameters
+            oa = orc.FlatScene(sd, kd_params=params(**kw)).arrays()
+            assert np.array_equal(oa["kd_nodes"], ha["kd_nodes"]) and np.array_equal(oa["kd_indices"], ha["kd_indices"])

@@ -42,6 +42,10 @@ def test_no_gpu_means_a_loud_error_not_a_fallback(mts):
     with pytest.raises(mts.MtsGpuError) as e:
         mts.Scene(mts.scenes.cornell_c5(sphere_subdiv=2), kd_params=kp, gpu_binning=True)
     assert "no HIP device" in str(e.value)
+    # ... nor does the device exact phase
+    with pytest.raises(mts.MtsGpuError) as e:
+        mts.Scene(mts.scenes.cornell_c1(), gpu_exact=True)
+    assert "no HIP device" in str(e.value)
 
 
 @pytest.mark.parametrize("maker", [
