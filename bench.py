@@ -186,7 +186,7 @@ def main():
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1spp", action="store_true", help="skip the time-to-1spp frames")
-    ap.add_argument("--host-kd", action="store_true", help="kd-tree binning phase on the host instead of the GPU (same tree)")
+    ap.add_argument("--host-kd", action="store_true", help="kd-tree build (binning and exact phase) on the host instead of the GPU (same tree)")
     ap.add_argument("--devices", default="", help="comma list: HIP device of each local rank (default: LOCAL_RANK). "
                     "Ranks sharing a device reduce their films through gloo on host copies (test mode)")
     ap.add_argument("--dump-film", default="", help="rank 0 writes the reduced film of the last step to this .npy file")
@@ -225,7 +225,7 @@ def main():
     # --- scene (host side: generate, flatten, upload; not timed) ---
     sd = pkg.scenes.cornell_c3(grid=args.grid, sphere_subdiv=5)
     t0 = time.time()
-    scene = pkg.Scene(sd, None, gpu_binning=not args.host_kd)
+    scene = pkg.Scene(sd, None, gpu_binning=not args.host_kd, gpu_exact=not args.host_kd)
     flatten_s = time.time() - t0
     W = H = args.res
     strong = args.spp_total > 0

@@ -997,22 +997,30 @@ void planOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_t
 // host replays the nodes depth first with the bookkeeping of buildTree (cost of the subtree, retraction :2327-2341,
 // counters) into the Context of every job, so everything downstream -- and the tree -- is what runExact produces.
 // ---------------------------------------------------------------------------------------------------------------
-struct XInst { uint32_t prim; float mn[3], mx[3]; uint32_t node; };        // 32 B
-struct XNodeDev {
+struct XInst { uint32_t prim; float mn[3], mx[3]; uint32_t node; };        // 32 B; node = index inside its level
+// A node of the exact phase, resident on the device.  The nodes of one level are contiguous, the children of a level's
+// split nodes form the next level (left, right, in node order).
+struct XNodeG {
 	float mn[3], mx[3];              // the node's box
 	uint32_t primCount;              // what the sweep counts numRight down from
-	uint32_t instBegin, instCount;
-	uint32_t sweep;                  // 0: a leaf before any sweep (stopPrims / maxDepth): no events
-	uint32_t isSplit, isLeaf;        // the host's decision
+	uint32_t instBegin, instCount;   // its instances in the level's instance array
+	uint32_t depth, badRefines;
+	uint32_t sweep, isSplit, isLeaf;
 	int32_t axis; float split; uint32_t planarLeft;
-	uint32_t childBase[2], childNode[2];
+	uint32_t numLeft, numRight;      // of the chosen plane (gkdtree.h:1950-2016)
+	uint32_t child;                  // global index of the left child (the right one follows)
+	uint32_t childBase[2];           // where the children's instances start in the next level's array
+	uint32_t pruned[2];              // straddlers whose clipped box in the left / right child is empty
+	uint32_t leafOffset;             // a leaf's primitives in the leaf item buffer
+	float cost; uint32_t retract;    // filled bottom-up when all levels are done
 };
-struct XBest { float cost, pos; int32_t axis; uint32_t numLeft, numRight, planarLeft; };
-struct XLeafItem { uint32_t prim; float mn0; uint32_t planar; };
-struct XParams { float traversalCost, queryCost, emptySpaceBonus; int clip; };
+// what the host needs of a node for the replay
+struct XNodeH { uint32_t primCount; int32_t kind; int32_t axis; float split; uint32_t child, pruned, leafOffset, leafCount, retract; };
+struct XTotals { uint32_t nSplit, nNextInst, nLeafItems, pad; };
+struct XParams { float traversalCost, queryCost, emptySpaceBonus; int clip; uint32_t stopPrims, maxDepth, maxBadRefines; int retract; };
 
 constexpr uint64_t kXInvalid = ~0ull;
-constexpr uint32_t kXMaxNodes = 1u << 22;
+constexpr uint32_t kXMaxNodes = 1u << 22;       // nodes per level (22 bits of the event key)
 
 #define KXHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string("kd-tree build (device exact phase): ") + hipGetErrorString(e_)); } while (0)
 
@@ -1056,11 +1064,11 @@ __device__ inline float xArea(const float *mn, const float *mx) {
 // transitionToNLogN (gkdtree.h:1668-1704): the instances of the jobs' primitives; keep[i] = 0 drops a primitive whose
 // clipped box is empty or has no area
 __global__ void k_x_init(const float *triPos, const float *genBox, const uint32_t *prims, const uint32_t *primNode, uint32_t n,
-                         const XNodeDev *nodes, int clip, XInst *out, uint32_t *keep) {
+                         const XNodeG *nodes, int clip, XInst *out, uint32_t *keep) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	XInst x; x.prim = prims[i]; x.node = primNode[i];
-	const XNodeDev &nd = nodes[x.node];
+	const XNodeG &nd = nodes[x.node];
 	bool ok = true;
 	if (clip) ok = xClipped(triPos, genBox, x.prim, nd.mn, nd.mx, x.mn, x.mx) && xArea(x.mn, x.mx) != 0;
 	else xBox(triPos, genBox, x.prim, x.mn, x.mx);
@@ -1070,19 +1078,29 @@ __global__ void k_x_compact(const XInst *in, const uint32_t *keep, const uint32_
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n && keep[i]) out[scan[i] - 1u] = in[i];
 }
-// counts of up to three flags inside the instance ranges of the nodes: out[j * n + k] = scan_j[end_k - 1] - scan_j[begin_k - 1]
-// (inclusive scans)
-__global__ void k_x_range_counts(const uint32_t *s0, const uint32_t *s1, const uint32_t *s2, const XNodeDev *nodes, uint32_t n, uint32_t *out) {
+// the roots after the compaction: their instance ranges from the inclusive scan of the keep flags
+__global__ void k_x_roots(XNodeG *nodes, uint32_t n, const uint32_t *scan, XTotals *totals) {
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= n) return;
-	const uint32_t b = nodes[k].instBegin, c = nodes[k].instCount;
-	const uint32_t *sc[3] = { s0, s1, s2 };
-	for (int j = 0; j < 3; ++j)
-		if (sc[j]) out[(size_t) j * n + k] = c ? sc[j][b + c - 1] - (b ? sc[j][b - 1] : 0u) : 0u;
+	XNodeG &nd = nodes[k];
+	const uint32_t b = nd.instBegin, c = nd.instCount;
+	const uint32_t before = b ? scan[b - 1] : 0u, kept = c ? scan[b + c - 1] - before : 0u;
+	nd.instBegin = before; nd.instCount = kept; nd.primCount = kept;
+	if (k == n - 1) { totals->nNextInst = before + kept; totals->nSplit = 0; totals->nLeafItems = 0; }
+}
+
+// the leaves that need no sweep (gkdtree.h:1903-1906)
+__global__ void k_x_prep(XNodeG *nodes, uint32_t n, XParams prm) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	XNodeG &nd = nodes[k];
+	const bool preLeaf = nd.primCount <= prm.stopPrims || nd.depth >= prm.maxDepth;
+	nd.sweep = preLeaf ? 0u : 1u; nd.isLeaf = preLeaf ? 1u : 0u; nd.isSplit = 0u;
+	nd.pruned[0] = nd.pruned[1] = 0u;
 }
 
 // createEventList: two key slots per instance and axis (a planar primitive uses one)
-__global__ void k_x_emit(const XInst *inst, uint32_t n, const XNodeDev *nodes, unsigned long long *keys, uint32_t *vals) {
+__global__ void k_x_emit(const XInst *inst, uint32_t n, const XNodeG *nodes, unsigned long long *keys, uint32_t *vals) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const XInst x = inst[i];
@@ -1117,16 +1135,17 @@ __global__ void k_x_flags(const unsigned long long *keys, uint32_t n, uint32_t *
 // the candidate plane of the group of events that ends at sorted position i (gkdtree.h:1950-2016)
 struct XCand { bool valid; float cost, pos; uint32_t numLeft, numRight, planarLeft; int axis; uint32_t node; };
 __device__ inline XCand xCandidate(uint32_t i, const unsigned long long *keys, const uint32_t *vals, const uint32_t *E, const uint32_t *P,
-                                   const uint32_t *S, const uint32_t *H, const uint32_t *segStart, const XInst *inst, const XNodeDev *nodes,
+                                   const uint32_t *S, const uint32_t *H, const uint32_t *segStart, const XInst *inst, const XNodeG *nodes,
                                    const XParams prm) {
 	XCand c; c.valid = false;
 	const unsigned long long k = keys[i];
 	const uint32_t seg = (uint32_t) (k >> 34);
 	c.node = seg >> 2; c.axis = (int) (seg & 3u);
-	const XNodeDev &nd = nodes[c.node];
+	const XNodeG &nd = nodes[c.node];
 	const uint32_t h = H[i] - 1u, s0 = segStart[seg];
 	const uint32_t Eh = h ? E[h - 1] : 0u, Ph = h ? P[h - 1] : 0u, Sh = h ? S[h - 1] : 0u;
 	const uint32_t Es = s0 ? E[s0 - 1] : 0u, Ps = s0 ? P[s0 - 1] : 0u, Ss = s0 ? S[s0 - 1] : 0u;
+	(void) Eh;
 	const uint32_t numPlanar = P[i] - Ph;
 	const uint32_t nL = (Sh - Ss) + (Ph - Ps);                     // starts and planars of the groups in front
 	const uint32_t nR = nd.primCount - ((P[i] - Ps) + (E[i] - Es)); // minus planars and ends up to and including this group
@@ -1160,7 +1179,7 @@ __device__ inline XCand xCandidate(uint32_t i, const unsigned long long *keys, c
 	return c;
 }
 __global__ void k_x_cost(const unsigned long long *keys, const uint32_t *vals, uint32_t n, const uint32_t *E, const uint32_t *P, const uint32_t *S,
-                         const uint32_t *H, const uint32_t *segStart, const XInst *inst, const XNodeDev *nodes, XParams prm,
+                         const uint32_t *H, const uint32_t *segStart, const XInst *inst, const XNodeG *nodes, XParams prm,
                          unsigned long long *nodeBest) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
@@ -1172,28 +1191,38 @@ __global__ void k_x_cost(const unsigned long long *keys, const uint32_t *vals, u
 	if (!c.valid) return;
 	atomicMin(&nodeBest[c.node], ((unsigned long long) xOrderable(c.cost) << 32) | (unsigned long long) i);
 }
-__global__ void k_x_best(const unsigned long long *nodeBest, uint32_t nNodes, const unsigned long long *keys, const uint32_t *vals, const uint32_t *E,
-                         const uint32_t *P, const uint32_t *S, const uint32_t *H, const uint32_t *segStart, const XInst *inst,
-                         const XNodeDev *nodes, XParams prm, XBest *out) {
+// what follows the sweep (gkdtree.h:2023-2051): a leaf after all, a "bad refine", or the split
+__global__ void k_x_decide(XNodeG *nodes, uint32_t nNodes, const unsigned long long *nodeBest, const unsigned long long *keys, const uint32_t *vals,
+                           const uint32_t *E, const uint32_t *P, const uint32_t *S, const uint32_t *H, const uint32_t *segStart, const XInst *inst,
+                           XParams prm) {
 	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= nNodes) return;
-	XBest b; b.cost = INFINITY; b.pos = 0; b.axis = 0; b.numLeft = 0; b.numRight = 0; b.planarLeft = 0;
+	XNodeG &nd = nodes[k];
+	if (!nd.sweep) return;
+	float cost = INFINITY, pos = 0; int axis = 0; uint32_t numLeft = 0, numRight = 0, planarLeft = 0;
 	const unsigned long long v = nodeBest[k];
 	if (v != ~0ull) {
 		const XCand c = xCandidate((uint32_t) v, keys, vals, E, P, S, H, segStart, inst, nodes, prm);
-		b.cost = c.cost; b.pos = c.pos; b.axis = c.axis; b.numLeft = c.numLeft; b.numRight = c.numRight; b.planarLeft = c.planarLeft;
+		cost = c.cost; pos = c.pos; axis = c.axis; numLeft = c.numLeft; numRight = c.numRight; planarLeft = c.planarLeft;
 	}
-	out[k] = b;
+	const float leafCost = nd.primCount * prm.queryCost;
+	bool leaf = false;
+	if (cost >= leafCost) {
+		if ((cost > 4 * leafCost && nd.primCount < 16) || nd.badRefines >= prm.maxBadRefines || cost == INFINITY) leaf = true;
+		else nd.badRefines++;
+	}
+	if (leaf) { nd.isLeaf = 1u; return; }
+	nd.isSplit = 1u; nd.axis = axis; nd.split = pos; nd.planarLeft = planarLeft; nd.numLeft = numLeft; nd.numRight = numRight;
 }
 
 // classification wrt. the chosen plane (gkdtree.h:2053-2103) and the boxes of the straddlers inside the children
 // (perfect splits, :2140-2219)
-__global__ void k_x_classify(const XInst *inst, uint32_t n, const XNodeDev *nodes, const float *triPos, const float *genBox, int clip,
-                             uint32_t *goesL, uint32_t *goesR, uint32_t *isLeafInst, float *boxL, float *boxR, uint32_t *pruned) {
+__global__ void k_x_classify(const XInst *inst, uint32_t n, XNodeG *nodes, const float *triPos, const float *genBox, int clip,
+                             uint32_t *goesL, uint32_t *goesR, uint32_t *isLeafInst, float *boxL, float *boxR) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const XInst x = inst[i];
-	const XNodeDev &nd = nodes[x.node];
+	XNodeG &nd = nodes[x.node];
 	uint32_t L = 0, R = 0;
 	isLeafInst[i] = nd.isLeaf;
 	if (nd.isSplit) {
@@ -1215,50 +1244,114 @@ __global__ void k_x_classify(const XInst *inst, uint32_t n, const XNodeDev *node
 				for (int c = 0; c < 3; ++c) { lmn[c] = rmn[c] = nd.mn[c]; lmx[c] = rmx[c] = nd.mx[c]; }
 				lmx[a] = split; rmn[a] = split;
 				if (xClipped(triPos, genBox, x.prim, lmn, lmx, cmn, cmx) && xArea(cmn, cmx) > 0) { for (int c = 0; c < 3; ++c) { boxL[6 * (size_t) i + c] = cmn[c]; boxL[6 * (size_t) i + 3 + c] = cmx[c]; } }
-				else { L = 0; atomicAdd(&pruned[2 * x.node], 1u); }
+				else { L = 0; atomicAdd(&nd.pruned[0], 1u); }
 				if (xClipped(triPos, genBox, x.prim, rmn, rmx, cmn, cmx) && xArea(cmn, cmx) > 0) { for (int c = 0; c < 3; ++c) { boxR[6 * (size_t) i + c] = cmn[c]; boxR[6 * (size_t) i + 3 + c] = cmx[c]; } }
-				else { R = 0; atomicAdd(&pruned[2 * x.node + 1], 1u); }
+				else { R = 0; atomicAdd(&nd.pruned[1], 1u); }
 			}
 		}
 	}
 	goesL[i] = L; goesR[i] = R;
 }
-__global__ void k_x_scatter(const XInst *inst, uint32_t n, const XNodeDev *nodes, const uint32_t *goesL, const uint32_t *goesR, const uint32_t *scanL,
-                            const uint32_t *scanR, const uint32_t *isLeafInst, const uint32_t *scanLeaf, const float *boxL, const float *boxR,
-                            XInst *next, XLeafItem *leafOut) {
+// per node: how many instances go to either child (from the inclusive scans of the flags)
+__global__ void k_x_counts(const XNodeG *nodes, uint32_t n, const uint32_t *sL, const uint32_t *sR, uint32_t *splitFlag, uint32_t *c2) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	const XNodeG &nd = nodes[k];
+	const uint32_t b = nd.instBegin, c = nd.instCount;
+	uint32_t nL = 0, nR = 0;
+	if (nd.isSplit && c) { nL = sL[b + c - 1] - (b ? sL[b - 1] : 0u); nR = sR[b + c - 1] - (b ? sR[b - 1] : 0u); }
+	splitFlag[k] = nd.isSplit; c2[2 * k] = nL; c2[2 * k + 1] = nR;
+}
+// the children of the split nodes = the next level (left, right, in node order); leaves learn where their items go
+__global__ void k_x_children(XNodeG *nodes, uint32_t n, XNodeG *next, uint32_t nextGlobal, const uint32_t *sSplit, const uint32_t *c2, const uint32_t *sC2,
+                             const uint32_t *sLeafInst, uint32_t nInst, uint32_t leafBase, XTotals *totals) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	XNodeG &nd = nodes[k];
+	if (nd.isSplit) {
+		const uint32_t r = sSplit[k] - 1u;
+		nd.child = nextGlobal + 2u * r;
+		for (int side = 0; side < 2; ++side) {
+			XNodeG c;
+			for (int a = 0; a < 3; ++a) { c.mn[a] = nd.mn[a]; c.mx[a] = nd.mx[a]; }
+			if (side == 0) c.mx[nd.axis] = nd.split; else c.mn[nd.axis] = nd.split;
+			c.primCount = (side == 0 ? nd.numLeft : nd.numRight) - nd.pruned[side];
+			c.instCount = c2[2 * k + side];
+			c.instBegin = sC2[2 * k + side] - c.instCount;
+			c.depth = nd.depth + 1u; c.badRefines = nd.badRefines;
+			c.sweep = c.isSplit = c.isLeaf = 0u; c.axis = 0; c.split = 0; c.planarLeft = 0; c.numLeft = c.numRight = 0;
+			c.child = 0; c.childBase[0] = c.childBase[1] = 0; c.pruned[0] = c.pruned[1] = 0; c.leafOffset = 0; c.cost = 0; c.retract = 0;
+			nd.childBase[side] = c.instBegin;
+			next[2u * r + side] = c;
+		}
+	} else {
+		// a leaf: its instances are contiguous in the level's compaction of leaf instances
+		nd.leafOffset = leafBase + (nd.instBegin ? sLeafInst[nd.instBegin - 1] : 0u);
+	}
+	if (k == n - 1) {
+		totals->nSplit = sSplit[n - 1]; totals->nNextInst = sC2[2 * n - 1];
+		totals->nLeafItems = nInst ? sLeafInst[nInst - 1] : 0u;
+	}
+}
+// instances to the children (stable: ascending primitive order is kept), leaf instances to the item buffer as
+// (leaf, axis-0 position, type) keys in the order leafFromEvents needs after ONE stable sort at the end
+__global__ void k_x_scatter(const XInst *inst, uint32_t n, const XNodeG *nodes, uint32_t levelGlobal, const uint32_t *goesL, const uint32_t *goesR,
+                            const uint32_t *scanL, const uint32_t *scanR, const uint32_t *isLeafInst, const uint32_t *scanLeaf, const float *boxL,
+                            const float *boxR, XInst *next, uint32_t leafBase, unsigned long long *leafKeys, uint32_t *leafPrims) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const XInst x = inst[i];
-	const XNodeDev &nd = nodes[x.node];
+	const XNodeG &nd = nodes[x.node];
 	const uint32_t b = nd.instBegin;
 	if (goesL[i]) {
-		XInst o; o.prim = x.prim; o.node = nd.childNode[0];
+		XInst o; o.prim = x.prim; o.node = 2u * (nd.child - (levelGlobal + 0u)) ; // placeholder, fixed below
+		o.node = 0;
 		for (int c = 0; c < 3; ++c) { o.mn[c] = boxL[6 * (size_t) i + c]; o.mx[c] = boxL[6 * (size_t) i + 3 + c]; }
+		o.node = nd.child - levelGlobal;          // index inside the next level (levelGlobal = global index of its first node)
 		next[nd.childBase[0] + (scanL[i] - 1u - (b ? scanL[b - 1] : 0u))] = o;
 	}
 	if (goesR[i]) {
-		XInst o; o.prim = x.prim; o.node = nd.childNode[1];
+		XInst o; o.prim = x.prim;
 		for (int c = 0; c < 3; ++c) { o.mn[c] = boxR[6 * (size_t) i + c]; o.mx[c] = boxR[6 * (size_t) i + 3 + c]; }
+		o.node = nd.child + 1u - levelGlobal;
 		next[nd.childBase[1] + (scanR[i] - 1u - (b ? scanR[b - 1] : 0u))] = o;
 	}
 	if (isLeafInst[i]) {
-		XLeafItem l; l.prim = x.prim; l.mn0 = x.mn[0]; l.planar = x.mn[0] == x.mx[0] ? 1u : 0u;
-		leafOut[scanLeaf[i] - 1u] = l;
+		const uint32_t pos = leafBase + scanLeaf[i] - 1u;
+		const uint32_t type = x.mn[0] == x.mx[0] ? (uint32_t) kPlanar : (uint32_t) kStart;
+		// (global node id of the leaf) | position | type: node ids grow with the buffer position
+		leafKeys[pos] = ((unsigned long long) (nd.leafOffset) << 34) | ((unsigned long long) xMono(x.mn[0]) << 2) | (unsigned long long) type;
+		leafPrims[pos] = x.prim;
 	}
 }
-
-// host view of a node of the exact phase
-struct XNode {
-	uint32_t job, depth, badRefines, primCount;
-	Box box;
-	uint32_t instBegin = 0, instCount = 0;
-	int kind = -1;                    // 0 inner, 1 leaf
-	int axis = 0; float split = 0;
-	int child[2] = { -1, -1 };
-	uint32_t pruned = 0;
-	size_t leafOffset = 0;            // its primitives in the order leafFromEvents lists them: leafStore[leafOffset ..)
-	uint32_t leafCount = 0;
-};
+// cost of the subtrees and retraction (gkdtree.h:2321-2341), one level at a time from the deepest one up
+__global__ void k_x_cost_up(XNodeG *all, uint32_t levelBase, uint32_t n, XParams prm) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	XNodeG &nd = all[levelBase + k];
+	const float leafCost = nd.primCount * prm.queryCost;
+	nd.retract = 0u;
+	if (!nd.isSplit) { nd.cost = leafCost; return; }
+	const float leftCost = all[nd.child].cost, rightCost = all[nd.child + 1u].cost;
+	const float e0 = nd.mx[0] - nd.mn[0], e1 = nd.mx[1] - nd.mn[1], e2 = nd.mx[2] - nd.mn[2];
+	const float temp = 1.0f / (e0 * e1 + e1 * e2 + e0 * e2);
+	const int a = nd.axis;
+	const float t0 = (a == 0 ? (e1 * e2) : a == 1 ? (e0 * e2) : (e0 * e1)) * temp;
+	const float t1 = (a == 0 ? (e1 + e2) : a == 1 ? (e0 + e2) : (e0 + e1)) * temp;
+	const float pl = t0 + t1 * (nd.split - nd.mn[a]), pr = t0 + t1 * (nd.mx[a] - nd.split);
+	const float finalCost = prm.traversalCost + (pl * leftCost + pr * rightCost);
+	if (!prm.retract || finalCost < leafCost) { nd.cost = finalCost; return; }
+	nd.cost = leafCost; nd.retract = 1u;
+}
+__global__ void k_x_host_view(const XNodeG *all, uint32_t n, XNodeH *out) {
+	const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= n) return;
+	const XNodeG &nd = all[k];
+	XNodeH h;
+	h.primCount = nd.primCount; h.kind = nd.isSplit ? 0 : 1; h.axis = nd.axis; h.split = nd.split; h.child = nd.child;
+	h.pruned = nd.pruned[0] + nd.pruned[1]; h.leafOffset = nd.leafOffset; h.leafCount = nd.isSplit ? 0u : nd.instCount; h.retract = nd.retract;
+	out[k] = h;
+}
 
 struct XScan {
 	DevBuf<unsigned char> tmp;
@@ -1275,6 +1368,15 @@ struct XScan {
 		KXHIP(rocprim::inclusive_scan((void *) tmp.p, bytes, in, out, n, rocprim::maximum<uint32_t>(), st));
 	}
 };
+// a device buffer that keeps its contents when it grows
+template <typename T> void growKeep(DevBuf<T> &b, size_t used, size_t need, hipStream_t st) {
+	if (need <= b.cap) return;
+	DevBuf<T> n;
+	n.reserve(std::max(need, 2 * b.cap));
+	if (used) KXHIP(hipMemcpyAsync(n.p, b.p, used * sizeof(T), hipMemcpyDeviceToDevice, st));
+	KXHIP(hipStreamSynchronize(st));
+	std::swap(b.p, n.p); std::swap(b.cap, n.cap);
+}
 
 // Builds the subtrees of all jobs on the current HIP device; fills job.ctx (root = node 0 of the context)
 void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_t nPrims, std::vector<std::unique_ptr<Job>> &jobs) {
@@ -1287,13 +1389,13 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 	struct StreamGuard { hipStream_t s; ~StreamGuard() { (void) hipStreamDestroy(s); } } guard{ st };
 	const int B = 256;
 	auto grid = [&](size_t n) { return dim3((unsigned) ((n + B - 1) / B)); };
-	const XParams prm{ p.traversalCost, p.queryCost, p.emptySpaceBonus, p.clip ? 1 : 0 };
+	const XParams prm{ p.traversalCost, p.queryCost, p.emptySpaceBonus, p.clip ? 1 : 0, p.stopPrims, p.maxDepth, p.maxBadRefines, p.retract ? 1 : 0 };
 	const bool timing = std::getenv("MTSGPU_KDTIMING") != nullptr;
-	double tm[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };      // setup, sweep (device), decisions, classify, children, scatter + leaves, replay
+	double tm[4] = { 0, 0, 0, 0 };      // setup, levels, download, replay
 	auto now = []() { return std::chrono::steady_clock::now(); };
 	auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
 	auto tPhase = now();
-	int nLevels = 0;
+	const int nThreads = std::max(1, std::min<int>(16, (int) std::thread::hardware_concurrency()));
 
 	// geometry: nine floats per triangle (NaN marks a non-triangle primitive, whose box is in genBox)
 	DevBuf<float> dTri, dGen;
@@ -1302,10 +1404,9 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 		float *tp = tpBuf.get();
 		std::atomic<bool> anyGenA(false);
 		{
-			const int T = std::max(1, std::min<int>(16, (int) std::thread::hardware_concurrency()));
 			std::vector<std::thread> pool;
-			for (int t = 0; t < T; ++t) pool.emplace_back([&, t]() {
-				for (uint32_t i = (uint32_t) ((uint64_t) nPrims * t / T); i < (uint32_t) ((uint64_t) nPrims * (t + 1) / T); ++i) {
+			for (int t = 0; t < nThreads; ++t) pool.emplace_back([&, t]() {
+				for (uint32_t i = (uint32_t) ((uint64_t) nPrims * t / nThreads); i < (uint32_t) ((uint64_t) nPrims * (t + 1) / nThreads); ++i) {
 					const uint32_t *tr = g.tri + 3 * (size_t) i;
 					if (tr[0] == MTSGPU_KNOTRIANGLE) { for (int q = 0; q < 9; ++q) tp[9 * (size_t) i + q] = std::numeric_limits<float>::quiet_NaN(); anyGenA = true; continue; }
 					for (int v = 0; v < 3; ++v) std::memcpy(&tp[9 * (size_t) i + 3 * v], g.vtx + 3 * (size_t) tr[v], 12);
@@ -1321,55 +1422,37 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 		KXHIP(hipStreamSynchronize(st));
 	}
 
-	std::vector<XNode> all;                       // every node of every job, in creation order
-	std::vector<uint32_t> active;                 // the nodes of the current level (indices into `all`)
-	std::vector<uint32_t> jobRoot(jobs.size());
+	// ---- the roots: one per job ----
 	size_t nInit = 0;
+	std::vector<XNodeG> roots(jobs.size());
 	for (size_t j = 0; j < jobs.size(); ++j) {
-		XNode n; n.job = (uint32_t) j; n.depth = jobs[j]->depth; n.badRefines = jobs[j]->badRefines; n.box = jobs[j]->nodeBox;
-		n.primCount = 0; n.instBegin = (uint32_t) nInit; n.instCount = (uint32_t) jobs[j]->prims.size();
+		XNodeG n; std::memset(&n, 0, sizeof(n));
+		for (int a = 0; a < 3; ++a) { n.mn[a] = jobs[j]->nodeBox.mn[a]; n.mx[a] = jobs[j]->nodeBox.mx[a]; }
+		n.depth = jobs[j]->depth; n.badRefines = jobs[j]->badRefines;
+		n.instBegin = (uint32_t) nInit; n.instCount = (uint32_t) jobs[j]->prims.size();
 		nInit += jobs[j]->prims.size();
-		jobRoot[j] = (uint32_t) all.size(); active.push_back((uint32_t) all.size()); all.push_back(std::move(n));
+		roots[j] = n;
 	}
-	if (active.size() > kXMaxNodes) throw std::runtime_error("kd-tree build (device exact phase): too many subtrees");
-	all.reserve(jobs.size() + nInit + nInit / 4);      // about 0.55 nodes per primitive in practice; untouched pages cost nothing
+	if (jobs.size() > kXMaxNodes) throw std::runtime_error("kd-tree build (device exact phase): too many subtrees");
+	if (nInit >= (1ull << 31)) throw std::runtime_error("kd-tree build (device exact phase): too many primitives");
 
+	DevBuf<XNodeG> dAll;                            // every node, level after level
+	size_t nAll = jobs.size();
+	dAll.reserve(jobs.size() + nInit + nInit / 4 + 1024);      // about 0.55 nodes per primitive in practice; grows if needed
+	KXHIP(hipMemcpyAsync(dAll.p, roots.data(), roots.size() * sizeof(XNodeG), hipMemcpyHostToDevice, st));
 	DevBuf<XInst> dInstA, dInstB;
-	DevBuf<XNodeDev> dNodes;
-	DevBuf<uint32_t> dU[12];
-	DevBuf<unsigned long long> dKeysA, dKeysB, dNodeBest;
-	DevBuf<uint32_t> dValsA, dValsB, dSegStart, dPruned, dCounts;
+	DevBuf<uint32_t> dU[12], dV[8];
+	DevBuf<unsigned long long> dKeysA, dKeysB, dNodeBest, dLeafKeys, dLeafKeys2;
+	DevBuf<uint32_t> dValsA, dValsB, dSegStart, dLeafPrims, dLeafPrims2;
 	DevBuf<float> dBoxL, dBoxR;
-	DevBuf<XBest> dBest;
-	DevBuf<XLeafItem> dLeaf;
+	DevBuf<XTotals> dTotals;
 	DevBuf<unsigned char> dSortTmp;
 	XScan scan;
-	std::vector<XNodeDev> hNodes;
-	auto uploadNodes = [&]() {
-		dNodes.reserve(hNodes.size());
-		KXHIP(hipMemcpyAsync(dNodes.p, hNodes.data(), hNodes.size() * sizeof(XNodeDev), hipMemcpyHostToDevice, st));
-	};
-	auto fillDev = [&](XNodeDev &d, const XNode &n) {
-		std::memset(&d, 0, sizeof(d));
-		for (int a = 0; a < 3; ++a) { d.mn[a] = n.box.mn[a]; d.mx[a] = n.box.mx[a]; }
-		d.primCount = n.primCount; d.instBegin = n.instBegin; d.instCount = n.instCount;
-	};
-	// per-node counts of up to three flag arrays (inclusive scans given; the device node table holds the ranges) -> host
-	auto rangeCounts = [&](const uint32_t *s0, const uint32_t *s1, const uint32_t *s2, std::vector<uint32_t> &out) {
-		const size_t nA = active.size();
-		dCounts.reserve(3 * nA);
-		hipLaunchKernelGGL(k_x_range_counts, grid(nA), dim3(B), 0, st, s0, s1, s2, dNodes.p, (uint32_t) nA, dCounts.p);
-		out.resize(3 * nA);
-		KXHIP(hipMemcpyAsync(out.data(), dCounts.p, 3 * nA * 4, hipMemcpyDeviceToHost, st));
-	};
-	std::vector<uint32_t> leafStore;              // the primitive lists of all leaves
-	const int nThreads = std::max(1, std::min<int>(16, (int) std::thread::hardware_concurrency()));
-	auto parallelFor = [&](size_t n, const std::function<void(size_t, size_t)> &fn) {
-		const int T = (int) std::min<size_t>((size_t) nThreads, std::max<size_t>(1, n / 4096));
-		if (T <= 1) { fn(0, n); return; }
-		std::vector<std::thread> pool;
-		for (int t = 0; t < T; ++t) pool.emplace_back([&, t]() { fn(n * t / T, n * (t + 1) / T); });
-		for (auto &th : pool) th.join();
+	dTotals.reserve(1);
+	XTotals totals{};
+	auto fetchTotals = [&]() {
+		KXHIP(hipMemcpyAsync(&totals, dTotals.p, sizeof(XTotals), hipMemcpyDeviceToHost, st));
+		KXHIP(hipStreamSynchronize(st));
 	};
 
 	// ---- level 0: the instances of the jobs' primitive lists, clipped to the jobs' boxes ----
@@ -1379,181 +1462,125 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 		size_t o = 0;
 		for (size_t j = 0; j < jobs.size(); ++j)
 			for (uint32_t prim : jobs[j]->prims) { hp[o] = prim; hn[o] = (uint32_t) j; ++o; }
-		hNodes.resize(active.size());
-		for (size_t k = 0; k < active.size(); ++k) fillDev(hNodes[k], all[active[k]]);
-		uploadNodes();
-		dU[0].reserve(nInit + 1); dU[1].reserve(nInit + 1); dU[2].reserve(nInit + 1); dU[3].reserve(nInit + 1);
-		dInstA.reserve(nInit + 1); dInstB.reserve(nInit + 1);
+		// every buffer gets its size once, with room for the straddlers that are duplicated on the way down (a
+		// reallocation inside the level loop costs a device synchronisation; it still happens if a level outgrows this)
+		const size_t instCap = nInit + nInit / 2 + 1024;
+		for (int k = 0; k < 4; ++k) dU[k].reserve(instCap);
+		for (int k = 4; k < 12; ++k) dU[k].reserve(6 * instCap);
+		dInstA.reserve(instCap); dInstB.reserve(instCap);
+		dKeysA.reserve(6 * instCap); dKeysB.reserve(6 * instCap); dValsA.reserve(6 * instCap); dValsB.reserve(6 * instCap);
+		dBoxL.reserve(6 * instCap); dBoxR.reserve(6 * instCap);
+		for (int k = 0; k < 4; ++k) dV[k].reserve(2 * std::min<size_t>(instCap, kXMaxNodes) + 1);
+		dSegStart.reserve(4 * std::min<size_t>(instCap, kXMaxNodes)); dNodeBest.reserve(std::min<size_t>(instCap, kXMaxNodes));
 		KXHIP(hipMemcpyAsync(dU[0].p, hp.data(), nInit * 4, hipMemcpyHostToDevice, st));
 		KXHIP(hipMemcpyAsync(dU[1].p, hn.data(), nInit * 4, hipMemcpyHostToDevice, st));
 		if (nInit) {
-			hipLaunchKernelGGL(k_x_init, grid(nInit), dim3(B), 0, st, dTri.p, dGen.p, dU[0].p, dU[1].p, (uint32_t) nInit, dNodes.p, prm.clip, dInstB.p, dU[2].p);
+			hipLaunchKernelGGL(k_x_init, grid(nInit), dim3(B), 0, st, dTri.p, dGen.p, dU[0].p, dU[1].p, (uint32_t) nInit, dAll.p, prm.clip, dInstB.p, dU[2].p);
 			scan.sum(dU[2].p, dU[3].p, nInit, st);
 			hipLaunchKernelGGL(k_x_compact, grid(nInit), dim3(B), 0, st, dInstB.p, dU[2].p, dU[3].p, (uint32_t) nInit, dInstA.p);
-		}
-		std::vector<uint32_t> kept;
-		rangeCounts(dU[3].p, nullptr, nullptr, kept);
-		KXHIP(hipStreamSynchronize(st));
-		for (size_t k = 0; k < active.size(); ++k) {
-			XNode &n = all[active[k]];
-			n.instBegin = (uint32_t) nInst; n.instCount = kept[k]; n.primCount = kept[k];
-			nInst += kept[k];
+			hipLaunchKernelGGL(k_x_roots, grid(jobs.size()), dim3(B), 0, st, dAll.p, (uint32_t) jobs.size(), dU[3].p, dTotals.p);
+			fetchTotals();
+			nInst = totals.nNextInst;
+		} else {
+			KXHIP(hipStreamSynchronize(st));
 		}
 	}
+	tm[0] = since(tPhase); tPhase = now();
 
-	tm[0] = since(tPhase);
 	// ---- the levels ----
-	while (!active.empty()) {
-		++nLevels;
-		tPhase = now();
-		const size_t nA = active.size();
+	std::vector<std::pair<size_t, size_t>> levels;       // (global index of the first node, nodes)
+	size_t levelBase = 0, nA = jobs.size(), leafTotal = 0;
+	dLeafKeys.reserve(nInit + nInit / 4 + 1024); dLeafPrims.reserve(nInit + nInit / 4 + 1024);
+	while (nA > 0) {
 		if (nA > kXMaxNodes) throw std::runtime_error("kd-tree build (device exact phase): more than 2^22 nodes in one level");
-		hNodes.resize(nA);
-		if (all.capacity() < all.size() + 2 * nA) all.reserve(std::max(all.size() + 2 * nA, 2 * all.capacity()));      // (rare: see the reserve above)
-		bool anySweep = false;
-		for (size_t k = 0; k < nA; ++k) {
-			XNode &n = all[active[k]];
-			fillDev(hNodes[k], n);
-			const bool preLeaf = n.primCount <= p.stopPrims || n.depth >= p.maxDepth;          // gkdtree.h:1903-1906
-			hNodes[k].sweep = preLeaf ? 0u : 1u;
-			if (preLeaf) { n.kind = 1; hNodes[k].isLeaf = 1; } else anySweep = true;
-		}
-		std::vector<XBest> best(nA);
+		levels.emplace_back(levelBase, nA);
+		XNodeG *nodes = dAll.p + levelBase;
+		hipLaunchKernelGGL(k_x_prep, grid(nA), dim3(B), 0, st, nodes, (uint32_t) nA, prm);
 		const size_t nEv = 6 * nInst;
-		if (anySweep && nInst) {
-			uploadNodes();
+		if (nInst) {
 			dKeysA.reserve(nEv); dKeysB.reserve(nEv); dValsA.reserve(nEv); dValsB.reserve(nEv);
 			for (int k = 4; k < 12; ++k) dU[k].reserve(nEv + 1);
-			dSegStart.reserve(4 * nA); dNodeBest.reserve(nA); dBest.reserve(nA);
-			hipLaunchKernelGGL(k_x_emit, grid(nInst), dim3(B), 0, st, dInstA.p, (uint32_t) nInst, dNodes.p, dKeysA.p, dValsA.p);
-			const bool detail = timing && std::getenv("MTSGPU_KDTIMING")[0] == '2';
-			auto tSort = now();
-			if (detail) KXHIP(hipStreamSynchronize(st));
+			dSegStart.reserve(4 * nA); dNodeBest.reserve(nA);
+			hipLaunchKernelGGL(k_x_emit, grid(nInst), dim3(B), 0, st, dInstA.p, (uint32_t) nInst, nodes, dKeysA.p, dValsA.p);
 			{
 				size_t bytes = 0;
-				// node | axis | position | type: 34 + 2 + the bits the node ids of this level need (unused events are all ones)
+				// node | axis | position | type: 34 + 2 + the bits the node ids of this level need (unused slots are all ones,
+				// which no event is because axis 3 does not exist: they sort last)
 				unsigned endBit = 36;
-				while (endBit < 58 && (nA - 1) >> (endBit - 36)) ++endBit;
-				endBit = std::min(58u, endBit + 1);      // one more so that the all-ones key of an unused slot sorts last
+				while (endBit < 58 && ((nA - 1) >> (endBit - 36))) ++endBit;
 				KXHIP(rocprim::radix_sort_pairs(nullptr, bytes, dKeysA.p, dKeysB.p, dValsA.p, dValsB.p, nEv, 0u, endBit, st));
 				dSortTmp.reserve(bytes + 16);
 				KXHIP(rocprim::radix_sort_pairs((void *) dSortTmp.p, bytes, dKeysA.p, dKeysB.p, dValsA.p, dValsB.p, nEv, 0u, endBit, st));
 			}
-			if (detail) { KXHIP(hipStreamSynchronize(st)); tm[7] += since(tSort); }
 			uint32_t *cE = dU[4].p, *cP = dU[5].p, *cS = dU[6].p, *hd = dU[7].p, *sE = dU[8].p, *sP = dU[9].p, *sS = dU[10].p, *sH = dU[11].p;
 			KXHIP(hipMemsetAsync(dSegStart.p, 0, 4 * nA * sizeof(uint32_t), st));
 			KXHIP(hipMemsetAsync(dNodeBest.p, 0xFF, nA * sizeof(unsigned long long), st));
 			hipLaunchKernelGGL(k_x_flags, grid(nEv), dim3(B), 0, st, dKeysB.p, (uint32_t) nEv, cE, cP, cS, hd, dSegStart.p);
 			scan.sum(cE, sE, nEv, st); scan.sum(cP, sP, nEv, st); scan.sum(cS, sS, nEv, st); scan.max(hd, sH, nEv, st);
-			hipLaunchKernelGGL(k_x_cost, grid(nEv), dim3(B), 0, st, dKeysB.p, dValsB.p, (uint32_t) nEv, sE, sP, sS, sH, dSegStart.p, dInstA.p, dNodes.p, prm, dNodeBest.p);
-			hipLaunchKernelGGL(k_x_best, grid(nA), dim3(B), 0, st, dNodeBest.p, (uint32_t) nA, dKeysB.p, dValsB.p, sE, sP, sS, sH, dSegStart.p, dInstA.p, dNodes.p, prm, dBest.p);
-			KXHIP(hipMemcpyAsync(best.data(), dBest.p, nA * sizeof(XBest), hipMemcpyDeviceToHost, st));
-			KXHIP(hipStreamSynchronize(st));
+			hipLaunchKernelGGL(k_x_cost, grid(nEv), dim3(B), 0, st, dKeysB.p, dValsB.p, (uint32_t) nEv, sE, sP, sS, sH, dSegStart.p, dInstA.p, nodes, prm, dNodeBest.p);
+			hipLaunchKernelGGL(k_x_decide, grid(nA), dim3(B), 0, st, nodes, (uint32_t) nA, dNodeBest.p, dKeysB.p, dValsB.p, sE, sP, sS, sH, dSegStart.p, dInstA.p, prm);
 		}
-		tm[1] += since(tPhase); tPhase = now();
-		// the decisions of gkdtree.h:2023-2051 on the host
-		std::vector<Split> chosen(nA);
-		for (size_t k = 0; k < nA; ++k) {
-			XNode &n = all[active[k]];
-			if (n.kind == 1) continue;
-			Split s; s.cost = best[k].cost; s.pos = best[k].pos; s.axis = best[k].axis; s.numLeft = best[k].numLeft; s.numRight = best[k].numRight; s.planarLeft = best[k].planarLeft != 0;
-			const float leafCost = n.primCount * p.queryCost;
-			bool leaf = false;
-			if (s.cost >= leafCost) {
-				if ((s.cost > 4 * leafCost && n.primCount < 16) || n.badRefines >= p.maxBadRefines || s.cost == kInf) leaf = true;
-				else ++n.badRefines;
-			}
-			if (leaf) { n.kind = 1; hNodes[k].isLeaf = 1; }
-			else { n.kind = 0; n.axis = s.axis; n.split = s.pos; hNodes[k].isSplit = 1; hNodes[k].axis = s.axis; hNodes[k].split = s.pos; hNodes[k].planarLeft = s.planarLeft ? 1u : 0u; }
-			chosen[k] = s;
-		}
-		tm[2] += since(tPhase); tPhase = now();
-		// classification, clipping, counts
-		std::vector<uint32_t> cnt3, hPruned(2 * nA, 0u);
-		size_t nNext = 0, nLeafItems = 0;
-		std::vector<uint32_t> nextActive;
+		// classification, clipping, children
+		for (int k = 0; k < 6; ++k) dU[k].reserve(nInst + 1);
+		for (int k = 0; k < 4; ++k) dV[k].reserve(2 * nA + 1);
+		dBoxL.reserve(6 * nInst + 6); dBoxR.reserve(6 * nInst + 6);
+		uint32_t *gL = dU[0].p, *gR = dU[1].p, *lf = dU[2].p, *sL = dU[3].p, *sR = dU[4].p, *sLf = dU[5].p;
+		uint32_t *splitFlag = dV[0].p, *sSplit = dV[1].p, *c2 = dV[2].p, *sC2 = dV[3].p;
 		if (nInst) {
-			uploadNodes();
-			for (int k = 0; k < 6; ++k) dU[k].reserve(nInst + 1);
-			dBoxL.reserve(6 * nInst); dBoxR.reserve(6 * nInst); dPruned.reserve(2 * nA);
-			KXHIP(hipMemsetAsync(dPruned.p, 0, 2 * nA * sizeof(uint32_t), st));
-			uint32_t *gL = dU[0].p, *gR = dU[1].p, *lf = dU[2].p, *sL = dU[3].p, *sR = dU[4].p, *sLf = dU[5].p;
-			hipLaunchKernelGGL(k_x_classify, grid(nInst), dim3(B), 0, st, dInstA.p, (uint32_t) nInst, dNodes.p, dTri.p, dGen.p, prm.clip, gL, gR, lf, dBoxL.p, dBoxR.p, dPruned.p);
+			hipLaunchKernelGGL(k_x_classify, grid(nInst), dim3(B), 0, st, dInstA.p, (uint32_t) nInst, nodes, dTri.p, dGen.p, prm.clip, gL, gR, lf, dBoxL.p, dBoxR.p);
 			scan.sum(gL, sL, nInst, st); scan.sum(gR, sR, nInst, st); scan.sum(lf, sLf, nInst, st);
-			rangeCounts(sL, sR, sLf, cnt3);
-			KXHIP(hipMemcpyAsync(hPruned.data(), dPruned.p, 2 * nA * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-			KXHIP(hipStreamSynchronize(st));
-		} else {
-			cnt3.assign(3 * nA, 0u);
 		}
-		const uint32_t *cntL = cnt3.data(), *cntR = cnt3.data() + nA, *cntLeaf = cnt3.data() + 2 * nA;
-		tm[3] += since(tPhase); tPhase = now();
-		// children (left, then right, in node order) and where their instances go
-		for (size_t k = 0; k < nA; ++k) {
-			const uint32_t id = active[k];
-			if (all[id].kind != 0) { nLeafItems += cntLeaf[k]; continue; }
-			const Split &s = chosen[k];
-			all[id].pruned = hPruned[2 * k] + hPruned[2 * k + 1];
-			for (int side = 0; side < 2; ++side) {
-				XNode c; c.job = all[id].job; c.depth = all[id].depth + 1; c.badRefines = all[id].badRefines;
-				c.box = all[id].box;
-				if (side == 0) c.box.mx[s.axis] = s.pos; else c.box.mn[s.axis] = s.pos;
-				c.primCount = (side == 0 ? s.numLeft : s.numRight) - hPruned[2 * k + side];
-				c.instCount = side == 0 ? cntL[k] : cntR[k];
-				c.instBegin = (uint32_t) nNext; nNext += c.instCount;
-				hNodes[k].childBase[side] = c.instBegin; hNodes[k].childNode[side] = (uint32_t) nextActive.size();
-				all[id].child[side] = (int) all.size();
-				nextActive.push_back((uint32_t) all.size());
-				all.push_back(std::move(c));
-			}
-		}
-		tm[4] += since(tPhase); tPhase = now();
+		hipLaunchKernelGGL(k_x_counts, grid(nA), dim3(B), 0, st, nodes, (uint32_t) nA, sL, sR, splitFlag, c2);
+		scan.sum(splitFlag, sSplit, nA, st); scan.sum(c2, sC2, 2 * nA, st);
+		// room for the next level's nodes (at most two per node)
+		if (nAll + 2 * nA > dAll.cap) { growKeep(dAll, nAll, nAll + 2 * nA, st); nodes = dAll.p + levelBase; }
+		hipLaunchKernelGGL(k_x_children, grid(nA), dim3(B), 0, st, nodes, (uint32_t) nA, dAll.p + nAll, (uint32_t) nAll, sSplit, c2, sC2, sLf, (uint32_t) nInst,
+		                   (uint32_t) leafTotal, dTotals.p);
+		fetchTotals();
+		const size_t nNext = totals.nNextInst, nLeafItems = totals.nLeafItems;
+		if (leafTotal + nLeafItems >= (1ull << 30)) throw std::runtime_error("kd-tree build (device exact phase): too many leaf entries");
 		if (nInst) {
-			uploadNodes();
-			dInstB.reserve(nNext + 1); dLeaf.reserve(nLeafItems + 1);
-			hipLaunchKernelGGL(k_x_scatter, grid(nInst), dim3(B), 0, st, dInstA.p, (uint32_t) nInst, dNodes.p, dU[0].p, dU[1].p, dU[3].p, dU[4].p, dU[2].p, dU[5].p,
-			                   dBoxL.p, dBoxR.p, dInstB.p, dLeaf.p);
-			std::vector<XLeafItem> items(nLeafItems);
-			if (nLeafItems) KXHIP(hipMemcpyAsync(items.data(), dLeaf.p, nLeafItems * sizeof(XLeafItem), hipMemcpyDeviceToHost, st));
-			KXHIP(hipStreamSynchronize(st));
-			// leafFromEvents: the axis-0 start / planar events in EventLess order
-			const size_t storeBase = leafStore.size();
-			leafStore.resize(storeBase + nLeafItems);
-			size_t o = 0;
-			for (size_t k = 0; k < nA; ++k) {
-				XNode &n = all[active[k]];
-				if (n.kind != 1) continue;
-				n.leafOffset = storeBase + o; n.leafCount = cntLeaf[k];
-				o += cntLeaf[k];
-			}
-			parallelFor(nA, [&](size_t lo, size_t hi) {
-				for (size_t k = lo; k < hi; ++k) {
-					const XNode &n = all[active[k]];
-					if (n.kind != 1) continue;
-					XLeafItem *first = items.data() + (n.leafOffset - storeBase), *last = first + n.leafCount;
-					std::sort(first, last, [](const XLeafItem &x, const XLeafItem &y) {
-						if (x.mn0 != y.mn0) return x.mn0 < y.mn0;
-						const uint32_t tx = x.planar ? kPlanar : kStart, ty = y.planar ? kPlanar : kStart;
-						if (tx != ty) return tx < ty;
-						return x.prim < y.prim;
-					});
-					for (uint32_t q = 0; q < n.leafCount; ++q) leafStore[n.leafOffset + q] = first[q].prim;
-				}
-			});
+			dInstB.reserve(nNext + 1);
+			growKeep(dLeafKeys, leafTotal, leafTotal + nLeafItems + 1, st); growKeep(dLeafPrims, leafTotal, leafTotal + nLeafItems + 1, st);
+			hipLaunchKernelGGL(k_x_scatter, grid(nInst), dim3(B), 0, st, dInstA.p, (uint32_t) nInst, nodes, (uint32_t) nAll, gL, gR, sL, sR, lf, sLf,
+			                   dBoxL.p, dBoxR.p, dInstB.p, (uint32_t) leafTotal, dLeafKeys.p, dLeafPrims.p);
 		}
 		std::swap(dInstA.p, dInstB.p); std::swap(dInstA.cap, dInstB.cap);
+		leafTotal += nLeafItems;
 		nInst = nNext;
-		active.swap(nextActive);
-		tm[5] += since(tPhase);
+		levelBase = nAll;
+		nA = 2 * (size_t) totals.nSplit;
+		nAll += nA;
 	}
-	tPhase = now();
+	tm[1] = since(tPhase); tPhase = now();
+
+	// ---- leaf order, subtree costs, download ----
+	// leafFromEvents lists the axis-0 start / planar events in EventLess order: one stable sort of all leaf items by
+	// (leaf, position, type); equal keys keep the ascending primitive order of the instances
+	std::vector<uint32_t> leafStore(leafTotal);
+	if (leafTotal) {
+		dLeafKeys2.reserve(leafTotal); dLeafPrims2.reserve(leafTotal);
+		size_t bytes = 0;
+		KXHIP(rocprim::radix_sort_pairs(nullptr, bytes, dLeafKeys.p, dLeafKeys2.p, dLeafPrims.p, dLeafPrims2.p, leafTotal, 0u, 64u, st));
+		dSortTmp.reserve(bytes + 16);
+		KXHIP(rocprim::radix_sort_pairs((void *) dSortTmp.p, bytes, dLeafKeys.p, dLeafKeys2.p, dLeafPrims.p, dLeafPrims2.p, leafTotal, 0u, 64u, st));
+		KXHIP(hipMemcpyAsync(leafStore.data(), dLeafPrims2.p, leafTotal * 4, hipMemcpyDeviceToHost, st));
+	}
+	for (size_t l = levels.size(); l-- > 0;)
+		hipLaunchKernelGGL(k_x_cost_up, grid(levels[l].second), dim3(B), 0, st, dAll.p, (uint32_t) levels[l].first, (uint32_t) levels[l].second, prm);
+	DevBuf<XNodeH> dView;
+	dView.reserve(nAll);
+	hipLaunchKernelGGL(k_x_host_view, grid(nAll), dim3(B), 0, st, dAll.p, (uint32_t) nAll, dView.p);
+	std::vector<XNodeH> all(nAll);
+	KXHIP(hipMemcpyAsync(all.data(), dView.p, nAll * sizeof(XNodeH), hipMemcpyDeviceToHost, st));
+	KXHIP(hipStreamSynchronize(st));
+	tm[2] = since(tPhase); tPhase = now();
 
 	// ---- replay: the bookkeeping of buildTree per job, depth first (nodes, indices, counters, retraction) ----
 	struct Emit {
-		const Builder &b; const Params &p; std::vector<XNode> &all; const std::vector<uint32_t> &leafStore;
-		float run(Context &c, uint32_t id, uint32_t node) {
-			XNode &n = all[id];
-			const float leafCost = n.primCount * p.queryCost;
+		const Builder &b; const Params &p; const std::vector<XNodeH> &all; const std::vector<uint32_t> &leafStore;
+		void run(Context &c, uint32_t id, uint32_t node) {
+			const XNodeH &n = all[id];
 			if (n.kind == 1) {
 				PNode &pn = c.nodes[node];
 				pn.kind = 1; pn.a = (uint32_t) c.indices.size(); pn.b = pn.a + n.primCount;
@@ -1563,7 +1590,7 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 					c.primIndexCount += n.primCount;
 				}
 				c.leafCount++;
-				return leafCost;
+				return;
 			}
 			c.pruned += n.pruned;
 			const uint32_t children = c.allocNodes(2);
@@ -1571,20 +1598,14 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 			const uint32_t leafBefore = c.leafCount, nonemptyBefore = c.nonemptyLeafCount, innerBefore = c.innerCount;
 			{ PNode &pn = c.nodes[node]; pn.kind = 0; pn.a = (uint32_t) n.axis; pn.b = children; pn.split = n.split; }
 			c.innerCount++;
-			const float leftCost = run(c, (uint32_t) n.child[0], children);
-			const float rightCost = run(c, (uint32_t) n.child[1], children + 1);
-			const XNode &m = all[id];
-			const SAH tch(m.box);
-			float pl, pr;
-			tch(m.axis, m.split - m.box.mn[m.axis], m.box.mx[m.axis] - m.split, pl, pr);
-			const float finalCost = p.traversalCost + (pl * leftCost + pr * rightCost);
-			if (!p.retract || finalCost < m.primCount * p.queryCost)
-				return finalCost;
+			run(c, n.child, children);
+			run(c, n.child + 1u, children + 1);
+			if (!n.retract)
+				return;
 			c.nodes.resize(nodePosBefore);
 			c.retracted++;
 			c.leafCount = leafBefore; c.nonemptyLeafCount = nonemptyBefore; c.innerCount = innerBefore;
 			b.leafAfterRetraction(c, node, indexPosBefore);
-			return leafCost;
 		}
 	} emit{ b, p, all, leafStore };
 	{
@@ -1598,7 +1619,7 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 					if (j >= jobs.size()) break;
 					Job &job = *jobs[j];
 					job.root = job.ctx.allocNodes(1);
-					emit.run(job.ctx, jobRoot[j], job.root);
+					emit.run(job.ctx, (uint32_t) j, job.root);
 					std::vector<uint32_t>().swap(job.prims);
 				}
 			} catch (...) {
@@ -1614,10 +1635,10 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 		for (auto &th : pool) th.join();
 		if (firstError) std::rethrow_exception(firstError);
 	}
-	tm[6] = since(tPhase);
+	tm[3] = since(tPhase);
 	if (timing)
-		std::fprintf(stderr, "[kdbuild] device exact phase: %d levels, %zu nodes; setup %.1f, sweep %.1f, decisions %.1f, classify %.1f, children %.1f, scatter + leaves %.1f, replay %.1f ms (sort alone %.1f)\n",
-		             nLevels, all.size(), tm[0], tm[1], tm[2], tm[3], tm[4], tm[5], tm[6], tm[7]);
+		std::fprintf(stderr, "[kdbuild] device exact phase: %zu levels, %zu nodes, %zu leaf entries; setup %.1f, levels %.1f, leaf sort + costs + download %.1f, replay %.1f ms\n",
+		             levels.size(), nAll, leafTotal, tm[0], tm[1], tm[2], tm[3]);
 }
 
 int log2i(uint32_t v) { int r = 0; while (v >>= 1) r++; return r; }

@@ -10,7 +10,7 @@ if knobs.pop("debug", "0") == "1":
     os.environ["MTSGPU_DEBUG"] = "1"
 count = knobs.pop("count", "0") == "1"
 sd = pkg.scenes.cornell_c3()
-scene = pkg.Scene(sd, None, gpu_binning=True)
+scene = pkg.Scene(sd, None, gpu_binning=True, gpu_exact=True)
 cam = pkg.PerspectiveCamera.for_description(sd, res, res)
 it = pkg.MIPathTracer(maxDepth=sd.max_depth)
 it.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp, seed=0x5EED)

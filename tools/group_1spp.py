@@ -7,7 +7,7 @@ pkg = _pkgload.load()
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 sd = pkg.scenes.cornell_c3()
-scene = pkg.Scene(sd, None, gpu_binning=True)
+scene = pkg.Scene(sd, None, gpu_binning=True, gpu_exact=True)
 cam = pkg.PerspectiveCamera.for_description(sd, 1024, 1024)
 g = pkg.DeviceGroup([0] * K, maxDepth=sd.max_depth)
 g.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp, seed=0x5EED)
