@@ -289,7 +289,7 @@ int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatil
 	for (int j = 0; j < std::max(1, c->nLumSamples); ++j) {
 		if (cancel && *cancel) return fail(c, MTSGPU_ECANCEL, "render cancelled");
 		rc = shadeRound(1, j, j == 0); if (rc) return rc;
-		const uint32_t nShadow = c->hostCounters[(kNumBins * kBinShards + 1) * kCounterStride];
+		const uint32_t nShadow = c->hostCounters[kShadowWord];
 		if (nShadow) {
 			rc = timedTrace(1, false, c->q.shadow, nShadow, true); if (rc) return rc;
 			c->stats.rays_shadow += nShadow;
@@ -299,7 +299,7 @@ int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatil
 	for (int j = 0; j < std::max(1, c->nBsdfSamples); ++j) {
 		if (cancel && *cancel) return fail(c, MTSGPU_ECANCEL, "render cancelled");
 		rc = shadeRound(2, j, false); if (rc) return rc;
-		const uint32_t nNext = c->hostCounters[kNumBins * kBinShards * kCounterStride];
+		const uint32_t nNext = c->hostCounters[kNextWord];
 		if (!nNext) continue;
 		rc = timedTrace(0, false, c->queueB, nNext, false); if (rc) return rc;
 		c->stats.rays_closest += nNext;
@@ -358,7 +358,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 			c->q.counters = set; c->q.next = nxt; c->q.spill = c->spillClosest;
 			int rc = timed(c->traceEvents, c->traceEvUsed, s1, 0); if (rc) return rc;
 			launch_trace(s1, 0, c->countTraversal, true, c->dsc, c->paths, c->q, cur, upper, b == 0,
-			             b == 0 ? nullptr : prev + (size_t) kCntNext * kCounterStride);
+			             b == 0 ? nullptr : prev + (size_t) kNextWord);
 			rc = timed(c->traceEvents, c->traceEvUsed, s1, 1); if (rc) return rc;
 			// the shading of this bounce adds to Li after the shadow rays of the previous one have (path.cpp:124 before :80)
 			if (shadowPending) HIPCHK(c, hipStreamWaitEvent(s1, c->evShadow[(b - 1) & 1], 0));
@@ -376,7 +376,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 			DQueues q2 = c->q; q2.spill = c->spillShadow;
 			rc = timed(c->traceEvents, c->traceEvUsed, s2, 0); if (rc) return rc;
 			launch_trace(s2, 1, c->countTraversal, false, c->dsc, c->paths, q2, c->q.shadow, upper, b == 0,
-			             set + (size_t) kCntShadow * kCounterStride);
+			             set + (size_t) kShadowWord);
 			rc = timed(c->traceEvents, c->traceEvUsed, s2, 1); if (rc) return rc;
 			HIPCHK(c, hipGetLastError());
 			HIPCHK(c, hipEventRecord(c->evShadow[b & 1], s2));
@@ -385,7 +385,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 		}
 		// how many paths are left: the one read-back of the chunk
 		uint32_t *hostNext = &c->hostCounters[kNumCounters * kCounterStride + 2];
-		HIPCHK(c, hipMemcpyAsync(hostNext, counterSet(c, b - 1) + (size_t) kCntNext * kCounterStride, sizeof(uint32_t), hipMemcpyDeviceToHost, s1));
+		HIPCHK(c, hipMemcpyAsync(hostNext, counterSet(c, b - 1) + (size_t) kNextWord, sizeof(uint32_t), hipMemcpyDeviceToHost, s1));
 		HIPCHK(c, hipEventRecord(c->evCount, s1));
 		HIPCHK(c, hipEventSynchronize(c->evCount));
 		upper = *hostNext;
@@ -448,7 +448,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
 		HIPCHK(c, hipGetLastError());
 		rc = readCounters(c); if (rc) return rc;
-		const uint32_t nNext = c->hostCounters[kCntNext * kCounterStride], nShadow = c->hostCounters[kCntShadow * kCounterStride];
+		const uint32_t nNext = c->hostCounters[kNextWord], nShadow = c->hostCounters[kShadowWord];
 		// shadow rays of this bounce (they add the direct-light term before the next bounce adds its own); on the second
 		// stream, so that the closest-hit launch of the next bounce runs next to them -- the shading above has completed
 		if (nShadow) {

@@ -20,8 +20,10 @@ constexpr int kNumCounters = kNumBins * kBinShards + 4;   // bins x shards, next
 // closest-hit launch of bounce b + 1 already fills the next set
 constexpr int kCounterSets = 2;
 constexpr int kCntNext = kNumBins * kBinShards, kCntShadow = kCntNext + 1, kCntDynClosest = kCntNext + 2, kCntDynShadow = kCntNext + 3;
+// word offsets of the two queue counters of k_shade inside a counter set (one 128-byte line each)
+constexpr int kNextWord = kCntNext * kCounterStride, kShadowWord = kCntShadow * kCounterStride;
 #ifndef MG_SHADE_BLOCK
-#define MG_SHADE_BLOCK 512
+#define MG_SHADE_BLOCK 1024     // 512: two atomics-bound milliseconds more per 64-spp frame (one reservation per workgroup)
 #endif
 constexpr int kShadeBlock = MG_SHADE_BLOCK;
 // device-side frame statistics (u64): rays of the closest-hit / shadow launches, segment-overflow flag, non-empty

@@ -1800,10 +1800,23 @@ __device__ __forceinline__ float mi_weight(float pdfA, float pdfB) {     // path
 // The path's 128-byte record is staged in LDS by k_shade (`row`, slot k = record slot k): ro / rd / h / T4 / L4 were
 // read from it already and, for a valid hit, slots 0, 1, 3 now hold the primitive's position chunks (see k_shade).
 // What changes is written back to `row`: ray_o, ray_d, bsdf when the path continues; thr, Li, misc always.
+// A staged path record in LDS: slot k of lane l lives at column k ^ (l & 7) of the lane's 8-slot row when the rows
+// are packed (MG_SHADE_PACKED: 128 B per lane, what 5 waves per SIMD can afford; two lanes share a bank group), or at
+// column k of a 9-slot row (144 B per lane, conflict-free)
+#ifndef MG_SHADE_PACKED
+#define MG_SHADE_PACKED 0
+#endif
+constexpr int kRowStride = MG_SHADE_PACKED ? kPathSlots : kPathSlots + 1;
+struct ShadeRow {
+	float4 *base; uint32_t x;
+	__device__ __forceinline__ float4 &operator[](int k) const { return base[MG_SHADE_PACKED ? ((uint32_t) k ^ x) : (uint32_t) k]; }
+};
+__device__ __forceinline__ uint32_t shade_row_index(uint32_t lane, uint32_t k) { return lane * kRowStride + (MG_SHADE_PACKED ? (k ^ (lane & 7u)) : k); }
+
 template <int BT, bool ROUNDS>
 __device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, const DConfig &cfg, const uint32_t id,
                                            const float4 ro, const float4 rd, const uint4 h, const float4 T4, const float4 L4,
-                                           float4 *row, bool &continues, bool &wantShadow, V3 &neeV, V3 &shO, V3 &shD) {
+                                           const ShadeRow row, bool &continues, bool &wantShadow, V3 &neeV, V3 &shO, V3 &shD) {
 	{
 		// rounds of MIDirectIntegrator (DConfig::dr_mode): later BSDF samples start again from the camera hit
 		const int mode = ROUNDS ? cfg.dr_mode : 0;
@@ -1994,10 +2007,17 @@ __device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, c
 #define MG_SHADE_ALL_SLOTS 1      // whole 128-byte lines in both directions; 0 (only the slots needed: 7 read, 6 written, 3 of the
                                   // triangle) was measured at 66 ms instead of 44 ms per frame: partial lines cost a read-modify-write
 #endif
-constexpr int kRowStride = kPathSlots + 1;      // LDS row of a staged path record: 9 float4, conflict-free for 16-byte accesses
 
 template <int BT, bool ROUNDS>
-__global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, BinView view_host,
+#ifndef MG_SHADE_WAVES
+#define MG_SHADE_WAVES 0
+#endif
+#if MG_SHADE_WAVES
+#define MG_SHADE_BOUNDS __launch_bounds__(kShadeBlock, MG_SHADE_WAVES)
+#else
+#define MG_SHADE_BOUNDS __launch_bounds__(kShadeBlock)
+#endif
+__global__ MG_SHADE_BOUNDS void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, BinView view_host,
                                                        const BinView *views_dev, const uint32_t *bin_ids) {
 	__shared__ uint32_t s_cnt[2][kShadeBlock / 64];
 	__shared__ uint32_t s_base[2];
@@ -2025,7 +2045,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 	// LDS accesses free of bank conflicts, and the rows are written back the same way: whole lines, coalesced.
 	// All LDS traffic is private to the wave (program order suffices, no barrier).
 	float4 *rows = s_rows[threadIdx.x >> 6];
-	float4 *row = rows + lane_id() * kRowStride;
+	const ShadeRow row{ rows + lane_id() * kRowStride, lane_id() & 7u };
 	const uint32_t sub = lane_id() & 7u, grp = lane_id() >> 3;
 	const uint64_t actMask = __ballot(active);
 	#pragma unroll
@@ -2033,7 +2053,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 		const uint32_t src = grp + 8u * r;
 		const uint32_t sid = (uint32_t) __shfl((int) id, (int) src);
 		// slot 7 (the raster position) is only read by the film kernels
-		if (((actMask >> src) & 1ull) && (MG_SHADE_ALL_SLOTS || sub != 7u)) rows[src * kRowStride + sub] = ld_stream<4>(&ps.base[(size_t) sid * kPathSlots + sub]);
+		if (((actMask >> src) & 1ull) && (MG_SHADE_ALL_SLOTS || sub != 7u)) rows[shade_row_index(src, sub)] = ld_stream<4>(&ps.base[(size_t) sid * kPathSlots + sub]);
 	}
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 	bool continues = false, wantShadow = false;
@@ -2065,7 +2085,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 		for (int r = 0; r < 4; ++r) {
 			const uint32_t src = grp4 + 16u * r;
 			const uint32_t sprim = (uint32_t) __shfl((int) prim, (int) src);
-			if (((validMask >> src) & 1ull) && (MG_SHADE_ALL_SLOTS || sub4 != 3u)) rows[src * kRowStride + slotOf] = sc.tri_pos[(size_t) sprim * kTriStride + sub4];
+			if (((validMask >> src) & 1ull) && (MG_SHADE_ALL_SLOTS || sub4 != 3u)) rows[shade_row_index(src, slotOf)] = sc.tri_pos[(size_t) sprim * kTriStride + sub4];
 		}
 	}
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -2077,12 +2097,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 		const uint32_t src = grp + 8u * r;
 		const uint32_t sid = (uint32_t) __shfl((int) id, (int) src);
 		// the hit (slot 2) and the raster position (slot 7) do not change here
-		if (((actMask >> src) & 1ull) && (MG_SHADE_ALL_SLOTS || (sub != 2u && sub != 7u))) st_stream<4>(&ps.base[(size_t) sid * kPathSlots + sub], rows[src * kRowStride + sub]);
+		if (((actMask >> src) & 1ull) && (MG_SHADE_ALL_SLOTS || (sub != 2u && sub != 7u))) st_stream<4>(&ps.base[(size_t) sid * kPathSlots + sub], rows[shade_row_index(src, sub)]);
 	}
 
 	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue.
-	// ballot + prefix popcount inside each wave, an LDS scan across the 8 waves, ONE atomic per
-	// workgroup and queue (a queue counter is a single word: every atomic on it serialises)
+	// ballot + prefix popcount inside each wave, an LDS scan across the waves, ONE atomic per workgroup and queue
+	// (a queue counter is a single word: every atomic on it serialises, which is why the workgroups are as large as
+	// they can be: 1024 threads, 43.6 -> 41.9 ms per 64-spp frame against 512).  Measured and rejected: both queues
+	// reserved with one 64-bit atomic on a shared word (43.4 ms); the reservation issued before the records are written
+	// back so that its round trip hides under those stores (45 ms: the extra barrier delays the stores of every wave)
 	const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
 	const unsigned long long mN = __ballot(continues), mS = __ballot(wantShadow);
 	if (lane == 0) { s_cnt[0][wave] = (uint32_t) __popcll(mN); s_cnt[1][wave] = (uint32_t) __popcll(mS); }
@@ -2090,7 +2113,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DScene sc, DPaths ps, DCo
 	if (threadIdx.x < 2) {
 		uint32_t total = 0;
 		for (int w = 0; w < kShadeBlock / 64; ++w) total += s_cnt[threadIdx.x][w];
-		s_base[threadIdx.x] = total ? atomicAdd(&q.counters[(kCntNext + threadIdx.x) * kCounterStride], total) : 0u;
+		s_base[threadIdx.x] = total ? atomicAdd(&q.counters[threadIdx.x == 0 ? kNextWord : kShadowWord], total) : 0u;
 	}
 	__syncthreads();
 	uint32_t offN = s_base[0], offS = s_base[1];
