@@ -1497,6 +1497,7 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 		XNodeG *nodes = dAll.p + levelBase;
 		hipLaunchKernelGGL(k_x_prep, grid(nA), dim3(B), 0, st, nodes, (uint32_t) nA, prm);
 		const size_t nEv = 6 * nInst;
+		if (nEv >= (1ull << 32)) throw std::runtime_error("kd-tree build (device exact phase): more than 2^32 edge events in one level");
 		if (nInst) {
 			dKeysA.reserve(nEv); dKeysB.reserve(nEv); dValsA.reserve(nEv); dValsB.reserve(nEv);
 			for (int k = 4; k < 12; ++k) dU[k].reserve(nEv + 1);

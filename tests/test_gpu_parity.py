@@ -195,7 +195,7 @@ def test_fuzz_scenes(gpu_lib, mts, orc, seed):
     sd = mts.scenes.fuzz(seed)
     kp = mts.abi.KdParams()
     if seed % 3 == 0: kp.exact_prim_threshold = 64                      # min-max binning phase too (on the device for seed % 6 == 0)
-    scene = mts.Scene(sd, kd_params=kp, gpu_binning=(seed % 6 == 0)); oscene = orc.FlatScene(sd, kd_params=kp)
+    scene = mts.Scene(sd, kd_params=kp, gpu_binning=(seed % 6 == 0), gpu_exact=(seed % 4 == 1)); oscene = orc.FlatScene(sd, kd_params=kp)
     a, b = scene.arrays(), oscene.arrays()
     for k in ("kd_nodes", "kd_indices", "triaccel", "vtx_nrm", "lum_tri_cdf"):
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k

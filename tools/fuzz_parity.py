@@ -19,7 +19,7 @@ for seed in range(first, first + count):
     sd = mts.scenes.fuzz(seed, n_meshes=6 + seed % 25)
     kp = mts.abi.KdParams()
     if seed % 3 == 0: kp.exact_prim_threshold = 32 + seed % 100
-    scene = mts.Scene(sd, kd_params=kp, gpu_binning=(seed % 2 == 0)); oscene = orc.FlatScene(sd, kd_params=kp)
+    scene = mts.Scene(sd, kd_params=kp, gpu_binning=(seed % 2 == 0), gpu_exact=(seed % 4 < 2)); oscene = orc.FlatScene(sd, kd_params=kp)
     a, b = scene.arrays(), oscene.arrays()
     same = all(np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)) for k in ("kd_nodes", "kd_indices", "triaccel", "vtx_nrm"))
     cam = mts.PerspectiveCamera.for_description(sd, W, H); ocam = orc.make_camera(sd, W, H)
