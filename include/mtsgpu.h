@@ -339,6 +339,12 @@ int  mtsgpu_ld_tables(mtsgpu_ctx *ctx, uint32_t pixel_key, float *out1d, float *
  * the plugins under src/samplers).  With the halton / hammersley samplers these are the reference's own numbers: the tables of
  * src/tests/test_samplers.cpp:33-78 are checked against this call.  n <= 4096. */
 int  mtsgpu_sampler_values(mtsgpu_ctx *ctx, uint32_t pixel_key, uint32_t sample_index, uint32_t n, int two_d, float *out);
+/* The reference's `Random` (MT19937-64, src/libcore/random.cpp:99-227, random.h:82-148) run on the device, one generator:
+ * seed == 0 is a default-constructed Random (seed 5489), otherwise Random::seed(seed); clone > 0 takes the clone-th
+ * Random(Random *) copy of it (random.cpp:105-110), the way per-worker samplers are made.  op 0: n x nextULong();
+ * 1: n x nextFloat() as bit patterns; 2: n x nextSize(arg); 3: Random::shuffle of 0 .. n-1.  A test hook: the library's
+ * samplers draw from keyed streams; this pins the generator itself to the reference's known answers. */
+int  mtsgpu_random_values(mtsgpu_ctx *ctx, int op, uint64_t seed, uint64_t arg, uint32_t clone, uint32_t n, uint64_t *out);
 /* MIPathTracer::Li for explicit camera samples: in [n][3] u32 = pixel x, y, sample index;
  * out [n][8] f32 = Li rgb, alpha, raster x, raster y, depth, unused */
 int  mtsgpu_li_samples(mtsgpu_ctx *ctx, const uint32_t *pix_samples, uint32_t n, float *out);

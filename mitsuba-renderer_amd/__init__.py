@@ -29,7 +29,7 @@ EXPORTS = [
     "mtsgpu_read_film", "mtsgpu_clear_film", "mtsgpu_get_stats", "mtsgpu_trace_rays", "mtsgpu_ld_tables",
     "mtsgpu_li_samples", "mtsgpu_flatten", "mtsgpu_flat_scene_get", "mtsgpu_flat_scene_free",
     "mtsgpu_flat_scene_kdstats", "mtsgpu_make_camera", "mtsgpu_make_camera_ortho", "mtsgpu_load_serialized", "mtsgpu_loaded_mesh_free",
-    "mtsgpu_make_camera_crop", "mtsgpu_hbm_triad", "mtsgpu_sampler_values", "mtsgpu_set_tuning", "mtsgpu_gather_roof",
+    "mtsgpu_make_camera_crop", "mtsgpu_hbm_triad", "mtsgpu_sampler_values", "mtsgpu_random_values", "mtsgpu_set_tuning", "mtsgpu_gather_roof",
     "mtsgpu_create_multi", "mtsgpu_group_destroy", "mtsgpu_group_size", "mtsgpu_group_ctx", "mtsgpu_group_last_error",
     "mtsgpu_group_upload_scene", "mtsgpu_group_set_camera", "mtsgpu_group_set_integrator", "mtsgpu_group_set_sampler",
     "mtsgpu_group_set_rfilter", "mtsgpu_group_render", "mtsgpu_group_last_reduce_kind",
@@ -113,6 +113,7 @@ def lib():
     L.mtsgpu_gather_roof.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_double)]
     L.mtsgpu_set_tuning.argtypes = [vp, C.c_char_p, C.c_long]
     L.mtsgpu_sampler_values.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, f32p]
+    L.mtsgpu_random_values.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.mtsgpu_hbm_triad.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.mtsgpu_create_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     L.mtsgpu_group_destroy.argtypes = [vp]; L.mtsgpu_group_destroy.restype = None
@@ -350,6 +351,13 @@ class MIPathTracer:
         out = np.zeros((n, 2) if two_d else (n,), dtype=np.float32)
         self._chk(lib().mtsgpu_sampler_values(self._ctx, int(pixel_key), int(sample_index), int(n), int(bool(two_d)),
                                               abi.ptr(out, abi.f32p)), "sampler_values")
+        return out
+
+    def random_values(self, op, n, seed=0, arg=0, clone=0):
+        """the reference's Random (MT19937-64) on the device: op 0 nextULong, 1 nextFloat bits, 2 nextSize(arg), 3 shuffle(0..n-1)"""
+        out = np.zeros(n, dtype=np.uint64)
+        self._chk(lib().mtsgpu_random_values(self._ctx, int(op), int(seed), int(arg), int(clone), int(n),
+                                             out.ctypes.data_as(C.POINTER(C.c_uint64))), "random_values")
         return out
 
     def li_samples(self, pix_samples):

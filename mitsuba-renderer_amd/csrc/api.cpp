@@ -1238,6 +1238,24 @@ int mtsgpu_ld_tables(mtsgpu_ctx *c, uint32_t pixel_key, float *out1d, float *out
 	return 0;
 }
 
+int mtsgpu_random_values(mtsgpu_ctx *c, int op, uint64_t seed, uint64_t arg, uint32_t clone, uint32_t n, uint64_t *out) {
+	if (!c || !out) return fail(c, MTSGPU_EINVAL, "null argument");
+	if (op < 0 || op > 3 || n == 0 || n > (1u << 20) || clone > 64 || (op == 2 && arg == 0)) return fail(c, MTSGPU_EINVAL, "bad Random request");
+	HIPCHK(c, hipSetDevice(c->device));
+	void *state = nullptr; unsigned long long *dOut = nullptr;
+	HIPCHK(c, hipMalloc(&state, random_state_bytes()));
+	hipError_t e = hipMalloc((void **) &dOut, (size_t) n * sizeof(unsigned long long));
+	if (e == hipSuccess) {
+		launch_random_values(c->stream, state, op, seed, arg, clone, n, dOut);
+		e = hipGetLastError();
+		if (e == hipSuccess) e = hipMemcpyAsync(out, dOut, (size_t) n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	}
+	(void) hipFree(state); if (dOut) (void) hipFree(dOut);
+	if (e != hipSuccess) return fail(c, MTSGPU_EHIP, "Random on the device: %s", hipGetErrorString(e));
+	return 0;
+}
+
 int mtsgpu_sampler_values(mtsgpu_ctx *c, uint32_t pixel_key, uint32_t sample_index, uint32_t n, int two_d, float *out) {
 	if (!c || !out) return fail(c, MTSGPU_EINVAL, "null argument");
 	if (n == 0) return 0;

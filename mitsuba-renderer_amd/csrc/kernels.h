@@ -234,6 +234,10 @@ void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_k
 // the requested sample arrays of the table-based samplers (ldsampler.cpp:152-153, stratified.cpp:136-138), continuing
 // that stream; writes cfg.arr_scr / arr_perm / arr_pts
 void launch_sample_arrays(hipStream_t s, const DConfig &cfg, uint32_t n_slots, const unsigned long long *state_in);
+// the reference's Random (MT19937-64) on the device, one generator: see k_random_values
+void launch_random_values(hipStream_t s, void *state, int op, unsigned long long seed, unsigned long long arg, uint32_t clone, uint32_t n,
+                          unsigned long long *out);
+size_t random_state_bytes();
 void launch_sampler_values(hipStream_t s, const DConfig &cfg, uint32_t pixel_key, uint32_t j, uint32_t n, int two_d, float *out);
 void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg,
                      const uint32_t *pixel_list, uint32_t n_slots, const uint32_t *explicit_samples,

@@ -285,6 +285,104 @@ __global__ void k_sampler_values(DConfig cfg, uint32_t pixel_key, uint32_t j, ui
 }
 
 // ===========================================================================
+// Random (src/libcore/random.cpp:99-227, include/mitsuba/core/random.h:82-148): the reference's MT19937-64 generator as
+// it stands, on the device.  The samplers of this library draw from keyed streams instead (one sequential stream per
+// worker cannot feed a wavefront); this generator is what a Mitsuba `Random` object is, one lane
+// per object, and is pinned by the reference's known answers (mtsgpu_random_values, tests/test_gpu_round2.py).
+// ===========================================================================
+struct MtRandom { uint64_t mt[312]; int mti; };
+__device__ inline void mt_seed(MtRandom &r, uint64_t s) {                     // random.cpp:99-103
+	r.mt[0] = s;
+	for (r.mti = 1; r.mti < 312; r.mti++)
+		r.mt[r.mti] = 6364136223846793005ULL * (r.mt[r.mti - 1] ^ (r.mt[r.mti - 1] >> 62)) + (uint64_t) r.mti;
+}
+__device__ inline void mt_seed_array(MtRandom &r, const uint64_t *init_key, uint64_t key_length) {     // random.cpp:118-140
+	uint64_t *mt = r.mt;
+	mt_seed(r, 19650218ULL);
+	uint64_t i = 1, j = 0, k = (312 > key_length ? 312 : key_length);
+	for (; k; k--) {
+		mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 62)) * 3935559000370003845ULL)) + init_key[j] + j;
+		i++; j++;
+		if (i >= 312) { mt[0] = mt[311]; i = 1; }
+		if (j >= key_length) j = 0;
+	}
+	for (k = 311; k; k--) {
+		mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 62)) * 2862933555777941757ULL)) - i;
+		i++;
+		if (i >= 312) { mt[0] = mt[311]; i = 1; }
+	}
+	mt[0] = 1ULL << 63;
+}
+__device__ inline uint64_t mt_next_ulong(MtRandom &r) {                       // random.cpp:143-178
+	const uint64_t MATRIX_A = 0xB5026F5AA96619E9ULL, UM = 0xFFFFFFFF80000000ULL, LM = 0x7FFFFFFFULL;
+	uint64_t *mt = r.mt;
+	uint64_t x;
+	if (r.mti >= 312) {
+		if (r.mti == 313) mt_seed(r, 5489ULL);         // a default-constructed Random
+		int i;
+		for (i = 0; i < 312 - 156; i++) {
+			x = (mt[i] & UM) | (mt[i + 1] & LM);
+			mt[i] = mt[i + 156] ^ (x >> 1) ^ ((x & 1ULL) ? MATRIX_A : 0ULL);
+		}
+		for (; i < 311; i++) {
+			x = (mt[i] & UM) | (mt[i + 1] & LM);
+			mt[i] = mt[i + (156 - 312)] ^ (x >> 1) ^ ((x & 1ULL) ? MATRIX_A : 0ULL);
+		}
+		x = (mt[311] & UM) | (mt[0] & LM);
+		mt[311] = mt[155] ^ (x >> 1) ^ ((x & 1ULL) ? MATRIX_A : 0ULL);
+		r.mti = 0;
+	}
+	x = mt[r.mti++];
+	x ^= (x >> 29) & 0x5555555555555555ULL;
+	x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+	x ^= (x << 37) & 0xFFF7EEE000000000ULL;
+	x ^= (x >> 43);
+	return x;
+}
+__device__ inline uint64_t mt_next_size(MtRandom &r, uint64_t n) {            // random.cpp:196-215: bit mask + rejection
+	uint64_t bitmask = n;
+	bitmask |= bitmask >> 1; bitmask |= bitmask >> 2; bitmask |= bitmask >> 4;
+	bitmask |= bitmask >> 8; bitmask |= bitmask >> 16; bitmask |= bitmask >> 32;
+	uint64_t result;
+	while ((result = (mt_next_ulong(r) & bitmask)) >= n) { }
+	return result;
+}
+// op 0: n x nextULong; 1: n x nextFloat (bit patterns); 2: n x nextSize(arg); 3: shuffle of 0 .. n-1 (random.h:145-148);
+// seed == 0: a default-constructed Random, otherwise Random::seed(seed); clone > 0: the clone-th Random(Random *) copy
+// of that generator (random.cpp:105-110: 312 draws from the parent, init_by_array), as the per-worker samplers are made
+__global__ void k_random_values(MtRandom *state, int op, unsigned long long seed, unsigned long long arg, uint32_t clone, uint32_t n,
+                                unsigned long long *out) {
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+	MtRandom &r = state[0], &child = state[1];
+	if (seed) mt_seed(r, seed); else r.mti = 313;
+	MtRandom *g = &r;
+	for (uint32_t c = 0; c < clone; ++c) {
+		uint64_t *buf = reinterpret_cast<uint64_t *>(state + 2);
+		for (int i = 0; i < 312; ++i) buf[i] = mt_next_ulong(r);
+		mt_seed_array(child, buf, 312);
+		g = &child;
+	}
+	if (op == 3) {
+		for (uint32_t i = 0; i < n; ++i) out[i] = i;
+		for (uint32_t it = n ? n - 1 : 0; it > 0; --it) {
+			const uint64_t other = mt_next_size(*g, (uint64_t) it);
+			const unsigned long long t = out[it]; out[it] = out[other]; out[other] = t;
+		}
+		return;
+	}
+	for (uint32_t i = 0; i < n; ++i) {
+		if (op == 0) out[i] = mt_next_ulong(*g);
+		else if (op == 1) out[i] = (unsigned long long) __float_as_uint(ulongToFloat(mt_next_ulong(*g)));
+		else out[i] = mt_next_size(*g, arg);
+	}
+}
+void launch_random_values(hipStream_t s, void *state, int op, unsigned long long seed, unsigned long long arg, uint32_t clone, uint32_t n,
+                          unsigned long long *out) {
+	hipLaunchKernelGGL(k_random_values, dim3(1), dim3(64), 0, s, reinterpret_cast<MtRandom *>(state), op, seed, arg, clone, n, out);
+}
+size_t random_state_bytes() { return 3 * sizeof(MtRandom); }
+
+// ===========================================================================
 // K1: camera samples (integrator.cpp:154-166, perspective.cpp:77-112)
 // ===========================================================================
 __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pixel_list, uint32_t n_slots,

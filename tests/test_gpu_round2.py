@@ -375,3 +375,40 @@ def test_device_exact_phase_builds_the_same_tree(gpu_lib, mts, orc, case):
         if case != "c3_1M":                                                 # the oracle's own builder, same parameters
             oa = orc.FlatScene(sd, kd_params=params(**kw)).arrays()
             assert np.array_equal(oa["kd_nodes"], ha["kd_nodes"]) and np.array_equal(oa["kd_indices"], ha["kd_indices"])
+
+
+def test_device_random_is_the_reference_mt19937_64(gpu_lib, mts, orc):
+    """`Random` (src/libcore/random.cpp:99-227, random.h:82-148) on the device against the reference's known answers
+    directly (SURVEY.md 8c.1: values measured from the reference, and ISO C++ [rand.predef] for std::mt19937_64, which
+    the reference's generator is) -- no oracle in between -- and against the oracle's generator for long sequences"""
+    import orc as O
+    it = mts.MIPathTracer(maxDepth=4)
+    out = it.random_values(0, 10000)                                   # default-constructed Random: seed 5489
+    assert int(out[0]) == 14514284786278117030
+    assert int(out[9999]) == 9981545732273789042
+    assert np.array_equal(out, it.random_values(0, 10000, seed=5489))
+    bits = it.random_values(1, 2).astype(np.uint32)
+    assert [float(v).hex() for v in bits.view(np.float32)] == ["0x1.eded5c0000000p-1", "0x1.17901c0000000p-1"]
+    assert int(it.random_values(0, 1, clone=1)[0]) == 13719712115898985683      # Random(Random *) clone #0 of a fresh parent
+    assert it.random_values(3, 8).tolist() == [7, 3, 1, 5, 2, 0, 4, 6]        # Random::shuffle of 0..7
+    # the oracle's generator (pinned by the same numbers in tests/test_oracle_kats.py): other seeds, nextSize, clones
+    L = orc.lib()
+    for seed in (1, 0x5EED, 2 ** 63 + 12345):
+        r = O.Random(); r.mti = 313
+        L.orc_random_seed(C.byref(r), seed)
+        ref = [L.orc_random_next_ulong(C.byref(r)) for _ in range(1000)]
+        assert it.random_values(0, 1000, seed=seed).tolist() == ref
+    for n in (1, 2, 3, 1000, 2 ** 32 + 1):
+        r = O.Random(); r.mti = 313
+        ref = [L.orc_random_next_size(C.byref(r), n) for _ in range(300)]
+        assert it.random_values(2, 300, arg=n).tolist() == ref
+    parent = O.Random(); parent.mti = 313
+    for clone in (1, 2, 3):
+        child = O.Random(); child.mti = 313
+        L.orc_random_seed_from(C.byref(child), C.byref(parent))
+        ref = [L.orc_random_next_ulong(C.byref(child)) for _ in range(500)]
+        assert it.random_values(0, 500, clone=clone).tolist() == ref
+    r = O.Random(); r.mti = 313
+    a = np.arange(1000, dtype=np.uint32)
+    L.orc_random_shuffle_u32(C.byref(r), a.ctypes.data_as(C.POINTER(C.c_uint32)), 1000)
+    assert it.random_values(3, 1000).tolist() == a.tolist()

@@ -9,11 +9,12 @@ knobs = dict(a.split("=") for a in sys.argv[3:])
 if knobs.pop("debug", "0") == "1":
     os.environ["MTSGPU_DEBUG"] = "1"
 count = knobs.pop("count", "0") == "1"
+sampler = knobs.pop("sampler", "ldsampler")
 sd = pkg.scenes.cornell_c3()
 scene = pkg.Scene(sd, None, gpu_binning=True, gpu_exact=True)
 cam = pkg.PerspectiveCamera.for_description(sd, res, res)
 it = pkg.MIPathTracer(maxDepth=sd.max_depth)
-it.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp, seed=0x5EED)
+it.preprocess(scene, cam, sampler=sampler, sampleCount=spp, seed=0x5EED)
 if knobs:
     it.set_tuning(**{k: int(v) for k, v in knobs.items()})
 it.set_options(time_kernels=True, count_traversal=count)
