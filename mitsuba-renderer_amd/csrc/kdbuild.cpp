@@ -19,6 +19,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -1119,18 +1120,22 @@ __global__ void k_x_emit(const XInst *inst, uint32_t n, const XNodeG *nodes, uns
 		vals[6 * (size_t) i + 2 * a] = i; vals[6 * (size_t) i + 2 * a + 1] = i;
 	}
 }
-// per sorted event: its type as three counters, the (index + 1) of the event that opens its group, segment starts
-__global__ void k_x_flags(const unsigned long long *keys, uint32_t n, uint32_t *cE, uint32_t *cP, uint32_t *cS, uint32_t *head, uint32_t *segStart) {
+// per sorted event: the (index + 1) of the event that opens its group, and where the segments (node, axis) start; the
+// three per-type counters of the sweep are read off the keys by the scans themselves (XIsType)
+__global__ void k_x_flags(const unsigned long long *keys, uint32_t n, uint32_t *head, uint32_t *segStart) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const unsigned long long k = keys[i];
 	const bool valid = k != kXInvalid;
-	const uint32_t type = (uint32_t) (k & 3ull);
-	cE[i] = valid && type == kEnd; cP[i] = valid && type == kPlanar; cS[i] = valid && type == kStart;
 	const unsigned long long prev = i ? keys[i - 1] : kXInvalid;
 	head[i] = (valid && (i == 0 || (prev >> 2) != (k >> 2))) ? i + 1u : 0u;
 	if (valid && (i == 0 || (prev >> 34) != (k >> 34))) segStart[(uint32_t) (k >> 34)] = i;
 }
+
+struct XIsType {
+	uint32_t type;
+	__host__ __device__ uint32_t operator()(unsigned long long k) const { return (k != kXInvalid && (uint32_t) (k & 3ull) == type) ? 1u : 0u; }
+};
 
 // the candidate plane of the group of events that ends at sorted position i (gkdtree.h:1950-2016)
 struct XCand { bool valid; float cost, pos; uint32_t numLeft, numRight, planarLeft; int axis; uint32_t node; };
@@ -1361,6 +1366,14 @@ struct XScan {
 		tmp.reserve(bytes + 16);
 		KXHIP(rocprim::inclusive_scan((void *) tmp.p, bytes, in, out, n, rocprim::plus<uint32_t>(), st));
 	}
+	// inclusive count of the events of one type, straight from the sorted keys
+	void countType(const unsigned long long *keys, uint32_t type, uint32_t *out, size_t n, hipStream_t st) {
+		auto in = rocprim::make_transform_iterator(keys, XIsType{ type });
+		size_t bytes = 0;
+		KXHIP(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<uint32_t>(), st));
+		tmp.reserve(bytes + 16);
+		KXHIP(rocprim::inclusive_scan((void *) tmp.p, bytes, in, out, n, rocprim::plus<uint32_t>(), st));
+	}
 	void max(const uint32_t *in, uint32_t *out, size_t n, hipStream_t st) {
 		size_t bytes = 0;
 		KXHIP(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::maximum<uint32_t>(), st));
@@ -1464,9 +1477,9 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 			for (uint32_t prim : jobs[j]->prims) { hp[o] = prim; hn[o] = (uint32_t) j; ++o; }
 		// every buffer gets its size once, with room for the straddlers that are duplicated on the way down (a
 		// reallocation inside the level loop costs a device synchronisation; it still happens if a level outgrows this)
-		const size_t instCap = nInit + nInit / 2 + 1024;
-		for (int k = 0; k < 4; ++k) dU[k].reserve(instCap);
-		for (int k = 4; k < 12; ++k) dU[k].reserve(6 * instCap);
+		const size_t instCap = nInit + nInit / 4 + 1024;
+		for (int k = 0; k < 6; ++k) dU[k].reserve(instCap);
+		for (int k = 7; k < 12; ++k) dU[k].reserve(6 * instCap);
 		dInstA.reserve(instCap); dInstB.reserve(instCap);
 		dKeysA.reserve(6 * instCap); dKeysB.reserve(6 * instCap); dValsA.reserve(6 * instCap); dValsB.reserve(6 * instCap);
 		dBoxL.reserve(6 * instCap); dBoxR.reserve(6 * instCap);
@@ -1500,7 +1513,7 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 		if (nEv >= (1ull << 32)) throw std::runtime_error("kd-tree build (device exact phase): more than 2^32 edge events in one level");
 		if (nInst) {
 			dKeysA.reserve(nEv); dKeysB.reserve(nEv); dValsA.reserve(nEv); dValsB.reserve(nEv);
-			for (int k = 4; k < 12; ++k) dU[k].reserve(nEv + 1);
+			for (int k = 7; k < 12; ++k) dU[k].reserve(nEv + 1);
 			dSegStart.reserve(4 * nA); dNodeBest.reserve(nA);
 			hipLaunchKernelGGL(k_x_emit, grid(nInst), dim3(B), 0, st, dInstA.p, (uint32_t) nInst, nodes, dKeysA.p, dValsA.p);
 			{
@@ -1513,11 +1526,12 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 				dSortTmp.reserve(bytes + 16);
 				KXHIP(rocprim::radix_sort_pairs((void *) dSortTmp.p, bytes, dKeysA.p, dKeysB.p, dValsA.p, dValsB.p, nEv, 0u, endBit, st));
 			}
-			uint32_t *cE = dU[4].p, *cP = dU[5].p, *cS = dU[6].p, *hd = dU[7].p, *sE = dU[8].p, *sP = dU[9].p, *sS = dU[10].p, *sH = dU[11].p;
+			uint32_t *hd = dU[7].p, *sE = dU[8].p, *sP = dU[9].p, *sS = dU[10].p, *sH = dU[11].p;
 			KXHIP(hipMemsetAsync(dSegStart.p, 0, 4 * nA * sizeof(uint32_t), st));
 			KXHIP(hipMemsetAsync(dNodeBest.p, 0xFF, nA * sizeof(unsigned long long), st));
-			hipLaunchKernelGGL(k_x_flags, grid(nEv), dim3(B), 0, st, dKeysB.p, (uint32_t) nEv, cE, cP, cS, hd, dSegStart.p);
-			scan.sum(cE, sE, nEv, st); scan.sum(cP, sP, nEv, st); scan.sum(cS, sS, nEv, st); scan.max(hd, sH, nEv, st);
+			hipLaunchKernelGGL(k_x_flags, grid(nEv), dim3(B), 0, st, dKeysB.p, (uint32_t) nEv, hd, dSegStart.p);
+			scan.countType(dKeysB.p, kEnd, sE, nEv, st); scan.countType(dKeysB.p, kPlanar, sP, nEv, st); scan.countType(dKeysB.p, kStart, sS, nEv, st);
+			scan.max(hd, sH, nEv, st);
 			hipLaunchKernelGGL(k_x_cost, grid(nEv), dim3(B), 0, st, dKeysB.p, dValsB.p, (uint32_t) nEv, sE, sP, sS, sH, dSegStart.p, dInstA.p, nodes, prm, dNodeBest.p);
 			hipLaunchKernelGGL(k_x_decide, grid(nA), dim3(B), 0, st, nodes, (uint32_t) nA, dNodeBest.p, dKeysB.p, dValsB.p, sE, sP, sS, sH, dSegStart.p, dInstA.p, prm);
 		}
