@@ -345,6 +345,16 @@ int  mtsgpu_sampler_values(mtsgpu_ctx *ctx, uint32_t pixel_key, uint32_t sample_
  * 1: n x nextFloat() as bit patterns; 2: n x nextSize(arg); 3: Random::shuffle of 0 .. n-1.  A test hook: the library's
  * samplers draw from keyed streams; this pins the generator itself to the reference's known answers. */
 int  mtsgpu_random_values(mtsgpu_ctx *ctx, int op, uint64_t seed, uint64_t arg, uint32_t clone, uint32_t n, uint64_t *out);
+/* The BSDF plugins as the device runs them, for n query records of ONE parameter block (bsdf_type may carry
+ * MTSGPU_BSDF_TWOSIDED; params[MTSGPU_BSDF_NPARAMS] as in the enum above).  queries [n][6], out [n][8]:
+ *   op 0  BSDF::f(bRec)               queries = wi.xyz, wo.xyz      out = f.rgb
+ *   op 1  BSDF::pdf(bRec)             queries = wi.xyz, wo.xyz      out = pdf
+ *   op 2  BSDF::sample(bRec, pdf, s)  queries = wi.xyz, s.x, s.y, - out = wo.xyz, pdf, f.rgb, sampledType (bit pattern)
+ *         (src/librender/bsdf.cpp:37-48 for the plugins that do not override it; f = 0 and pdf = 0 for a failed sample)
+ * wi / wo are in the local shading frame (include/mitsuba/render/bsdf.h:34-132).  A test hook: the chi-square
+ * procedure of the reference (src/tests/test_chisquare.cpp:299-420 with the BSDFs of data/tests/test_bsdf.xml) runs
+ * against these values, i.e. against the code k_shade executes, with no CPU restatement in between. */
+int  mtsgpu_bsdf_eval(mtsgpu_ctx *ctx, uint32_t bsdf_type, const float *params, int op, uint32_t n, const float *queries, float *out);
 /* MIPathTracer::Li for explicit camera samples: in [n][3] u32 = pixel x, y, sample index;
  * out [n][8] f32 = Li rgb, alpha, raster x, raster y, depth, unused */
 int  mtsgpu_li_samples(mtsgpu_ctx *ctx, const uint32_t *pix_samples, uint32_t n, float *out);

@@ -32,7 +32,7 @@ EXPORTS = [
     "mtsgpu_make_camera_crop", "mtsgpu_hbm_triad", "mtsgpu_sampler_values", "mtsgpu_random_values", "mtsgpu_set_tuning", "mtsgpu_gather_roof",
     "mtsgpu_create_multi", "mtsgpu_group_destroy", "mtsgpu_group_size", "mtsgpu_group_ctx", "mtsgpu_group_last_error",
     "mtsgpu_group_upload_scene", "mtsgpu_group_set_camera", "mtsgpu_group_set_integrator", "mtsgpu_group_set_sampler",
-    "mtsgpu_group_set_rfilter", "mtsgpu_group_render", "mtsgpu_group_last_reduce_kind",
+    "mtsgpu_group_set_rfilter", "mtsgpu_group_render", "mtsgpu_group_last_reduce_kind", "mtsgpu_bsdf_eval",
 ]
 
 
@@ -114,6 +114,7 @@ def lib():
     L.mtsgpu_set_tuning.argtypes = [vp, C.c_char_p, C.c_long]
     L.mtsgpu_sampler_values.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, f32p]
     L.mtsgpu_random_values.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.mtsgpu_bsdf_eval.argtypes = [vp, C.c_uint32, f32p, C.c_int, C.c_uint32, f32p, f32p]
     L.mtsgpu_hbm_triad.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.mtsgpu_create_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     L.mtsgpu_group_destroy.argtypes = [vp]; L.mtsgpu_group_destroy.restype = None
@@ -358,6 +359,20 @@ class MIPathTracer:
         out = np.zeros(n, dtype=np.uint64)
         self._chk(lib().mtsgpu_random_values(self._ctx, int(op), int(seed), int(arg), int(clone), int(n),
                                              out.ctypes.data_as(C.POINTER(C.c_uint64))), "random_values")
+        return out
+
+    def bsdf_eval(self, bsdf_type, params, op, wi, aux):
+        """BSDF::f (op 0), pdf (1), sample(bRec, pdf, sample) (2) on the device for n query records (mtsgpu_bsdf_eval):
+        wi [n][3] or [3]; aux = wo [n][3] (op 0, 1) or the 2D sample [n][2] (op 2).  Returns [n][8]."""
+        aux = np.atleast_2d(np.asarray(aux, dtype=np.float32))
+        n = aux.shape[0]
+        q = np.zeros((n, 6), dtype=np.float32)
+        q[:, :3] = np.asarray(wi, dtype=np.float32).reshape(-1, 3)
+        q[:, 3:3 + aux.shape[1]] = aux
+        P = np.zeros(abi.BSDF_NPARAMS, dtype=np.float32); P[:len(params)] = params
+        out = np.zeros((n, 8), dtype=np.float32)
+        self._chk(lib().mtsgpu_bsdf_eval(self._ctx, int(bsdf_type), abi.ptr(P, abi.f32p), int(op), n, abi.ptr(q, abi.f32p),
+                                         abi.ptr(out, abi.f32p)), "bsdf_eval")
         return out
 
     def li_samples(self, pix_samples):

@@ -1286,6 +1286,28 @@ int mtsgpu_sampler_values(mtsgpu_ctx *c, uint32_t pixel_key, uint32_t sample_ind
 	return 0;
 }
 
+int mtsgpu_bsdf_eval(mtsgpu_ctx *c, uint32_t bsdf_type, const float *params, int op, uint32_t n, const float *queries, float *out) {
+	if (!c || !params || !queries || !out) return fail(c, MTSGPU_EINVAL, "null argument");
+	if ((bsdf_type & 0xFFu) >= (uint32_t) MTSGPU_BSDF_NTYPES || (bsdf_type & ~(0xFFu | (uint32_t) MTSGPU_BSDF_TWOSIDED)) || op < 0 || op > 2)
+		return fail(c, MTSGPU_EINVAL, "bad BSDF type or operation");
+	if (n == 0) return 0;
+	if (n > (1u << 24)) return fail(c, MTSGPU_EINVAL, "at most 2^24 query records per call");
+	HIPCHK(c, hipSetDevice(c->device));
+	float *dQ = nullptr, *dOut = nullptr;
+	HIPCHK(c, hipMalloc((void **) &dQ, (size_t) n * 6 * sizeof(float)));
+	hipError_t e = hipMalloc((void **) &dOut, (size_t) n * 8 * sizeof(float));
+	if (e == hipSuccess) e = hipMemcpyAsync(dQ, queries, (size_t) n * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) {
+		launch_bsdf_eval(c->stream, bsdf_type, params, op, n, dQ, dOut);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(out, dOut, (size_t) n * 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	(void) hipFree(dQ); if (dOut) (void) hipFree(dOut);
+	if (e != hipSuccess) return fail(c, MTSGPU_EHIP, "BSDF read-out failed: %s", hipGetErrorString(e));
+	return 0;
+}
+
 int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, float *out) {
 	int rc = checkReady(c); if (rc) return rc;
 	if (!pix_samples || !out) return fail(c, MTSGPU_EINVAL, "null argument");

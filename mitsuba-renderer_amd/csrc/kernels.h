@@ -14,6 +14,7 @@ constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 constexpr int kTriStride = 8;         // float4 per primitive record: one 128-byte line holds positions AND normals
 constexpr int kLumStride = 32;        // MTSGPU_LUM_NPARAMS
 constexpr int kCounterStride = 32;    // one 128-byte line per queue counter (atomics on one line serialise)
+constexpr int kBsdfNParams = 16;      // MTSGPU_BSDF_NPARAMS
 constexpr int kBinShards = 16;        // the closest-hit kernel appends to bins[b] through 16 independent segments
 constexpr int kNumCounters = kNumBins * kBinShards + 4;   // bins x shards, next, shadow, dynamic heads of the two traversal launches
 // Two sets of counters, used by alternate bounces: the shadow rays of bounce b are traced (second stream) while the
@@ -239,6 +240,8 @@ void launch_random_values(hipStream_t s, void *state, int op, unsigned long long
                           unsigned long long *out);
 size_t random_state_bytes();
 void launch_sampler_values(hipStream_t s, const DConfig &cfg, uint32_t pixel_key, uint32_t j, uint32_t n, int two_d, float *out);
+// BSDF::f (op 0), pdf (1), sample(bRec, pdf, sample) (2) for n query records [n][6] of one parameter block; out [n][8]
+void launch_bsdf_eval(hipStream_t s, uint32_t type, const float *params, int op, uint32_t n, const float *queries, float *out);
 void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg,
                      const uint32_t *pixel_list, uint32_t n_slots, const uint32_t *explicit_samples,
                      uint32_t n_paths, uint32_t *queue);

@@ -1879,6 +1879,44 @@ template <int BT> struct Bsdf2 {
 	}
 };
 
+// BSDF::f / BSDF::pdf / BSDF::sample(bRec, pdf, sample) read out for tests (mtsgpu_bsdf_eval): the chi-square procedure of
+// src/tests/test_chisquare.cpp:299-420 runs against exactly the code k_shade runs.  One query record per thread:
+// wi = q[i][0..2]; op 0 / 1: wo = q[i][3..5]; op 2: sample = q[i][3..4].
+template <int BT>
+__device__ __forceinline__ void bsdf_eval_one(bool two, const float *P, int op, const float *q, float *o) {
+	const V3 wi(q[0], q[1], q[2]);
+	if (op == 0) {
+		const V3 f = Bsdf2<BT>::f(two, P, wi, V3(q[3], q[4], q[5]));
+		o[0] = f.x; o[1] = f.y; o[2] = f.z;
+	} else if (op == 1) {
+		o[0] = Bsdf2<BT>::pdf(two, P, wi, V3(q[3], q[4], q[5]));
+	} else {
+		V3 wo; float pdf; uint32_t st;
+		const V3 f = Bsdf2<BT>::sample(two, P, wi, q[3], q[4], wo, pdf, st);
+		o[0] = wo.x; o[1] = wo.y; o[2] = wo.z; o[3] = pdf; o[4] = f.x; o[5] = f.y; o[6] = f.z; o[7] = __uint_as_float(st);
+	}
+}
+struct BsdfParams { float v[kBsdfNParams]; };
+__global__ void k_bsdf_eval(uint32_t type, BsdfParams params, int op, uint32_t n, const float *queries, float *out) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const bool two = (type & 0x100u) != 0;
+	const float *P = params.v, *q = queries + 6 * (size_t) i;
+	float o[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	switch (type & 0xFFu) {
+		case 0: bsdf_eval_one<0>(two, P, op, q, o); break;
+		case 1: bsdf_eval_one<1>(two, P, op, q, o); break;
+		case 2: bsdf_eval_one<2>(two, P, op, q, o); break;
+		case 3: bsdf_eval_one<3>(two, P, op, q, o); break;
+		case 4: bsdf_eval_one<4>(two, P, op, q, o); break;
+		case 5: bsdf_eval_one<5>(two, P, op, q, o); break;
+		case 6: bsdf_eval_one<6>(two, P, op, q, o); break;
+		default: bsdf_eval_one<7>(two, P, op, q, o); break;
+	}
+	#pragma unroll
+	for (int k = 0; k < 8; ++k) out[8 * (size_t) i + k] = o[k];
+}
+
 __device__ __forceinline__ float mi_weight(float pdfA, float pdfB) {     // path.cpp:218-222
 	pdfA *= pdfA;
 	pdfB *= pdfB;
@@ -2427,6 +2465,12 @@ void launch_sample_arrays(hipStream_t s, const DConfig &cfg, uint32_t n_slots, c
 
 void launch_sampler_values(hipStream_t s, const DConfig &cfg, uint32_t pixel_key, uint32_t j, uint32_t n, int two_d, float *out) {
 	hipLaunchKernelGGL(k_sampler_values, dim3(1), dim3(64), 0, s, cfg, pixel_key, j, n, two_d, out);
+}
+
+void launch_bsdf_eval(hipStream_t s, uint32_t type, const float *params, int op, uint32_t n, const float *queries, float *out) {
+	BsdfParams p;
+	for (int k = 0; k < kBsdfNParams; ++k) p.v[k] = params[k];
+	if (n) hipLaunchKernelGGL(k_bsdf_eval, dim3(blocks_for(n, 256)), dim3(256), 0, s, type, p, op, n, queries, out);
 }
 
 void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg,

@@ -158,6 +158,7 @@ void orc_render_tiles(const mtsgpu_scene *sc, const mtsgpu_camera *cam, const or
 void  orc_bsdf_f(uint32_t type, const float *params, const float wi[3], const float wo[3], float out[3]);
 float orc_bsdf_pdf(uint32_t type, const float *params, const float wi[3], const float wo[3]);
 /* sample(bRec, pdf, sample): returns f (not divided), fills wo, pdf, sampledType */
+void  orc_bsdf_eval(uint32_t type, const float *params, int op, uint32_t n, const float *queries, float *out);
 void  orc_bsdf_sample(uint32_t type, const float *params, const float wi[3], const float s[2],
                       float wo[3], float *pdf, uint32_t *sampled_type, float out[3]);
 

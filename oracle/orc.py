@@ -115,6 +115,7 @@ def lib():
     L.orc_luminaire_pdf.argtypes = [C.POINTER(abi.Scene), C.c_int, f32p, f32p, f32p, f32p]; L.orc_luminaire_pdf.restype = C.c_float
     L.orc_bsdf_f.argtypes = [C.c_uint32, f32p, f32p, f32p, f32p]
     L.orc_bsdf_pdf.argtypes = [C.c_uint32, f32p, f32p, f32p]; L.orc_bsdf_pdf.restype = C.c_float
+    L.orc_bsdf_eval.argtypes = [C.c_uint32, f32p, C.c_int, C.c_uint32, f32p, f32p]; L.orc_bsdf_eval.restype = None
     L.orc_bsdf_sample.argtypes = [C.c_uint32, f32p, f32p, f32p, f32p, f32p, u32p, f32p]
     _lib = L
     return L
@@ -183,6 +184,20 @@ def render(scene_ptr, cam, params, rect=None):
     x0, y0, x1, y1 = rect if rect else (0, 0, W, H)
     lib().orc_render_rect(scene_ptr, C.byref(cam), C.byref(params), x0, y0, x1, y1, abi.ptr(film, abi.f32p), C.byref(st))
     return film, st
+
+
+def bsdf_eval(bsdf_type, params, op, wi, aux):
+    """the oracle's BSDF::f (op 0) / pdf (1) / sample(bRec, pdf, sample) (2) for n query records, laid out like
+    mtsgpu_bsdf_eval: returns [n][8]"""
+    aux = np.atleast_2d(np.asarray(aux, dtype=np.float32))
+    n = aux.shape[0]
+    q = np.zeros((n, 6), dtype=np.float32)
+    q[:, :3] = np.asarray(wi, dtype=np.float32).reshape(-1, 3)
+    q[:, 3:3 + aux.shape[1]] = aux
+    P = np.zeros(abi.BSDF_NPARAMS, dtype=np.float32); P[:len(params)] = params
+    out = np.zeros((n, 8), dtype=np.float32)
+    lib().orc_bsdf_eval(int(bsdf_type), abi.ptr(P, abi.f32p), int(op), n, abi.ptr(q, abi.f32p), abi.ptr(out, abi.f32p))
+    return out
 
 
 def li_samples(scene_ptr, cam, params, pix_samples):

@@ -1236,6 +1236,26 @@ void orc_bsdf_sample(uint32_t type, const float *P, const float wi[3], const flo
 		wo[2] *= -1;
 }
 
+/* n query records of one parameter block, the layout of mtsgpu_bsdf_eval (include/mtsgpu.h): queries [n][6], out [n][8];
+ * op 0 f, 1 pdf, 2 sample(bRec, pdf, sample) -> wo, pdf, f, sampledType */
+void orc_bsdf_eval(uint32_t type, const float *P, int op, uint32_t n, const float *queries, float *out) {
+	#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t) n; ++i) {
+		const float *q = queries + 6 * i;
+		float *o = out + 8 * i;
+		for (int k = 0; k < 8; ++k) o[k] = 0.0f;
+		if (op == 0) {
+			orc_bsdf_f(type, P, q, q + 3, o);
+		} else if (op == 1) {
+			o[0] = orc_bsdf_pdf(type, P, q, q + 3);
+		} else {
+			uint32_t st = 0;
+			orc_bsdf_sample(type, P, q, q + 3, o, o + 3, &st, o + 4);
+			memcpy(o + 7, &st, 4);
+		}
+	}
+}
+
 /* BSDF::sample(bRec, pdf, sample): value NOT divided by pdf */
 static void bsdf_sample_base(uint32_t type, const float *P, const float wi[3], const float s[2],
                              float wo[3], float *pdf, uint32_t *stype, float out[3]) {
