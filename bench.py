@@ -19,6 +19,7 @@ worker processes itself (before anything touches a GPU) and prints rank 0's JSON
 
 One JSON line on rank 0 (see DESIGN.md section 8 for the definition of every field)."""
 import argparse
+import datetime
 import hashlib
 import json
 import os
@@ -217,15 +218,31 @@ def main():
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if shared_device:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        backend = "gloo" if shared_device else "nccl"
+        try:
+            # a rendezvous or communicator that cannot form must end the run with a reason, not hang it
+            kw = {} if shared_device else {"device_id": torch.device("cuda", device)}
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120), **kw)
+            probe = torch.ones(1, device="cpu" if shared_device else "cuda")
+            dist.all_reduce(probe)                       # first collective: RCCL builds its rings here
+            if not shared_device:
+                torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError("all_reduce of ones over %d ranks returned %s" % (world, probe.item()))
+        except Exception as e:
+            sys.stderr.write("bench.py rank %d/%d (device %d): torch.distributed backend %s failed: %s: %s\n"
+                             % (rank, world, device, backend, type(e).__name__, e))
+            sys.stderr.flush()
+            os._exit(3)
 
     # --- scene (host side: generate, flatten, upload; not timed) ---
     sd = pkg.scenes.cornell_c3(grid=args.grid, sphere_subdiv=5)
     t0 = time.time()
-    scene = pkg.Scene(sd, None, gpu_binning=not args.host_kd, gpu_exact=not args.host_kd)
+    # kd-tree build: the binning phase on the device; the exact phase there too from 2 M triangles up (below that its
+    # per-level launches cost more than the host's job pool: 0.157 s against 0.120 s at 1 M, profiles/r02e_kdbuild_bench.txt).
+    # The tree is the same bit for bit either way.
+    n_tris = 5 * 2 * args.grid * args.grid + 20480
+    scene = pkg.Scene(sd, None, gpu_binning=not args.host_kd, gpu_exact=(not args.host_kd) and n_tris > 2_000_000)
     flatten_s = time.time() - t0
     W = H = args.res
     strong = args.spp_total > 0
@@ -240,10 +257,14 @@ def main():
     it.set_film_buffer(film.data_ptr(), keepalive=film)
     host_film = torch.zeros((H, W, 5), dtype=torch.float32).pin_memory() if (world > 1 and shared_device) else None
 
+    split = {"render_s": 0.0, "reduce_s": 0.0}     # this rank's time inside the steps: its own frame, the film reduce
+
     def step():
+        t_a = time.perf_counter()
         film.zero_()
-        if not it.render():
+        if not it.render():                     # returns with the stream idle
             raise RuntimeError("render cancelled")
+        t_b = time.perf_counter()
         if world > 1:
             if shared_device:                   # test mode: two ranks on one GPU cannot form an RCCL communicator
                 host_film.copy_(film)
@@ -252,6 +273,9 @@ def main():
                     film.copy_(host_film)
             else:
                 pkg.filmreduce.reduce_film(film, dst=0)
+            torch.cuda.synchronize()            # the next step's film.zero_() would wait for the reduce anyway
+        split["render_s"] += t_b - t_a
+        split["reduce_s"] += time.perf_counter() - t_b
 
     def fence():
         torch.cuda.synchronize()
@@ -275,6 +299,7 @@ def main():
     trace_launches = 0
     shade_ms = 0.0
     fence()
+    split["render_s"] = split["reduce_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -282,10 +307,19 @@ def main():
         trace_ms += st["trace_ms"]; shade_ms += st["shade_ms"]; trace_launches += st["trace_launches"]
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = [split["render_s"] / args.steps * 1e3]
+    reduce_ms = [split["reduce_s"] / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_device else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own render time and the time it spent in the reduce (waiting for the slowest rank included):
+        # one SCALE run then tells load imbalance from collective cost
+        mine = torch.tensor([rank_ms[0], reduce_ms[0]], dtype=torch.float64, device="cpu" if shared_device else "cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(e[0].item()) for e in every]
+        reduce_ms = [float(e[1].item()) for e in every]
     if args.dump_film and rank == 0:
         np.save(args.dump_film, film.cpu().numpy())
 
@@ -343,6 +377,9 @@ def main():
                 "parallelism": "ImageBlock tiles, morton(tx, ty) %% %d + one RCCL film reduce per frame" % world,
                 "host_flatten_s": flatten_s,
             },
+            # per rank: ms per step of its own frame (film clear + all kernels), and of the film reduce that follows
+            # (it includes the wait for the slowest rank; on rank 0 also the receive)
+            "rank_ms": rank_ms, "reduce_ms": reduce_ms,
             "time_to_1spp_frame_ms": one_spp_ms,
             "avg_path_length": counts.get("avg_path_length"),
             "roofline": {
@@ -366,7 +403,7 @@ def main():
                 "algorithmic_requests_per_ray": req_per_step / max(rays, 1),
             },
             "roofline_shade": {
-                "kernel": "k_shade (one Li iteration per path: emitter hit, MIS, RR, NEE sample, BSDF sample) + k_generate + k_accumulate",
+                "kernel": "k_shade (one Li iteration per path: emitter hit, MIS, RR, NEE sample, BSDF sample); ms_per_step brackets the k_shade launches only",
                 "bound": "hbm", "achieved": sh_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sh_achieved / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_step": sh_bytes, "ms_per_step": shade_ms / args.steps,
             },

@@ -312,10 +312,17 @@ int  mtsgpu_group_set_integrator(mtsgpu_group *g, int max_depth, int rr_depth, i
 int  mtsgpu_group_set_sampler(mtsgpu_group *g, int kind, uint32_t spp, int ld_depth, uint64_t seed);
 int  mtsgpu_group_set_rfilter(mtsgpu_group *g, float size_x, float size_y, const float *values);
 /* block_size as in mtsgpu_set_tiles; ordered_reduce: 0 = RCCL when possible, 1 = always the ordered peer-copy sum,
- * 2 = RCCL or fail, also for a single member (self-test of the collective path on a one-GPU machine) */
+ * 2 = fail when RCCL cannot be initialised and run the collective also for a single member (self-test of the
+ * collective path on a one-GPU machine) */
 int  mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, volatile const int *cancel);
 /* 0 = ordered peer-copy sum, 1 = RCCL ncclReduce: what the last mtsgpu_group_render used */
 int  mtsgpu_group_last_reduce_kind(const mtsgpu_group *g);
+/* Why the last mtsgpu_group_render summed the films in member order although RCCL was asked for ("" when it did not have
+ * to): librccl could not be loaded (the environment variable MTSGPU_RCCL_LIB names the library to load), the
+ * communicator could not be created, or ncclReduce / ncclGroupEnd failed.  A failed collective does not lose the frame:
+ * its result is received in a staging buffer, the members' films stay as rendered, the group stops using RCCL and adds
+ * the films up in member order. */
+const char *mtsgpu_group_reduce_note(const mtsgpu_group *g);
 
 /* HBM triad a[i] = b[i] + s * c[i] over three arrays of `bytes` each on `device` (float4 lanes, best of `iters`
  * launches): the practical bandwidth roof next to the 8 TB/s specification.  GB/s in *gbs. */

@@ -32,7 +32,7 @@ EXPORTS = [
     "mtsgpu_make_camera_crop", "mtsgpu_hbm_triad", "mtsgpu_sampler_values", "mtsgpu_random_values", "mtsgpu_set_tuning", "mtsgpu_gather_roof",
     "mtsgpu_create_multi", "mtsgpu_group_destroy", "mtsgpu_group_size", "mtsgpu_group_ctx", "mtsgpu_group_last_error",
     "mtsgpu_group_upload_scene", "mtsgpu_group_set_camera", "mtsgpu_group_set_integrator", "mtsgpu_group_set_sampler",
-    "mtsgpu_group_set_rfilter", "mtsgpu_group_render", "mtsgpu_group_last_reduce_kind", "mtsgpu_bsdf_eval",
+    "mtsgpu_group_set_rfilter", "mtsgpu_group_render", "mtsgpu_group_last_reduce_kind", "mtsgpu_group_reduce_note", "mtsgpu_bsdf_eval",
 ]
 
 
@@ -128,6 +128,7 @@ def lib():
     L.mtsgpu_group_set_rfilter.argtypes = [vp, C.c_float, C.c_float, f32p]
     L.mtsgpu_group_render.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.mtsgpu_group_last_reduce_kind.argtypes = [vp]
+    L.mtsgpu_group_reduce_note.argtypes = [vp]; L.mtsgpu_group_reduce_note.restype = C.c_char_p
     _lib = L
     return L
 
@@ -440,8 +441,9 @@ class DeviceGroup:
         self._chk(lib().mtsgpu_group_set_rfilter(self._g, float(size[0]), float(size[1]), abi.ptr(values, abi.f32p)), "set_rfilter")
 
     def render(self, block_size=32, ordered_reduce=False):
+        """ordered_reduce: False / 0 = RCCL when possible, True / 1 = the ordered peer-copy sum, 2 = RCCL must initialise"""
         self._cancel.value = 0
-        rc = lib().mtsgpu_group_render(self._g, int(block_size), int(bool(ordered_reduce)), C.byref(self._cancel))
+        rc = lib().mtsgpu_group_render(self._g, int(block_size), int(ordered_reduce), C.byref(self._cancel))
         if rc == -4:
             return False
         self._chk(rc, "group_render")
@@ -452,6 +454,10 @@ class DeviceGroup:
 
     def reduce_kind(self):
         return {0: "ordered peer-copy sum", 1: "rccl ncclReduce"}.get(lib().mtsgpu_group_last_reduce_kind(self._g))
+
+    def reduce_note(self):
+        """why the last render fell back to the ordered sum ("" when it did not)"""
+        return lib().mtsgpu_group_reduce_note(self._g).decode()
 
     def film(self):
         out = np.zeros((self.camera.c.height, self.camera.c.width, 5), dtype=np.float32)

@@ -806,7 +806,20 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 				}
 			}
 		}
-		rc |= upload(c, (const uint32_t **) &d.leaf_ta, ta.data(), ta.size());
+		if (MG_LEAF_SPLIT) {
+			// heads (dwords 0..3) first, then the 32-byte tails: one allocation, two views
+			const size_t nE = (size_t) sc->n_indices + 1;
+			std::vector<uint32_t> split(12 * nE, 0u);
+			for (size_t e = 0; e < nE; ++e) {
+				std::memcpy(&split[4 * e], &ta[12 * e], 16);
+				std::memcpy(&split[4 * nE + 8 * e], &ta[12 * e + 4], 32);
+			}
+			rc |= upload(c, (const uint32_t **) &d.leaf_ta, split.data(), split.size());
+			d.leaf_tail = d.leaf_ta ? d.leaf_ta + nE : nullptr;
+		} else {
+			rc |= upload(c, (const uint32_t **) &d.leaf_ta, ta.data(), ta.size());
+			d.leaf_tail = d.leaf_ta;
+		}
 		// per-primitive position / normal records for the shading kernels
 		const size_t TS = 4 * (size_t) kTriStride;                    // floats per record (one 128-byte line)
 		std::vector<float> triRec(TS * ((size_t) sc->n_tris + 1), 0.0f);

@@ -31,11 +31,18 @@ struct Rccl {
 	decltype(&ncclGetErrorString) errorString = nullptr;
 
 	bool load(std::string &why) {
-		for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" }) {
-			handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-			if (handle) break;
+		// MTSGPU_RCCL_LIB names the library to load (a site's own build; tests point it at a file that does not exist to
+		// exercise the fallback); otherwise the usual sonames
+		const char *forced = getenv("MTSGPU_RCCL_LIB");
+		if (forced && *forced) {
+			handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+		} else {
+			for (const char *name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" }) {
+				handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+				if (handle) break;
+			}
 		}
-		if (!handle) { why = std::string("dlopen(librccl) failed: ") + dlerror(); return false; }
+		if (!handle) { const char *e = dlerror(); why = std::string("dlopen(") + (forced && *forced ? forced : "librccl") + ") failed: " + (e ? e : "?"); return false; }
 		commInitAll = (decltype(commInitAll)) dlsym(handle, "ncclCommInitAll");
 		commDestroy = (decltype(commDestroy)) dlsym(handle, "ncclCommDestroy");
 		groupStart = (decltype(groupStart)) dlsym(handle, "ncclGroupStart");
@@ -60,8 +67,9 @@ struct mtsgpu_group {
 	Rccl rccl;
 	std::vector<ncclComm_t> comms;         // one per member when RCCL is usable
 	std::string rcclNote;                  // why RCCL is not used, if it is not
-	float *staging = nullptr; size_t stagingFloats = 0;   // on members[0]'s device, for the ordered sum
+	float *staging = nullptr; size_t stagingFloats = 0;   // on members[0]'s device: a peer's film (ordered sum) / the RCCL result
 	int lastReduceKind = 0;
+	std::string reduceNote;                // why the last frame fell back to the ordered sum ("" when it did not)
 	std::string error;
 };
 
@@ -195,9 +203,73 @@ int mtsgpu_group_set_rfilter(mtsgpu_group *g, float size_x, float size_y, const 
 	return 0;
 }
 
+namespace {
+
+// keeps the calling thread's current HIP device: the Mitsuba plugin calls from its RenderJob thread, which owns other state
+struct DeviceGuard {
+	int saved = -1;
+	DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+	~DeviceGuard() { if (saved >= 0) (void) hipSetDevice(saved); }
+};
+
+int ensureStaging(mtsgpu_group *g, size_t count) {
+	if (g->stagingFloats >= count) return 0;
+	GHIP(g, hipSetDevice(g->devices[0]));
+	if (g->staging) (void) hipFree(g->staging);
+	g->staging = nullptr; g->stagingFloats = 0;
+	GHIP(g, hipMalloc((void **) &g->staging, count * sizeof(float)));
+	g->stagingFloats = count;
+	return 0;
+}
+
+// ONE ncclReduce(sum, f32, root 0) over the members' films.  The result is received in the staging buffer and copied
+// over member 0's film only when every step succeeded, so that a collective that fails half way leaves the films as the
+// members rendered them and the caller can still add them up in member order.  false + *why on any failure.
+bool reduceWithRccl(mtsgpu_group *g, size_t count, std::string &why) {
+	const int n = (int) g->members.size();
+	mtsgpu_ctx *root = g->members[0];
+	if (ensureStaging(g, count)) { why = g->error; return false; }
+	const char *inject = getenv("MTSGPU_RCCL_FAIL");          // fault injection for tests: "reduce" fails the collective call
+	ncclResult_t r = g->rccl.groupStart();
+	hipError_t he = hipSuccess;
+	if (r == ncclSuccess) {
+		for (int i = 0; i < n && r == ncclSuccess && he == hipSuccess; ++i) {
+			he = hipSetDevice(g->devices[i]);
+			if (he != hipSuccess) break;
+			mtsgpu_ctx *c = g->members[i];
+			if (inject && !strcmp(inject, "reduce")) { r = ncclInternalError; break; }
+			r = g->rccl.reduce(c->film, i == 0 ? g->staging : c->film, count, ncclFloat, ncclSum, 0, g->comms[i], c->stream);
+		}
+		const ncclResult_t r2 = g->rccl.groupEnd();           // always: an open group would swallow the next frame's calls
+		if (r == ncclSuccess) r = r2;
+	}
+	if (he != hipSuccess) { why = std::string("hipSetDevice inside the RCCL group: ") + hipGetErrorString(he); return false; }
+	if (r != ncclSuccess) {
+		why = std::string("ncclReduce: ") + (inject && !strcmp(inject, "reduce") ? "failure injected by MTSGPU_RCCL_FAIL" : g->rccl.errorString(r));
+		return false;
+	}
+	for (int i = 0; i < n; ++i) {
+		if ((he = hipSetDevice(g->devices[i])) != hipSuccess || (he = hipStreamSynchronize(g->members[i]->stream)) != hipSuccess) {
+			why = std::string("waiting for the RCCL reduce on member ") + std::to_string(i) + ": " + hipGetErrorString(he);
+			return false;
+		}
+	}
+	if ((he = hipSetDevice(g->devices[0])) != hipSuccess
+	    || (he = hipMemcpyAsync(root->film, g->staging, count * sizeof(float), hipMemcpyDeviceToDevice, root->stream)) != hipSuccess
+	    || (he = hipStreamSynchronize(root->stream)) != hipSuccess) {
+		why = std::string("copying the reduced film: ") + hipGetErrorString(he);
+		return false;
+	}
+	return true;
+}
+
+} // namespace
+
 int mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, volatile const int *cancel) {
 	if (!g) return gfail(nullptr, MTSGPU_EINVAL, "null group");
+	DeviceGuard keepDevice;
 	const int n = (int) g->members.size();
+	g->reduceNote.clear();
 	// 1 + 2: every member clears its film and renders its part of the tiles, one host thread per GPU
 	int rc = forAll(g, "render", [&](mtsgpu_ctx *c, int i) {
 		if (int r = mtsgpu_set_tiles(c, block_size, i, n)) return r;
@@ -214,22 +286,18 @@ int mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, vol
 			return gfail(g, MTSGPU_ESTATE, "member %d has a different film size", i);
 	if (ordered_reduce == 2 && !ensureComms(g))
 		return gfail(g, MTSGPU_EHIP, "RCCL is not usable: %s", g->rcclNote.c_str());
-	if (ordered_reduce != 1 && ensureComms(g)) {
-		ncclResult_t r = g->rccl.groupStart();
-		for (int i = 0; i < n && r == ncclSuccess; ++i) {
-			GHIP(g, hipSetDevice(g->devices[i]));
-			mtsgpu_ctx *c = g->members[i];
-			r = g->rccl.reduce(c->film, root->film, count, ncclFloat, ncclSum, 0, g->comms[i], c->stream);
+	if (ordered_reduce != 1) {
+		if (ensureComms(g)) {
+			std::string why;
+			if (reduceWithRccl(g, count, why)) { g->lastReduceKind = 1; return 0; }
+			// The collective failed: the films are untouched (see reduceWithRccl).  Give RCCL up for this group -- a
+			// communicator that has failed once is not trusted again -- and add the films up in member order instead.
+			for (ncclComm_t cm : g->comms) if (cm) (void) g->rccl.commDestroy(cm);
+			g->comms.clear();
+			g->rcclNote = why;
+			(void) hipGetLastError();
 		}
-		const ncclResult_t r2 = g->rccl.groupEnd();
-		if (r != ncclSuccess || r2 != ncclSuccess)
-			return gfail(g, MTSGPU_EHIP, "ncclReduce: %s", g->rccl.errorString(r != ncclSuccess ? r : r2));
-		for (int i = 0; i < n; ++i) {
-			GHIP(g, hipSetDevice(g->devices[i]));
-			GHIP(g, hipStreamSynchronize(g->members[i]->stream));
-		}
-		g->lastReduceKind = 1;
-		return 0;
+		if (n > 1 || ordered_reduce == 2) g->reduceNote = g->rcclNote;
 	}
 	// ordered sum on member 0's GPU: film_0 += film_1, += film_2, ... (a fixed order, so filters wider than a pixel
 	// give the same bits on every run); a peer's film travels over xGMI into a staging buffer first
@@ -237,12 +305,7 @@ int mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, vol
 	for (int i = 1; i < n; ++i) {
 		const float *src = g->members[i]->film;
 		if (g->devices[i] != g->devices[0]) {
-			if (g->stagingFloats < count) {
-				if (g->staging) (void) hipFree(g->staging);
-				g->staging = nullptr; g->stagingFloats = 0;
-				GHIP(g, hipMalloc((void **) &g->staging, count * sizeof(float)));
-				g->stagingFloats = count;
-			}
+			if (int r = ensureStaging(g, count)) return r;
 			GHIP(g, hipMemcpyPeerAsync(g->staging, g->devices[0], src, g->devices[i], count * sizeof(float), root->stream));
 			src = g->staging;
 		}
@@ -253,6 +316,8 @@ int mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, vol
 	g->lastReduceKind = 0;
 	return 0;
 }
+
+const char *mtsgpu_group_reduce_note(const mtsgpu_group *g) { return g ? g->reduceNote.c_str() : ""; }
 
 int mtsgpu_hbm_triad(int device, size_t bytes, int iters, double *gbs) {
 	if (!gbs || bytes < 4096 || iters <= 0) return gfail(nullptr, MTSGPU_EINVAL, "bad triad arguments");

@@ -31,6 +31,12 @@ constexpr int kShadeBlock = MG_SHADE_BLOCK;
 // traversal launches -- what the host counts itself when it reads the queue sizes back every bounce
 enum { kStatClosest = 0, kStatShadow = 1, kStatOverflow = 2, kStatLaunches = 3, kNumDevStats = 4 };
 
+// Layout of the leaf records: 0 = whole 48-byte records; 1 = heads and tails in two arrays (round-3 experiment, rejected:
+// 205 -> 210-215 ms of traversal per C3 frame, profiles/r03b_exp_trace_layouts.txt -- the tail of a record whose plane test
+// passes is an L1 hit on the line its head brought in; in an array of its own it is an L2 miss that costs the fabric a line)
+#ifndef MG_LEAF_SPLIT
+#define MG_LEAF_SPLIT 0
+#endif
 // Scene in HBM (all pointers are device pointers); see DESIGN.md section 3
 struct DScene {
 	const uint2    *nodes;        // 8 B: (left child index << 2 | axis, split) or (1 << 31 | first record, end record)
@@ -38,6 +44,9 @@ struct DScene {
 	// TriAccel of primitive kd_indices[e] (dword 0 = k << 30 | "not an occluder" << 29 | global
 	// primitive id, dword 10 = shape), so a leaf's primitives are one contiguous run
 	const uint4    *leaf_ta;
+	// MG_LEAF_SPLIT: leaf_ta holds only the 16-byte HEADS (dwords 0..3), entry e at leaf_ta[e]; the other 32 bytes of entry e
+	// are leaf_tail[2 e], leaf_tail[2 e + 1].  Eight heads share a 128-byte line instead of 2.67 whole records.
+	const uint4    *leaf_tail;
 	// per-primitive gather record, one 128-byte line (kTriStride float4): p0.xyz p1.xyz p2.xyz -, shape, flags |
 	// n0.xyz n1.xyz n2.xyz | pad -- one line instead of 3 index + 18 scattered vertex fetches; tri_nrm = tri_pos + 3
 	const float4   *tri_pos;
@@ -68,14 +77,14 @@ struct DScene {
 // What k_trace needs of the scene (a kernel argument: the fewer scalar registers it pins, the fewer get spilled)
 struct DTraceScene {
 	const uint2 *nodes;
-	const uint4 *leaf_ta;
+	const uint4 *leaf_ta, *leaf_tail;
 	const uint32_t *shape_bin;
 	uint32_t has_shapes;
 	float aabb_min[3], aabb_max[3];
 };
 inline DTraceScene trace_scene(const DScene &sc) {
 	DTraceScene t;
-	t.nodes = sc.nodes; t.leaf_ta = sc.leaf_ta; t.shape_bin = sc.shape_bin; t.has_shapes = sc.has_shapes;
+	t.nodes = sc.nodes; t.leaf_ta = sc.leaf_ta; t.leaf_tail = sc.leaf_tail; t.shape_bin = sc.shape_bin; t.has_shapes = sc.has_shapes;
 	for (int i = 0; i < 3; ++i) { t.aabb_min[i] = sc.aabb_min[i]; t.aabb_max[i] = sc.aabb_max[i]; }
 	return t;
 }

@@ -588,17 +588,34 @@ template <int N> __device__ __forceinline__ void exp_pad(float &x) {
 #ifndef MG_TOP_PAIRS
 #define MG_TOP_PAIRS 128
 #endif
+// MG_STACK2 (round-3 experiment, rejected): a stack entry is TWO dwords -- (far child index << 2 | split axis, split
+// plane) -- instead of the parent's index: a pop then needs no fetch of the parent node to rebuild the exit point (one of
+// the two gathers per pop, 7 of the 65 vector-memory requests per ray on C3).  But the LDS then holds 6 levels instead of
+// 10 in the same bytes and the deeper pushes spill 8 bytes each to HBM: 205 -> 228 ms (profiles/r03b_exp_trace_layouts.txt).
+#ifndef MG_STACK2
+#define MG_STACK2 0
+#endif
+#if MG_STACK2 && !defined(MG_STACK_LDS_SET)
+#undef MG_STACK_LDS
+#define MG_STACK_LDS 6
+#endif
 constexpr int kStackLDS = MG_STACK_LDS;       // stack levels kept in LDS (deeper ones spill: 1 push in 10^4 at 12 levels on C3)
 // The first 2 * kTopPairs device nodes -- the root and the sibling pairs below it in breadth-first order, see
 // mtsgpu_upload_scene -- are copied into LDS by every workgroup: each ray's descent from the root starts with 8-9
 // levels that every other ray visits too, and a vector-memory request costs the CU ~0.5-1 ns per lane where an LDS
 // read costs ~0.05 (profiles/r02_ta_gather_microbench.txt).  0 switches the cache off.
 constexpr uint32_t kTopPairs = MG_TOP_PAIRS;
-constexpr int kSpillLevels = 40;      // 12 + 40 >= MTS_KD_MAXDEPTH (48) + 2
+constexpr int kSpillLevels = 50 - kStackLDS;      // LDS + spill levels = MTS_KD_MAXDEPTH (48, gkdtree.h:35) + 2
+static_assert(kStackLDS >= 1 && kStackLDS + kSpillLevels >= 48 + 2, "the traversal stack must hold every tree the reference can build");
+struct alignas(MG_STACK2 ? 8 : 4) StackWord {
+	uint32_t v[MG_STACK2 ? 2 : 1];
+	__device__ __forceinline__ uint32_t &operator[](int i) { return v[i]; }
+	__device__ __forceinline__ const uint32_t &operator[](int i) const { return v[i]; }
+};
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 
-size_t trace_spill_levels() { return kSpillLevels; }
+size_t trace_spill_levels() { return kSpillLevels * (MG_STACK2 ? 2 : 1); }      // in dwords per thread
 size_t trace_stack_levels() { return kStackLDS + kSpillLevels; }
 uint32_t trace_top_nodes() { return 2u * kTopPairs; }
 
@@ -612,10 +629,18 @@ uint32_t trace_top_nodes() { return 2u * kTopPairs; }
 // what is computed for a ray.
 // `first` is the queue index of the wave's first batch, `stride` the distance to its next one, `static_n` the
 // statically dealt prefix of the queue.
+// leaf record e: its head (k | flags | primitive, n_u, n_v, n_d) and the two halves of its tail
+__device__ __forceinline__ const uint4 *leaf_head(const DTraceScene &sc, uint32_t e) {
+	return MG_LEAF_SPLIT ? &sc.leaf_ta[e] : &sc.leaf_ta[3 * (size_t) e];
+}
+__device__ __forceinline__ const uint4 *leaf_tail(const DTraceScene &sc, uint32_t e, uint32_t half) {
+	return MG_LEAF_SPLIT ? &sc.leaf_tail[2 * (size_t) e + half] : &sc.leaf_ta[3 * (size_t) e + 1 + half];
+}
+
 template <int MODE, bool COUNT, bool BIN>
 __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &ps, const DQueues &q, const TracePlan &plan,
                                            const uint32_t *queue, uint32_t n, const uint32_t first, const uint32_t stride,
-                                           uint32_t (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock], const uint4 *s_top) {
+                                           StackWord (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock], const uint4 *s_top) {
 	// node fetches: from the LDS copy of the top of the tree when the index lies inside it
 	auto load_node = [&](uint32_t i) -> uint2 {
 		if (kTopPairs && i < 2u * kTopPairs) return reinterpret_cast<const uint2 *>(s_top)[i];
@@ -658,7 +683,9 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 	float mint = 0, maxt = 0, tmax0 = 0;
 	float enx = 0, eny = 0, enz = 0, exx = 0, exy = 0, exz = 0, ex_t = 0;   // stack[enPt].p, stack[exPt].p, stack[exPt].t
 	int sp = 0;
+	// MG_STACK2: ex_ref = far child << 2 | axis of the current exit point (ex_node is its upper bits), ex_split its plane
 	uint32_t ex_node = kNullNode, ex_ref = kSentinel, cur = 0;
+	float ex_split = 0;
 	float best_t = MG_INF, best_u = 0, best_v = 0;
 	uint32_t best_prim = kNoPrim, best_shape = 0;
 	// best_shape: shape index of the accepted hit (dword 10 of its record), read while the record is at hand
@@ -840,12 +867,19 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					const uint32_t side = side1 ? 1u : 0u;
 					if (push) {
 						// push the current exit point's reference; (cur, far child) becomes the exit point
-						if (sp < kStackLDS) s_stack[sp][tid] = ex_ref;
-						else { q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref; if (COUNT && MG_EXP_COUNT_SPILL) w_batch++; }
+						if (MG_STACK2) {
+							StackWord w; w[0] = ex_ref; w[MG_STACK2 ? 1 : 0] = __float_as_uint(ex_split);
+							if (sp < kStackLDS) s_stack[sp][tid] = w;
+							else { reinterpret_cast<StackWord *>(q.spill)[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = w; if (COUNT && MG_EXP_COUNT_SPILL) w_batch++; }
+						} else {
+							if (sp < kStackLDS) s_stack[sp][tid][0] = ex_ref;
+							else { q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref; if (COUNT && MG_EXP_COUNT_SPILL) w_batch++; }
+						}
 						++sp;
 						const uint32_t farRight = A ? 1u : 0u;
 						const float distToSplit = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
-						ex_ref = (cur << 1) | farRight;
+						ex_ref = MG_STACK2 ? (((left + farRight) << 2) | (uint32_t) axis) : ((cur << 1) | farRight);
+						ex_split = split;
 						ex_t = distToSplit;
 						const float px = ox + distToSplit * dx, py = oy + distToSplit * dy, pz = oz + distToSplit * dz;
 						exx = (axis == 0) ? split : px; exy = (axis == 1) ? split : py; exz = (axis == 2) ? split : pz;   // selects, not branches
@@ -872,12 +906,12 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					// are only fetched for primitives whose t lies inside [mint, maxt] (triaccel.h:141-149).
 					uint4 A;
 					more = e != last;
-					if (more) A = ld_stream<2>(&sc.leaf_ta[3 * (size_t) e]);
+					if (more) A = ld_stream<2>(leaf_head(sc, e));
 					// like the descent, the primitive loop stops when fewer than q.leaf_min lanes have entries left;
 					// those lanes keep their position (e_cont) and go on in the next round
 					do { if (more) {
 						uint4 An = A;
-						if (e + 1 != last) An = ld_stream<2>(&sc.leaf_ta[3 * (size_t) (e + 1)]);      // next record's head in flight
+						if (e + 1 != last) An = ld_stream<2>(leaf_head(sc, e + 1));      // next record's head in flight
 						const uint32_t prim = A.x & 0x1FFFFFFFu, k = A.x >> 30;
 						if (COUNT) c_idx++;
 						MG_WSLOT(w_leaf);
@@ -892,7 +926,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						if (COUNT && fresh) c_tri++;
 						if (sc.has_shapes && k == 3u && A.y != 0u && fresh && occl) {     // has_shapes is uniform: one scalar branch
 							// a non-triangle shape (skdtree.h:287-296 / :328-332); A.y = shape type, B = centre + radius
-							const uint4 B = sc.leaf_ta[3 * (size_t) e + 1];
+							const uint4 B = *leaf_tail(sc, e, 0);
 							const V3 ctr(__uint_as_float(B.x), __uint_as_float(B.y), __uint_as_float(B.z));
 							const float rad = __uint_as_float(B.w);
 							if (MODE != 0) {
@@ -902,7 +936,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 								if (sphere_intersect(ctr, rad, V3(ox, oy, oz), V3(dx, dy, dz), mint, maxt, ts)) {
 									maxt = ts;
 									best_t = ts; best_u = 0.0f; best_v = 0.0f; best_prim = prim;
-									best_shape = sc.leaf_ta[3 * (size_t) e + 2].z;
+									best_shape = leaf_tail(sc, e, 1)->z;
 								}
 							}
 						}
@@ -913,8 +947,8 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
 						const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
 						if (ok && !(t < mint || t > maxt)) {
-							const uint4 B = ld_stream<2>(&sc.leaf_ta[3 * (size_t) e + 1]);
-							const uint4 C = ld_stream<2>(&sc.leaf_ta[3 * (size_t) e + 2]);         // c_nu, c_nv, shape index, -
+							const uint4 B = ld_stream<2>(leaf_tail(sc, e, 0));
+							const uint4 C = ld_stream<2>(leaf_tail(sc, e, 1));         // c_nu, c_nv, shape index, -
 							const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
 							const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
 							const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
@@ -948,22 +982,31 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						finished = true;
 					} else {
 						--sp;
-						nd = load_node(cur);         // in flight together with the parent's node below
-						const uint32_t ref = (sp < kStackLDS) ? s_stack[sp][tid]
-						                                      : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
+						nd = load_node(cur);         // in flight together with the parent's node below (MG_STACK2: the only fetch)
+						StackWord sw;
+						if (MG_STACK2) sw = (sp < kStackLDS) ? s_stack[sp][tid]
+						                                     : reinterpret_cast<const StackWord *>(q.spill)[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
+						else sw[0] = (sp < kStackLDS) ? s_stack[sp][tid][0] : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
+						const uint32_t ref = sw[0];
 						if (ref == kSentinel) {
 							ex_t = tmax0; exx = ox + tmax0 * dx; exy = oy + tmax0 * dy; exz = oz + tmax0 * dz;
 							ex_node = kNullNode; ex_ref = kSentinel;
 						} else {
-							const uint32_t parent = ref >> 1;
-							const uint2 pn = load_node(parent);
-							const int axis = (int) (pn.x & 3u);
-							const float split = __uint_as_float(pn.y);
-							ex_node = (pn.x >> 2) + (ref & 1u);
+							int axis; float split;
+							if (MG_STACK2) {
+								axis = (int) (ref & 3u); split = __uint_as_float(sw[MG_STACK2 ? 1 : 0]);
+								ex_node = ref >> 2;
+							} else {
+								const uint32_t parent = ref >> 1;
+								const uint2 pn = load_node(parent);
+								axis = (int) (pn.x & 3u);
+								split = __uint_as_float(pn.y);
+								ex_node = (pn.x >> 2) + (ref & 1u);
+							}
 							ex_t = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
 							const float px = ox + ex_t * dx, py = oy + ex_t * dy, pz = oz + ex_t * dz;
 							exx = (axis == 0) ? split : px; exy = (axis == 1) ? split : py; exz = (axis == 2) ? split : pz;
-							ex_ref = ref;
+							ex_ref = ref; ex_split = split;
 						}
 					}
 				}
@@ -996,7 +1039,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 template <int MODE, bool COUNT, bool BIN>
 __global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trace(DTraceScene sc, DPaths ps, DQueues q,
                                                           const uint32_t *queue, uint32_t n_host, const uint32_t *n_dev) {
-	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
+	__shared__ StackWord s_stack[kStackLDS][kTraceBlock];
 	__shared__ uint32_t s_mbox[8][kTraceBlock];
 	__shared__ uint4 s_top[kTopPairs ? kTopPairs : 1];
 	// the number of rays: known to the host, or left in device memory by the kernel that filled the queue

@@ -263,6 +263,7 @@ def test_bench_world2_branch_on_one_gpu(gpu_lib, mts, orc, tmp_path):
         line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
         rec = json.loads(line)
         assert rec["n_gpus"] == 2 and rec["scaling"] == mode and rec["value"] > 0
+        assert len(rec["rank_ms"]) == 2 and len(rec["reduce_ms"]) == 2 and min(rec["rank_ms"]) > 0
         assert rec["roofline"]["frac"] > 0 and "cpu_baseline" not in rec
         cam = mts.PerspectiveCamera.for_description(sd, 96, 96)
         it = mts.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth)
