@@ -343,6 +343,17 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 	uint32_t upper = nPaths;                   // what the host knows about the queue sizes
 	bool shadowPending = false;
 	int b = 0;
+	// Every way out of this function -- cancel, a failed HIP call, the normal end -- leaves the context as the host-driven
+	// loop expects it and the second stream joined: a shadow launch still running on it adds to Li with a plain
+	// read-modify-write (k_trace MODE 1), and the next frame's clear / generate kernels on c->stream are not ordered
+	// against it otherwise (a GUI cancels and re-renders at once).
+	struct Restore {
+		mtsgpu_ctx *c; hipStream_t s2; const bool &pending;
+		~Restore() {
+			if (pending) (void) hipStreamSynchronize(s2);
+			c->q.dev_stats = nullptr; c->q.counters = c->counterSets; c->q.spill = c->spillClosest;
+		}
+	} restore{ c, s2, shadowPending };
 	auto timed = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used, hipStream_t s, int which) -> int {
 		if (!c->timeKernels) return 0;
 		hipEvent_t *ev = which == 0 ? nextEventPair(c, pool, used) : &pool[used - 1].first;
@@ -351,7 +362,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 		return 0;
 	};
 	while (b < limit && upper > 0) {
-		if (cancel && *cancel) { c->q.dev_stats = nullptr; return fail(c, MTSGPU_ECANCEL, "render cancelled"); }
+		if (cancel && *cancel) return fail(c, MTSGPU_ECANCEL, "render cancelled");
 		const int end = (int) std::min<long long>((long long) b + chunk, limit);
 		for (; b < end; ++b) {
 			uint32_t *set = counterSet(c, b), *prev = counterSet(c, b - 1);
@@ -390,8 +401,10 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 		HIPCHK(c, hipEventSynchronize(c->evCount));
 		upper = *hostNext;
 	}
-	if (shadowPending) HIPCHK(c, hipStreamWaitEvent(s1, c->evShadow[(b - 1) & 1], 0));
-	c->q.dev_stats = nullptr; c->q.counters = c->counterSets; c->q.spill = c->spillClosest;
+	if (shadowPending) {
+		HIPCHK(c, hipStreamWaitEvent(s1, c->evShadow[(b - 1) & 1], 0));      // the film kernels that follow wait on the device
+		shadowPending = false;                                               // ... so the guard need not block the host
+	}
 	return 0;
 }
 
@@ -1058,7 +1071,7 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	rc = ensureFilm(c); if (rc) return rc;
 	const int W = c->cam.width, H = c->cam.height, bs = c->blockSize;
 	const uint32_t spp = effectiveSpp(c);
-	// ImageBlock work units (imageproc.cpp:43-78) owned by this context: tile t -> part t % n_parts
+	// ImageBlock work units (imageproc.cpp:43-78) owned by this context: tile (tx, ty) -> part morton(tx, ty) % n_parts
 	std::vector<uint32_t> pixels;
 	std::vector<TileMeta> tiles;
 	// Film::hasHighQualityEdges: the rendered rectangle grows by the filter border (renderproc.cpp:146-153)

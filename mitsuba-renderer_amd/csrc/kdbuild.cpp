@@ -1464,6 +1464,7 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 	dTotals.reserve(1);
 	XTotals totals{};
 	auto fetchTotals = [&]() {
+		KXHIP(hipGetLastError());        // a failed launch is not sticky: catch it before its outputs are trusted
 		KXHIP(hipMemcpyAsync(&totals, dTotals.p, sizeof(XTotals), hipMemcpyDeviceToHost, st));
 		KXHIP(hipStreamSynchronize(st));
 	};
@@ -1587,8 +1588,16 @@ void exactOnDevice(const Builder &b, const Params &p, const Geometry &g, uint32_
 	dView.reserve(nAll);
 	hipLaunchKernelGGL(k_x_host_view, grid(nAll), dim3(B), 0, st, dAll.p, (uint32_t) nAll, dView.p);
 	std::vector<XNodeH> all(nAll);
+	KXHIP(hipGetLastError());
 	KXHIP(hipMemcpyAsync(all.data(), dView.p, nAll * sizeof(XNodeH), hipMemcpyDeviceToHost, st));
 	KXHIP(hipStreamSynchronize(st));
+	// what the replay indexes with: child ids inside the node table, leaf ranges inside the leaf store
+	for (size_t i = 0; i < nAll; ++i) {
+		const XNodeH &n = all[i];
+		if (n.kind == 1 ? (n.primCount > 0 && (size_t) n.leafOffset + n.leafCount > leafTotal)
+		                : ((size_t) n.child + 1 >= nAll || (size_t) n.child <= i))
+			throw std::runtime_error("kd-tree build (device exact phase): inconsistent node table read back from the device");
+	}
 	tm[2] = since(tPhase); tPhase = now();
 
 	// ---- replay: the bookkeeping of buildTree per job, depth first (nodes, indices, counters, retraction) ----
