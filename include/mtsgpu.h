@@ -225,6 +225,9 @@ int  mtsgpu_create(int device, mtsgpu_ctx **out);
 void mtsgpu_destroy(mtsgpu_ctx *ctx);
 const char *mtsgpu_last_error(const mtsgpu_ctx *ctx); /* ctx may be NULL: global */
 int  mtsgpu_abi_version(void);
+/* first 16 hex digits of the sha256 of the library's sources, stamped in at build time (csrc/stamp.cpp): lets a
+ * build script tell a stale binary from a current one */
+const char *mtsgpu_source_hash(void);
 /* sizeof() of the ABI structs as compiled into the library: 0 scene, 1 camera, 2 stats, 3 mesh,
  * 4 scene_desc, 5 kd_params (bindings check their own layout against these) */
 size_t mtsgpu_abi_sizeof(int which);

@@ -23,7 +23,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTSGPU_LIB") or os.path.join(_HERE, "libmtsgpu.so")
 
 EXPORTS = [
-    "mtsgpu_create", "mtsgpu_destroy", "mtsgpu_last_error", "mtsgpu_abi_version", "mtsgpu_abi_sizeof", "mtsgpu_set_stream",
+    "mtsgpu_create", "mtsgpu_destroy", "mtsgpu_last_error", "mtsgpu_abi_version", "mtsgpu_source_hash", "mtsgpu_abi_sizeof", "mtsgpu_set_stream",
     "mtsgpu_upload_scene", "mtsgpu_set_camera", "mtsgpu_set_integrator", "mtsgpu_set_direct_integrator", "mtsgpu_set_sampler",
     "mtsgpu_set_tiles", "mtsgpu_set_rfilter", "mtsgpu_set_film_edges", "mtsgpu_tabulate_filter", "mtsgpu_set_film_buffer", "mtsgpu_set_options", "mtsgpu_render", "mtsgpu_sync",
     "mtsgpu_read_film", "mtsgpu_clear_film", "mtsgpu_get_stats", "mtsgpu_trace_rays", "mtsgpu_ld_tables",
@@ -56,11 +56,43 @@ def load_serialized(path, shape_index=0, bsdf=-1, lum=-1, name=None):
         lib().mtsgpu_loaded_mesh_free(h)
 
 
+_SOURCES = ["api.cpp", "group.cpp", "kernels.hip", "kdbuild.cpp", "flatten.cpp", "serialized.cpp",       # SRCS, then HDRS of csrc/Makefile
+            "host.h", "ctx.h", "kernels.h", "devmath.h", os.path.join("..", "..", "include", "mtsgpu.h")]
+
+
+def source_hash():
+    """the hash csrc/Makefile stamps into the library (csrc/stamp.cpp), recomputed from the sources on disk"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in _SOURCES:
+        h.update(open(os.path.join(_HERE, "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def built_hash(path=None):
+    """mtsgpu_source_hash() of a built library, None if it cannot be loaded or predates the stamp"""
+    try:
+        L = C.CDLL(path or os.path.join(_HERE, "libmtsgpu.so"))
+        L.mtsgpu_source_hash.restype = C.c_char_p
+        return L.mtsgpu_source_hash().decode()
+    except (OSError, AttributeError):
+        return None
+
+
 def build(force=False):
-    """Compile libmtsgpu.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile libmtsgpu.so for gfx950 (hipcc cross-compiles without a GPU).  make is incremental; a binary whose stamped
+    source hash differs from the sources on disk (e.g. a copied-in .so newer than the files) is rebuilt from scratch."""
     csrc = os.path.join(_HERE, "csrc")
-    cmd = ["make", "-C", csrc, "-j4"] + (["-B"] if force else [])
-    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    lib_path = os.path.join(_HERE, "libmtsgpu.so")
+    subprocess.check_call(["make", "-C", csrc, "-j4"] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    # checked in a child process: a library that is already loaded here would answer for the OLD file
+    probe = "import ctypes as C; L = C.CDLL(%r); L.mtsgpu_source_hash.restype = C.c_char_p; print(L.mtsgpu_source_hash().decode())" % lib_path
+    got = subprocess.run([os.sys.executable, "-c", probe], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().strip()
+    if got != source_hash():
+        subprocess.check_call(["make", "-C", csrc, "-j4", "-B"], stdout=subprocess.DEVNULL)
+        got = subprocess.run([os.sys.executable, "-c", probe], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().strip()
+        if got != source_hash():
+            raise MtsGpuError("libmtsgpu.so reports source hash %r after a full rebuild, the sources hash to %r" % (got, source_hash()))
     return LIB_PATH
 
 
@@ -80,6 +112,7 @@ def lib():
     L.mtsgpu_destroy.argtypes = [vp]; L.mtsgpu_destroy.restype = None
     L.mtsgpu_last_error.argtypes = [vp]; L.mtsgpu_last_error.restype = C.c_char_p
     L.mtsgpu_abi_version.argtypes = []
+    L.mtsgpu_source_hash.argtypes = []; L.mtsgpu_source_hash.restype = C.c_char_p
     L.mtsgpu_abi_sizeof.argtypes = [C.c_int]; L.mtsgpu_abi_sizeof.restype = C.c_size_t
     L.mtsgpu_set_stream.argtypes = [vp, vp]
     L.mtsgpu_upload_scene.argtypes = [vp, C.POINTER(abi.Scene)]

@@ -233,3 +233,9 @@ def test_serialized_mesh_loader(mts, tmp_path):
     sio.write(str(tmp_path / "oob.serialized"), broken)
     with pytest.raises(mts.MtsGpuError):
         mts.load_serialized(str(tmp_path / "oob.serialized"), 0)
+
+
+def test_library_is_built_from_the_sources_on_disk(mts):
+    """mtsgpu_source_hash() (stamped in by csrc/Makefile, csrc/stamp.cpp) equals the hash of the sources: the binary that
+    ships to the GPU box is not a stale one"""
+    assert mts.lib().mtsgpu_source_hash().decode() == mts.source_hash()

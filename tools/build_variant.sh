@@ -6,5 +6,5 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../mitsuba-renderer_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -pthread "$@" \
-    -x hip -shared api.cpp group.cpp kernels.hip kdbuild.cpp flatten.cpp serialized.cpp -o ../libmtsgpu_$name.so -lz -ldl
+    -x hip -shared api.cpp group.cpp kernels.hip kdbuild.cpp flatten.cpp serialized.cpp stamp.cpp -o ../libmtsgpu_$name.so -lz -ldl
 ls -la ../libmtsgpu_$name.so
