@@ -577,6 +577,9 @@ template <int BIT, typename T> __device__ __forceinline__ void st_stream(T *p, c
 #ifndef MG_EXP_PAD_LEAF
 #define MG_EXP_PAD_LEAF 0
 #endif
+#ifndef MG_EXP_COUNT_CAND
+#define MG_EXP_COUNT_CAND 0      // counting build: counter 7 = primitives whose plane distance passes, counter 6 = those with u >= 0
+#endif
 template <int N> __device__ __forceinline__ void exp_pad(float &x) {
 	#pragma unroll
 	for (int i = 0; i < N; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(x));
@@ -770,7 +773,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 			const uint32_t taken = (B - nlive < remaining) ? B - nlive : remaining;
 			const uint32_t my = sup_base + r;
 			sup_base += taken; sup_left -= taken;
-			if (!MG_EXP_COUNT_SPILL) MG_WSLOT(w_batch);
+			if (!MG_EXP_COUNT_SPILL && !MG_EXP_COUNT_CAND) MG_WSLOT(w_batch);
 			if (take) {
 				id = (MODE == 1) ? my : ld_stream<1>(&queue[my]);       // shadow rays are addressed by their queue position
 				float4 a, b;
@@ -896,7 +899,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				if (!inner) {
 				// --- leaf: test the primitives (sahkdtree3.h:262-288, skdtree.h:244-336) ---
 				if (COUNT && e_cont == kNoPrim) c_leaf++;      // a resumed leaf was counted already
-				MG_WSLOT(w_outer);
+				if (!MG_EXP_COUNT_CAND) MG_WSLOT(w_outer);
 				bool hitShadow = false, more = false;
 				{
 					uint32_t e = (e_cont != kNoPrim) ? e_cont : (nd.x & 0x7FFFFFFFu);     // resume an interrupted leaf
@@ -947,6 +950,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
 						const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
 						if (ok && !(t < mint || t > maxt)) {
+							if (COUNT && MG_EXP_COUNT_CAND) w_batch++;
 							const uint4 B = ld_stream<2>(leaf_tail(sc, e, 0));
 							const uint4 C = ld_stream<2>(leaf_tail(sc, e, 1));         // c_nu, c_nv, shape index, -
 							const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
@@ -956,6 +960,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 							const float hv = o_v + t * d_v - a_v;
 							const float u = hv * b_nu + hu * b_nv;
 							const float v = hu * c_nu + hv * c_nv;
+							if (COUNT && MG_EXP_COUNT_CAND && u >= 0) w_outer++;
 							if (u >= 0 && v >= 0 && u + v <= 1.0f) {
 								if (MODE != 0) hitShadow = true;
 								maxt = t;      // a later hit with equal t replaces this one (t > maxt rejects)
