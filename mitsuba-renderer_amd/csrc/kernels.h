@@ -7,9 +7,25 @@ namespace mg {
 
 constexpr int kNumBsdfTypes = 8;      // lambertian, dielectric, roughmetal, microfacet, mirror, phong, roughglass, difftrans
 constexpr int kNumBins = kNumBsdfTypes + 1;   // + "terminal" (miss / no BSDF)
-constexpr int kTraceBlock = 256;
-constexpr unsigned kTraceBlocksPerCuMax = 8;      // largest persistent traversal grid: CUs x 8 resident workgroups
-constexpr unsigned trace_blocks_per_cu(int mode) { return mode == 0 ? 7u : 8u; }   // closest-hit state needs 72 VGPRs, shadow rays 64
+// Threads per traversal workgroup and resident workgroups per CU.  Round 3: 512 threads, 3 workgroups for closest-hit rays
+// (24 waves per CU, up to 80 VGPRs) and 4 for shadow rays (32 waves, 64 VGPRs), instead of 7 / 8 workgroups of 256: the
+// LDS copy of the top of the tree is shared by 8 waves instead of 4, so the same LDS holds 10 levels of it (1 024 sibling
+// pairs) instead of 8 -- every ray's descent from the root and every pop that lands there skip two more vector-memory
+// requests, which buys more than the four waves per CU cost (205 -> 199 ms per C3 frame,
+// profiles/r03e_exp_trace_workgroups.txt).  Workgroups whose wave count is not a multiple of four (384, 896 threads)
+// lose a third of the CU's wave slots and are out.  MG_TRACE_BLOCK / MG_TRACE_WGS override the rule in experiment builds.
+#ifndef MG_TRACE_BLOCK
+#define MG_TRACE_BLOCK 512
+#endif
+constexpr int kTraceBlock = MG_TRACE_BLOCK;
+static_assert(kTraceBlock % 256 == 0 && kTraceBlock <= 1024, "whole multiples of four waves");
+#ifdef MG_TRACE_WGS
+constexpr unsigned trace_blocks_per_cu(int) { return MG_TRACE_WGS; }
+#else
+constexpr unsigned trace_blocks_per_cu(int mode) { return (mode == 0 ? 24u : 32u) / (kTraceBlock / 64); }
+#endif
+constexpr unsigned trace_waves_per_simd(int mode) { return trace_blocks_per_cu(mode) * (kTraceBlock / 64) / 4; }
+constexpr unsigned kTraceBlocksPerCuMax = 2048 / kTraceBlock;      // largest persistent traversal grid: 32 waves per CU
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 constexpr int kTriStride = 8;         // float4 per primitive record: one 128-byte line holds positions AND normals
 constexpr int kLumStride = 32;        // MTSGPU_LUM_NPARAMS

@@ -589,7 +589,7 @@ template <int N> __device__ __forceinline__ void exp_pad(float &x) {
 #define MG_STACK_LDS 10
 #endif
 #ifndef MG_TOP_PAIRS
-#define MG_TOP_PAIRS 128
+#define MG_TOP_PAIRS (MG_TRACE_BLOCK >= 512 ? 1024 : 128)
 #endif
 // MG_STACK2 (round-3 experiment, rejected): a stack entry is TWO dwords -- (far child index << 2 | split axis, split
 // plane) -- instead of the parent's index: a pop then needs no fetch of the parent node to rebuild the exit point (one of
@@ -653,6 +653,11 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 		if (kTopPairs && left < 2u * kTopPairs) return s_top[left >> 1];
 		return reinterpret_cast<const uint4 *>(sc.nodes)[left >> 1];
 	};
+	// The hashed mailbox decides which of two primitives with equal t is reported (sahkdtree3.h:130-144, :278-283), so
+	// closest-hit rays keep it.  For any-hit rays it only saves repeated tests of a primitive that spans several leaves --
+	// the answer is a disjunction over the same primitives either way -- and its 8 dwords per lane are better spent on
+	// the LDS copy of the tree: the shadow kernels run without it (counting builds keep it: the oracle counts with it).
+	constexpr bool kMbox = MODE == 0 || COUNT;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t gtid = blockIdx.x * kTraceBlock + tid;     // spill slot of this lane
 	const uint32_t lane = lane_id();
@@ -822,8 +827,10 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				done = !go;       // a ray that misses the scene's box is finished at once
 				has = go;
 				if (go) {
-					#pragma unroll
-					for (int i = 0; i < 8; ++i) s_mbox[i][tid] = 0xFFFFFFFFu;
+					if (kMbox) {
+						#pragma unroll
+						for (int i = 0; i < 8; ++i) s_mbox[i][tid] = 0xFFFFFFFFu;
+					}
 					// entry point (stack[enPt]) and current exit point (stack[exPt]) in registers
 					enx = ox + mint * dx; eny = oy + mint * dy; enz = oz + mint * dz;      // stack[enPt].p = ray(mint)
 					tmax0 = maxt;
@@ -922,8 +929,8 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						// Flat form of the mailbox test + TriAccel::rayIntersect: the plane distance t is computed for
 						// every entry (selects, no branches) and masked afterwards; only the barycentric part, which
 						// needs the rest of the record, is conditional.
-						uint32_t *mslot = &s_mbox[prim & 7u][tid];
-						const bool fresh = *mslot != prim;                        // not in the mailbox
+						uint32_t *mslot = &s_mbox[kMbox ? (prim & 7u) : 0u][tid];
+						const bool fresh = !kMbox || *mslot != prim;              // not in the mailbox
 						const bool occl = !(MODE != 0 && (A.x & 0x20000000u));   // shape->isOccluder() (skdtree.h:318-333)
 						const bool ok = fresh && occl && (k != 3u);               // k == 3: degenerate triangle or another shape
 						if (COUNT && fresh) c_tri++;
@@ -967,7 +974,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 								best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = C.z;
 							}
 						}
-						*mslot = prim;         // (re)writing an entry that is already there changes nothing
+						if (kMbox) *mslot = prim;         // (re)writing an entry that is already there changes nothing
 						A = An;
 						++e;
 					}
@@ -1042,10 +1049,10 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 }
 
 template <int MODE, bool COUNT, bool BIN>
-__global__ __launch_bounds__(kTraceBlock, trace_blocks_per_cu(MODE)) void k_trace(DTraceScene sc, DPaths ps, DQueues q,
+__global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(MODE)) void k_trace(DTraceScene sc, DPaths ps, DQueues q,
                                                           const uint32_t *queue, uint32_t n_host, const uint32_t *n_dev) {
 	__shared__ StackWord s_stack[kStackLDS][kTraceBlock];
-	__shared__ uint32_t s_mbox[8][kTraceBlock];
+	__shared__ uint32_t s_mbox[(MODE == 0 || COUNT) ? 8 : 1][kTraceBlock];
 	__shared__ uint4 s_top[kTopPairs ? kTopPairs : 1];
 	// the number of rays: known to the host, or left in device memory by the kernel that filled the queue
 	const uint32_t n = n_dev ? (uint32_t) __builtin_amdgcn_readfirstlane((int) *n_dev) : n_host;
