@@ -66,9 +66,9 @@ inline void copyMatrix(float *dst, const Matrix4x4 *m) {
 /* Reads back what <BSDF class>::serialize wrote -- the only access to the BSDF plugins' private parameters.  The
  * object goes through InstanceManager::serialize into memory (wire format, src/libcore/serialization.cpp:72-85: a new
  * object is [id][class name][its serialize()], a known one just [id], NULL is [0]) and the fields are read back in the
- * order the plugin's serialize() documents.  Nothing is re-instantiated.  This works for BSDFs because they have no
- * parent (BSDF::setParent is empty, bsdf.cpp:55-57) and their only children are textures; shapes and luminaires point
- * back at the scene and cannot be read this way -- their values come from the public evaluation API instead. */
+ * order the plugin's serialize() documents.  Nothing is re-instantiated.  This works for BSDFs as they stand because
+ * they have no parent (BSDF::setParent is empty, bsdf.cpp:55-57) and their only children are textures; shapes and
+ * luminaires point back at the scene: see DetachedReader below. */
 class BSDFParamReader {
 public:
 	BSDFParamReader(const BSDF *bsdf) {
@@ -205,12 +205,12 @@ struct FlatScene {
 		lumShape.assign(lums.size(), -1); lumInvArea.assign(lums.size(), 0.0f);
 		sc.background_lum = -1;
 		for (size_t l = 0; l < lums.size(); ++l) {
-			const Luminaire *lum = lums[l];
+			Luminaire *lum = lums[l];                                                 /* non-const: DetachedReader takes the parent off and puts it back */
 			lumIndex[lum] = (int) l;
 			float *P = &lumParams[(size_t) MTSGPU_LUM_NPARAMS * l];
 			const std::string cls = lum->getClass()->getName();
-			/* luminaires point back at their shape / the scene, so serialize() would drag the whole scene along: their
-			 * (few) parameters are read through the public evaluation interface, which returns the stored values as is */
+			/* area, constant and point luminaires hand their stored values out through the public evaluation interface
+			 * unchanged; the others keep them private and are read back from serialize() (DetachedReader) */
 			if (cls == "AreaLuminaire") {
 				lumType.push_back(MTSGPU_LUM_AREA);
 				ShapeSamplingRecord sRec; sRec.n = Normal(0, 0, 1);
