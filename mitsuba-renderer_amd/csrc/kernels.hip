@@ -577,6 +577,9 @@ template <int BIT, typename T> __device__ __forceinline__ void st_stream(T *p, c
 #ifndef MG_EXP_PAD_LEAF
 #define MG_EXP_PAD_LEAF 0
 #endif
+#ifndef MG_NODE_SC1
+#define MG_NODE_SC1 0      // experiment: sibling pairs fetched past the L1 (see load_pair)
+#endif
 #ifndef MG_EXP_COUNT_CAND
 #define MG_EXP_COUNT_CAND 0      // counting build: counter 7 = primitives whose plane distance passes, counter 6 = those with u >= 0
 #endif
@@ -650,8 +653,18 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 		return sc.nodes[i];
 	};
 	auto load_pair = [&](uint32_t left) -> uint4 {
+#if MG_NODE_SC1
+		// the pair through a load that does not allocate in the CU's L1 (sc1: served by the L2 like a miss would be):
+		// the 256 lines of the L1 then belong to the leaf records, whose tails are asked for a microsecond after their heads
+		const uint4 *p = (kTopPairs && left < 2u * kTopPairs) ? &s_top[left >> 1] : &reinterpret_cast<const uint4 *>(sc.nodes)[left >> 1];
+		nt_u4 v;
+		asm volatile("flat_load_dwordx4 %0, %1 sc1" : "=v"(v) : "v"(p) : "memory");
+		uint4 out; __builtin_memcpy(&out, &v, 16);
+		return out;
+#else
 		if (kTopPairs && left < 2u * kTopPairs) return s_top[left >> 1];
 		return reinterpret_cast<const uint4 *>(sc.nodes)[left >> 1];
+#endif
 	};
 	// The hashed mailbox decides which of two primitives with equal t is reported (sahkdtree3.h:130-144, :278-283), so
 	// closest-hit rays keep it.  For any-hit rays it only saves repeated tests of a primitive that spans several leaves --
@@ -858,7 +871,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					const uint32_t left = nd.x >> 2;            // device nodes hold the absolute index of the left child
 					// both children in one 16-byte load (sibling pairs are 16-byte aligned in the device order), issued
 					// before the case logic below instead of after it: the step is a chain of dependent fetches
-					const uint4 pair = load_pair(left);
+					uint4 pair = load_pair(left);
 					if (COUNT) c_inner++;
 					MG_WSLOT(w_inner);
 					if (MG_EXP_PAD_DESC) exp_pad<MG_EXP_PAD_DESC>(pad);
@@ -896,6 +909,13 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						ex_node = left + farRight;
 					}
 					cur = left + side;
+#if MG_NODE_SC1
+					{	// the compiler does not know the asm above is a load: wait for it here, with the registers as operands
+						nt_u4 v; __builtin_memcpy(&v, &pair, 16);
+						asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(v) :: "memory");
+						__builtin_memcpy(&pair, &v, 16);
+					}
+#endif
 					nd = side1 ? make_uint2(pair.z, pair.w) : make_uint2(pair.x, pair.y);
 				}
 				// evaluated for all lanes after the step (a lane that did not step sits on a leaf): the flag then is one
