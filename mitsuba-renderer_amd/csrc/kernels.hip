@@ -577,6 +577,9 @@ template <int BIT, typename T> __device__ __forceinline__ void st_stream(T *p, c
 #ifndef MG_EXP_PAD_LEAF
 #define MG_EXP_PAD_LEAF 0
 #endif
+#ifndef MG_EXP_PAD_TA
+#define MG_EXP_PAD_TA 0       // experiment (C3 only): N extra random 16-byte L2-resident gathers per descent step, results unused
+#endif
 #ifndef MG_NODE_SC1
 #define MG_NODE_SC1 0      // experiment: sibling pairs fetched past the L1 (see load_pair)
 #endif
@@ -875,6 +878,14 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					if (COUNT) c_inner++;
 					MG_WSLOT(w_inner);
 					if (MG_EXP_PAD_DESC) exp_pad<MG_EXP_PAD_DESC>(pad);
+					if (MG_EXP_PAD_TA) {
+						// what one more request per step costs: a line of the node array picked by a hash of the step's node
+						#pragma unroll
+						for (int r = 0; r < MG_EXP_PAD_TA; ++r) {
+							const uint4 x = reinterpret_cast<const uint4 *>(sc.nodes)[((left + 0x9E37u * (uint32_t) (r + 1)) * 2654435761u >> 13) & 0x3FFFFu];
+							pad += __uint_as_float(x.x & 1u);
+						}
+					}
 					const float pen = sel3(enx, eny, enz, axis), pex = sel3(exx, exy, exz, axis);
 					const bool A = pen <= split, B = pex <= split, C = pen == split, D = split < pex;
 					//   A &&  B        : left only            (N1-N3, P5, Z2, Z3)
@@ -1053,7 +1064,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 		}
 	}
 
-	if ((MG_EXP_PAD_DESC || MG_EXP_PAD_LEAF) && pad == -1.0f) q.trace_counts[7] = 1ull;      // keeps the padding alive
+	if ((MG_EXP_PAD_DESC || MG_EXP_PAD_LEAF || MG_EXP_PAD_TA) && pad == -1.0f) q.trace_counts[7] = 1ull;      // keeps the padding alive
 	if (COUNT) {
 		// wave reduction, then one atomic per wave and counter
 		unsigned long long v[8] = { c_inner, c_leaf, c_idx, c_tri, w_inner, w_leaf, w_outer, w_batch };
