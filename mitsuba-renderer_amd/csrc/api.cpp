@@ -1072,8 +1072,6 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	const int W = c->cam.width, H = c->cam.height, bs = c->blockSize;
 	const uint32_t spp = effectiveSpp(c);
 	// ImageBlock work units (imageproc.cpp:43-78) owned by this context: tile (tx, ty) -> part morton(tx, ty) % n_parts
-	std::vector<uint32_t> pixels;
-	std::vector<TileMeta> tiles;
 	// Film::hasHighQualityEdges: the rendered rectangle grows by the filter border (renderproc.cpp:146-153)
 	const int off = c->hqEdges ? -c->filtBorder : 0;
 	const int RW = W - 2 * off, RH = H - 2 * off;
@@ -1082,23 +1080,34 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	const int cx = c->cam.crop_offset_x, cy = c->cam.crop_offset_y;
 	const int keyW = filmWidth(c) - 2 * off;
 	if ((uint64_t) keyW * (uint64_t) (filmHeight(c) - 2 * off) > 0xFFFFFFFFull) return fail(c, MTSGPU_EINVAL, "film too large");
-	for (int t = 0; t < tx * ty; ++t) {
-		if (tileMorton((uint32_t) (t % tx), (uint32_t) (t / tx)) % (uint32_t) c->nParts != (uint32_t) c->part) continue;
-		const int x0 = off + (t % tx) * bs, y0 = off + (t / tx) * bs;            // inside the crop window
-		TileMeta tm{};
-		tm.x0 = x0 + cx; tm.y0 = y0 + cy; tm.w = std::min(bs, off + RW - x0); tm.h = std::min(bs, off + RH - y0);
-		tm.slot_base = (uint32_t) pixels.size(); tm.block_index = (uint32_t) tiles.size();
-		tm.colour = (uint32_t) (((t % tx) & 1) + 2 * ((t / tx) & 1));
-		tiles.push_back(tm);
-		for (int y = tm.y0; y < tm.y0 + tm.h; ++y)
-			for (int x = tm.x0; x < tm.x0 + tm.w; ++x)
-				pixels.push_back((uint32_t) (y - off) * (uint32_t) keyW + (uint32_t) (x - off));
+	std::vector<uint32_t> &pixels = c->renderPixels;
+	std::vector<TileMeta> &tiles = c->renderTiles;
+	const std::vector<long long> key = { W, H, bs, off, cx, cy, keyW, c->nParts, c->part };
+	const bool reuse = c->renderListValid && key == c->renderKey && c->pixelList && c->pixelListCap >= pixels.size();
+	if (!reuse) {
+		pixels.clear(); tiles.clear();
+		for (int t = 0; t < tx * ty; ++t) {
+			if (tileMorton((uint32_t) (t % tx), (uint32_t) (t / tx)) % (uint32_t) c->nParts != (uint32_t) c->part) continue;
+			const int x0 = off + (t % tx) * bs, y0 = off + (t / tx) * bs;            // inside the crop window
+			TileMeta tm{};
+			tm.x0 = x0 + cx; tm.y0 = y0 + cy; tm.w = std::min(bs, off + RW - x0); tm.h = std::min(bs, off + RH - y0);
+			tm.slot_base = (uint32_t) pixels.size(); tm.block_index = (uint32_t) tiles.size();
+			tm.colour = (uint32_t) (((t % tx) & 1) + 2 * ((t / tx) & 1));
+			tiles.push_back(tm);
+			for (int y = tm.y0; y < tm.y0 + tm.h; ++y)
+				for (int x = tm.x0; x < tm.x0 + tm.w; ++x)
+					pixels.push_back((uint32_t) (y - off) * (uint32_t) keyW + (uint32_t) (x - off));
+		}
+		c->renderKey = key; c->renderListValid = false;
 	}
 	std::memset(&c->stats, 0, sizeof(c->stats));
 	c->traceEvUsed = c->shadeEvUsed = 0;
 	if (pixels.empty()) return 0;
-	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, pixels.size()); if (rc) return rc;
-	HIPCHK(c, hipMemcpyAsync(c->pixelList, pixels.data(), pixels.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	if (!reuse) {
+		rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, pixels.size()); if (rc) return rc;
+		HIPCHK(c, hipMemcpyAsync(c->pixelList, pixels.data(), pixels.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		c->renderListValid = true;
+	}
 
 	const bool wideFilter = c->filtBorder > 0;
 	if (wideFilter && 2 * c->filtBorder > bs) return fail(c, MTSGPU_EINVAL, "filter border %d too wide for block size %d", c->filtBorder, bs);
@@ -1242,6 +1251,7 @@ int mtsgpu_ld_tables(mtsgpu_ctx *c, uint32_t pixel_key, float *out1d, float *out
 	const int depth = c->ldDepth;
 	int rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, (size_t) 3 * depth); if (rc) return rc;
 	rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, (size_t) 2 * depth * spp); if (rc) return rc;
+	c->renderListValid = false;
 	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, 1); if (rc) return rc;
 	HIPCHK(c, hipMemcpyAsync(c->pixelList, &pixel_key, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	DConfig cfg{};
@@ -1288,6 +1298,7 @@ int mtsgpu_sampler_values(mtsgpu_ctx *c, uint32_t pixel_key, uint32_t sample_ind
 	const uint32_t spp = effectiveSpp(c);
 	if (n > 4096u || sample_index >= spp) return fail(c, MTSGPU_EINVAL, "sample index or count out of range");
 	HIPCHK(c, hipSetDevice(c->device));
+	c->renderListValid = false;
 	int rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, 1); if (rc) return rc;
 	HIPCHK(c, hipMemcpyAsync(c->pixelList, &pixel_key, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	if (samplerHasTables(c)) {
@@ -1350,6 +1361,7 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 	}
 	rc = ensurePaths(c, n); if (rc) return rc;
 	rc = ensureBuf(c, &c->explicitSamples, &c->explicitCap, 3 * (size_t) n); if (rc) return rc;
+	c->renderListValid = false;
 	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, n); if (rc) return rc;
 	HIPCHK(c, hipMemcpyAsync(c->explicitSamples, pix_samples, 3 * (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipMemcpyAsync(c->pixelList, keys.data(), (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));

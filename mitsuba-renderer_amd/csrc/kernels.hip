@@ -163,9 +163,18 @@ __global__ __launch_bounds__(64) void k_ld_tables_lds(DConfig cfg, const uint32_
 		}
 		__syncthreads();
 		const uint32_t rows = (n_slots - slot0 < L) ? n_slots - slot0 : L;
-		for (uint32_t r = 0; r < rows; ++r) {
-			uint16_t *dst = perm + ((size_t) (slot0 + r) * 2 * depth + arr) * spp;
-			for (uint32_t k = lane; k < spp; k += 64u) dst[k] = s_p[k * L + ((r ^ k) & lm)];
+		if (spp >= 64u) {
+			for (uint32_t r = 0; r < rows; ++r) {
+				uint16_t *dst = perm + ((size_t) (slot0 + r) * 2 * depth + arr) * spp;
+				for (uint32_t k = lane; k < spp; k += 64u) dst[k] = s_p[k * L + ((r ^ k) & lm)];
+			}
+		} else {
+			// short rows (a 1-spp frame: one entry per pixel): the lanes share out (row, entry) pairs instead of walking the
+			// rows one by one with most of the wave idle
+			for (uint32_t idx = lane; idx < rows * spp; idx += 64u) {
+				const uint32_t r = idx / spp, k = idx - r * spp;
+				perm[((size_t) (slot0 + r) * 2 * depth + arr) * spp + k] = s_p[k * L + ((r ^ k) & lm)];
+			}
 		}
 		__syncthreads();
 	}
