@@ -2638,7 +2638,7 @@ void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, co
 
 void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,
                        uint32_t spp_per_slot, float *film, unsigned long long *path_len) {
-	if (n_slots) hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, ps, cfg, n_slots, spp_per_slot, film, path_len);
+	if (n_slots) hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(n_slots, 256)), dim3(256), 0, s, ps, cfg, n_slots, spp_per_slot, film, path_len);
 }
 void launch_path_lengths(hipStream_t s, const DPaths &ps, uint32_t n_paths, unsigned long long *path_len) {
 	if (n_paths) hipLaunchKernelGGL(k_path_lengths, dim3(blocks_for(n_paths, 256)), dim3(256), 0, s, ps, n_paths, path_len);
