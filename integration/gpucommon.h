@@ -59,8 +59,8 @@ inline void rgbOf(const Spectrum &s, float *out) {
 	out[0] = (float) r; out[1] = (float) g; out[2] = (float) b;
 }
 
-inline void copyMatrix(float *dst, const Matrix4x4 *m) {
-	for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) dst[4 * i + j] = (float) m->m[i][j];     /* matrix layout: transform.h */
+inline void copyMatrix(float *dst, const Matrix4x4 &m) {
+	for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) dst[4 * i + j] = (float) m.m[i][j];     /* matrix layout: transform.h */
 }
 
 /* Reads back what <BSDF class>::serialize wrote -- the only access to the BSDF plugins' private parameters.  The

@@ -239,3 +239,27 @@ def test_library_is_built_from_the_sources_on_disk(mts):
     """mtsgpu_source_hash() (stamped in by csrc/Makefile, csrc/stamp.cpp) equals the hash of the sources: the binary that
     ships to the GPU box is not a stale one"""
     assert mts.lib().mtsgpu_source_hash().decode() == mts.source_hash()
+
+
+REFERENCE_INCLUDE = "/root/reference/include"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_INCLUDE), reason="the reference checkout is only present in the build container")
+@pytest.mark.parametrize("plugin", ["gpupath", "gpudirect"])
+def test_plugin_sources_pass_the_compiler_front_end(plugin):
+    """integration/<plugin>.cpp + gpucommon.h type-check against Mitsuba's own declarations (Integrator, Scene, ShapeKDTree,
+    ImageBlock, Sampler, InstanceManager, ...: include/mitsuba/render/integrator.h:45-88, core/cobject.h:79-87) and against
+    include/mtsgpu.h.  Syntax only: nothing is compiled to code, nothing of the reference is built or run.  The Boost headers
+    Mitsuba's headers pull in are absent from this image; tests/plugin_syntax/ holds stand-ins for this check alone."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    cmd = ["g++", "-std=gnu++17", "-fsyntax-only", "-Wall", "-DSINGLE_PRECISION", "-include", "unistd.h",
+           "-I" + os.path.join(root, "tests", "plugin_syntax"), "-isystem", REFERENCE_INCLUDE, "-I" + os.path.join(root, "include"),
+           os.path.join(root, "integration", plugin + ".cpp")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert r.returncode == 0, r.stdout[-4000:]
+    ours = [l for l in r.stdout.splitlines() if "integration/" in l and "warning" in l]
+    assert not ours, "\n".join(ours)
