@@ -49,13 +49,13 @@ def algorithmic_bytes(st):
     return 8 * st["n_inner"] + 8 * st["n_leaf"] + 4 * st["n_idx"] + 48 * st["n_idx"] + 48 * rays
 
 
-def algorithmic_requests(st):
-    """Lane-level vector-memory requests the traversal algorithm itself needs: one 16-byte
-    sibling-pair fetch per inner node, one 16-byte record head per index entry, two 8-byte node fetches per pop (a ray
-    pops once per leaf but the last), the ray (2 x 16 B) and the hit (16 B).  The plane-test tails, queue ids and stack
-    spills come on top in the real kernel (PMC: TCP_TOTAL_CACHE_ACCESSES is ~1.25 x this)."""
+def issued_requests(st):
+    """Lane-level vector-memory requests the traversal kernels ISSUED in the counting step (mtsgpu_stats.req_*): sibling
+    pairs and single nodes that were not served by the LDS copy of the top of the tree, one record head per index entry,
+    the record tails, stack spills, and per ray the ray (2 x 16 B) and the hit (16 B; for a shadow ray: origin,
+    direction, and the pending term when it is unoccluded)."""
     rays = st["rays_closest"] + st["rays_shadow"]
-    return st["n_inner"] + st["n_idx"] + 2 * max(st["n_leaf"] - rays, 0) + 3 * rays
+    return st["req_pair_global"] + st["req_node_global"] + st["req_head"] + st["req_tail"] + st["req_spill"] + 3 * rays
 
 
 def shade_algorithmic_bytes(st):
@@ -129,6 +129,10 @@ def cpu_baseline(pkg, sd, res, spp, max_depth, seconds=12.0):
             "mrays_per_s_per_thread": rays1 / 1e6,
             "mrays_per_s_per_thread_all_threads": raysN / 1e6 / cores,
             "scaling_efficiency": rateN / (rate1 * cores),
+            # NOT measured: the same host without the cgroup quota -- every visible CPU at the per-thread rate and
+            # parallel efficiency measured on the granted ones -- so that nobody reads value as "one whole host"
+            "extrapolated_all_visible_cpus": {"value": rateN / cores * visible / 1e6, "unit": "Msamples/s", "cpus": visible,
+                                              "note": "measured %d-thread rate x %d / %d; an extrapolation, not a measurement" % (cores, visible, cores)},
             "build": flags,
             "sample": "centre crops of the %dx%d frame x %d spp: %dx%d pixels on 1 thread (%.1f s), %dx%d pixels on %d threads "
                       "(%d camera samples, %.1f s); oracle/liboracle_native.so, OpenMP over pixels"
@@ -175,6 +179,66 @@ def spawn_workers(n):
     return rc
 
 
+def group_child(args):
+    """--group-child N: the drop-in's own multi-GPU form, timed in a fresh process.  A Mitsuba process calls the
+    integrator once (src/librender/scene.cpp:356-359), so the plugin drives all GPUs from ONE process through
+    mtsgpu_create_multi / mtsgpu_group_render (one host thread per GPU, the films summed by one ncclReduce through a
+    dlopen'ed librccl, or by ordered peer copies; renderproc.cpp:123-130 is the merge being replaced).  Same workload and
+    sharding as the process-per-GPU form above; prints one JSON object."""
+    import _pkgload
+    pkg = _pkgload.load()
+    n = args.group_child
+    devices = [int(x) for x in args.devices.split(",")][:n] if args.devices else list(range(n))
+    sd = pkg.scenes.cornell_c3(grid=args.grid, sphere_subdiv=5)
+    n_tris = 5 * 2 * args.grid * args.grid + 20480
+    scene = pkg.Scene(sd, None, gpu_binning=not args.host_kd, gpu_exact=(not args.host_kd) and n_tris > 2_000_000)
+    spp_total = args.spp_total if args.spp_total > 0 else args.spp * n
+    cam = pkg.PerspectiveCamera.for_description(sd, args.res, args.res)
+    g = pkg.DeviceGroup(devices, maxDepth=sd.max_depth, rrDepth=sd.rr_depth)
+    g.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp_total, seed=0x5EED)
+    assert g.render()                           # warm-up: buffers, RCCL communicators
+    times = []
+    for _ in range(max(1, args.steps)):
+        t0 = time.perf_counter()
+        assert g.render()                       # returns with the reduced film in member 0
+        times.append((time.perf_counter() - t0) * 1e3)
+    ms = sum(times) / len(times)
+    out = {"form": "one process, %d GPUs: mtsgpu_create_multi + mtsgpu_group_render" % n, "devices": devices,
+           "group_ms_per_step": ms, "group_ms_best": min(times), "steps": len(times),
+           "value": args.res * args.res * spp_total / (ms * 1e-3) / 1e6, "unit": "Msamples/s",
+           "reduce_kind": g.reduce_kind(), "reduce_note": g.reduce_note()}
+    if args.dump_film:
+        import numpy as np
+        np.save(args.dump_film, g.film())
+    print(json.dumps(out), flush=True)
+
+
+def run_group_child(args, world):
+    """rank 0, after every rank has finished: the group form in a fresh child process (never exec; 120 s; a failure
+    leaves a note instead of the numbers)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--group-child", str(world), "--steps", "3", "--res", str(args.res),
+           "--spp", str(args.spp), "--spp-total", str(args.spp_total), "--grid", str(args.grid)]
+    if args.host_kd:
+        cmd.append("--host-kd")
+    if args.devices:
+        cmd += ["--devices", args.devices]
+    if args.dump_group_film:
+        cmd += ["--dump-film", args.dump_group_film]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": "exit code %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within 120 s"}
+    except Exception as e:
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,7 +255,13 @@ def main():
     ap.add_argument("--devices", default="", help="comma list: HIP device of each local rank (default: LOCAL_RANK). "
                     "Ranks sharing a device reduce their films through gloo on host copies (test mode)")
     ap.add_argument("--dump-film", default="", help="rank 0 writes the reduced film of the last step to this .npy file")
+    ap.add_argument("--group-child", type=int, default=0, help="(internal) time the one-process device group over N GPUs and print its JSON")
+    ap.add_argument("--no-group", action="store_true", help="skip the one-process device-group timing")
+    ap.add_argument("--dump-group-film", default="", help="the group child writes its reduced film to this .npy file")
     args = ap.parse_args()
+
+    if args.group_child > 0:
+        return group_child(args)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_workers(args.gpus))
@@ -283,28 +353,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # --- untimed: warmup + one counting step (algorithmic work of the traversal kernels) ---
-    it.set_options(max_paths=args.max_paths, count_traversal=False, time_kernels=True)
+    # --- untimed: warmup, one counting step (algorithmic work of the traversal kernels), and KT steps with a HIP-event
+    # pair around every launch on the library's streams: the per-kernel durations of the roofline blocks.  The timed
+    # steps below run WITHOUT those events (about 130 event pairs per frame are not part of the hot path).
+    it.set_options(max_paths=args.max_paths, count_traversal=False, time_kernels=False)
     for _ in range(args.warmup):
         step()
-    it.set_options(max_paths=args.max_paths, count_traversal=True, time_kernels=True)
+    it.set_options(max_paths=args.max_paths, count_traversal=True, time_kernels=False)
     step()
     torch.cuda.synchronize()
     counts = it.stats()
     bytes_per_step = algorithmic_bytes(counts)
     it.set_options(max_paths=args.max_paths, count_traversal=False, time_kernels=True)
-
-    # --- timed region: exactly K steps between barriers ---
     trace_ms = 0.0
     trace_launches = 0
     shade_ms = 0.0
+    kt_steps = 2
+    for _ in range(kt_steps):
+        step()
+        st = it.stats()                     # per-launch HIP-event durations on the library's streams
+        trace_ms += st["trace_ms"]; shade_ms += st["shade_ms"]; trace_launches += st["trace_launches"]
+    trace_ms /= kt_steps; shade_ms /= kt_steps; trace_launches /= kt_steps      # per step from here on
+    it.set_options(max_paths=args.max_paths, count_traversal=False, time_kernels=False)
+
+    # --- timed region: exactly K steps between barriers ---
     fence()
     split["render_s"] = split["reduce_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        st = it.stats()                     # per-launch HIP-event durations on the library's stream
-        trace_ms += st["trace_ms"]; shade_ms += st["shade_ms"]; trace_launches += st["trace_launches"]
     fence()
     elapsed = time.perf_counter() - t0
     rank_ms = [split["render_s"] / args.steps * 1e3]
@@ -322,6 +399,22 @@ def main():
         reduce_ms = [float(e[1].item()) for e in every]
     if args.dump_film and rank == 0:
         np.save(args.dump_film, film.cpu().numpy())
+
+    # --- replay roof of the closest-hit kernel on a sample of the frame's own rays (untimed; rank 0) ---
+    replay_raw = None
+    replay_note = None
+    r_stride = 1
+    if rank == 0:
+        try:
+            avail = W * H * spp_total // world
+            r_stride = 8 if avail >= (32 << 20) else 1
+            r_n = min(8 << 20, avail // r_stride)          # 8 M rays: twice the size from which the early loop exits are on
+            if r_n >= 65536:
+                replay_raw = it.replay_roof(r_n, r_stride, reps=3)
+            else:
+                replay_note = "frame too small for a replay sample"
+        except Exception as e:
+            replay_note = "%s: %s" % (type(e).__name__, e)
 
     # --- time to a 1-spp frame (second half of BASELINE.json's metric), untimed region ---
     one_spp_ms = None
@@ -354,14 +447,32 @@ def main():
             pass
         total_samples = W * H * spp_total * args.steps
         value = total_samples / elapsed / 1e6
-        achieved = bytes_per_step * args.steps / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        achieved = bytes_per_step / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         rays = counts["rays_closest"] + counts["rays_shadow"]
         triad = pkg.hbm_triad_gbs(device)
         gather = pkg.gather_roof(device, 4)
-        req_per_step = algorithmic_requests(counts)
-        req_rate = req_per_step * args.steps / (trace_ms * 1e-3) if trace_ms > 0 else 0.0
+        req_per_step = issued_requests(counts)
+        replay = {"kernel": "k_trace<closest>", "bound": "vector-memory requests: the kernel's own request stream replayed without arithmetic "
+                  "(mtsgpu_replay_roof: same lines in the same per-ray order, node requests chained, same grid and LDS footprint)",
+                  "issued_requests_per_ray": req_per_step / max(rays, 1),
+                  "lds_served_requests_per_ray": (counts["req_pair_lds"] + counts["req_node_lds"]) / max(rays, 1),
+                  "issued_breakdown_per_ray": {"pairs": counts["req_pair_global"] / max(rays, 1), "pop_nodes": counts["req_node_global"] / max(rays, 1),
+                                               "record_heads": counts["req_head"] / max(rays, 1), "record_tails": counts["req_tail"] / max(rays, 1),
+                                               "stack_spills": counts["req_spill"] / max(rays, 1), "ray_and_hit": 3.0},
+                  "random_gather_4MiB_G_per_s": gather / 1e9 if gather else None,
+                  "note": replay_note}
+        if replay_raw:
+            rr = replay_raw
+            replay.update({
+                "sample": "%d closest-hit rays: the last ray of every %dth path of the frame just rendered" % (rr["rays"], r_stride),
+                "sample_requests_per_ray": rr["requests"] / rr["rays"], "sample_truncated_rays": rr["truncated_rays"],
+                "product_ms": rr["product_ms"], "replay_ms": rr["replay_ms"],
+                "achieved": rr["requests"] / (rr["product_ms"] * 1e-3) / 1e9, "peak": rr["requests"] / (rr["replay_ms"] * 1e-3) / 1e9,
+                "unit": "G lane-requests/s", "frac": rr["replay_ms"] / rr["product_ms"],
+                "replay_floor_trace_ms_per_step": trace_ms * rr["replay_ms"] / rr["product_ms"],
+            })
         sh_bytes = shade_algorithmic_bytes(counts)
-        sh_achieved = sh_bytes * args.steps / (shade_ms * 1e-3) / 1e9 if shade_ms > 0 else 0.0
+        sh_achieved = sh_bytes / (shade_ms * 1e-3) / 1e9 if shade_ms > 0 else 0.0
         out = {
             "metric": "Msamples/s", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -390,30 +501,29 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_step / max(counts["trace_launches"], 1),
                 "algorithmic_bytes_per_step": bytes_per_step, "bytes_per_ray": bytes_per_step / max(rays, 1),
                 "rays_per_step": rays, "launches_per_step": counts["trace_launches"],
-                "avg_launch_ms": trace_ms / max(trace_launches, 1), "trace_ms_per_step": trace_ms / args.steps,
-                "shade_ms_per_step": shade_ms / args.steps,
+                "avg_launch_ms": trace_ms / max(trace_launches, 1), "trace_ms_per_step": trace_ms,
+                "kernel_times_from": "%d untimed steps with HIP events around every launch, right before the timed steps" % kt_steps,
+                "shade_ms_per_step": shade_ms,
                 "n_inner_per_ray": counts["n_inner"] / max(rays, 1), "n_leaf_per_ray": counts["n_leaf"] / max(rays, 1),
                 "n_idx_per_ray": counts["n_idx"] / max(rays, 1), "n_tri_tested_per_ray": counts["n_tri_tested"] / max(rays, 1),
             },
-            "roofline_requests": {
-                "kernel": "k_trace", "bound": "vector-memory request rate (TA / TCP): 16-byte gathers, one cache line per lane",
-                "achieved": req_rate / 1e9, "peak": gather / 1e9 if gather else None, "unit": "G lane-requests/s",
-                "frac": req_rate / gather if gather else None,
-                "peak_source": "mtsgpu_gather_roof: random 16-byte loads over a 4 MiB footprint, measured in this run",
-                "algorithmic_requests_per_ray": req_per_step / max(rays, 1),
-            },
+            "roofline_requests": replay,
             "roofline_shade": {
                 "kernel": "k_shade (one Li iteration per path: emitter hit, MIS, RR, NEE sample, BSDF sample); ms_per_step brackets the k_shade launches only",
                 "bound": "hbm", "achieved": sh_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sh_achieved / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_step": sh_bytes, "ms_per_step": shade_ms / args.steps,
+                "algorithmic_bytes_per_step": sh_bytes, "ms_per_step": shade_ms,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, sd, args.res, args.spp, sd.max_depth)
-        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if not args.no_group:
+            # every rank is done (the others exit now): the form the Mitsuba plugin uses, all GPUs behind one process
+            out["group"] = run_group_child(args, world)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MTSGPU_ABI_VERSION 4
+#define MTSGPU_ABI_VERSION 5
 
 enum {
 	MTSGPU_OK = 0,
@@ -216,6 +216,12 @@ typedef struct mtsgpu_stats {
 	/* time during which at least one traversal launch was running (the shadow rays of a bounce run next to the
 	 * closest-hit launch of the following one when `overlap` is on: trace_ms then counts that time twice) */
 	double trace_union_ms;
+	/* vector-memory requests the traversal kernels ISSUED (lane level; only filled when counting is on): 16-byte sibling
+	 * pairs fetched from global memory / served by the LDS copy of the top of the tree, single 8-byte nodes (two per pop)
+	 * from global memory / from the LDS copy, 16-byte tails of leaf records (two per primitive whose plane distance lies
+	 * inside the ray's interval), stack words spilled to HBM, 16-byte record heads (n_idx plus the heads fetched again when
+	 * an interrupted leaf is resumed).  Ray and hit: 3 per ray. */
+	uint64_t req_pair_global, req_pair_lds, req_node_global, req_node_lds, req_tail, req_spill, req_head;
 } mtsgpu_stats;
 
 typedef struct mtsgpu_ctx mtsgpu_ctx;
@@ -326,6 +332,9 @@ int  mtsgpu_group_last_reduce_kind(const mtsgpu_group *g);
  * its result is received in a staging buffer, the members' films stay as rendered, the group stops using RCCL and adds
  * the films up in member order. */
 const char *mtsgpu_group_reduce_note(const mtsgpu_group *g);
+/* mtsgpu_set_tuning on every member.  One key belongs to the group itself and exists for tests: "rccl_fail" != 0 makes
+ * the next collectives report a failure, which exercises the fall-back to the ordered sum. */
+int  mtsgpu_group_set_tuning(mtsgpu_group *g, const char *key, long value);
 
 /* HBM triad a[i] = b[i] + s * c[i] over three arrays of `bytes` each on `device` (float4 lanes, best of `iters`
  * launches): the practical bandwidth roof next to the 8 TB/s specification.  GB/s in *gbs. */
@@ -335,6 +344,16 @@ int  mtsgpu_hbm_triad(int device, size_t bytes, int iters, double *gbs);
  * element from `footprint_bytes` (a power of two; 4 MiB sits in the L2 like the upper kd-tree), with k_trace's grid
  * shape.  The traversal kernel is bound by this rate, not by DRAM bytes. */
 int  mtsgpu_gather_roof(int device, size_t footprint_bytes, double *lane_requests_per_s);
+/* Measurement: the REPLAY roof of the closest-hit traversal kernel.  Takes every stride-th of the first n * stride path
+ * records in memory -- after mtsgpu_render() each holds the last ray of its path -- traces them once with the counting
+ * kernel, which records every vector-memory request of every ray (which sibling pair, node, leaf-record chunk, path-record
+ * slot), then times (a) the product kernel and (b) a kernel that re-issues exactly those requests, in the same order per
+ * ray, node requests chained like the descent, from the same grid shape, with NO arithmetic, no stack, no mailbox: the
+ * time the memory system needs for this request stream.  (b) / (a) is the fraction of its request roof the kernel runs at.
+ * out[12]: rays, recorded requests, rays whose list was truncated (256 requests), product ms, replay ms (best of reps),
+ * then the issued-request counters of the sample: pairs global / LDS, nodes global / LDS, record heads, tails, spills.
+ * Overwrites the hits of the sampled path records; call after the film has been read. */
+int  mtsgpu_replay_roof(mtsgpu_ctx *ctx, uint32_t n, uint32_t stride, int reps, double *out);
 
 /* --- standalone kernels exposed for parity tests and the traversal benchmark */
 /* ShapeKDTree::rayIntersect(ray, its) / (ray) on n host rays.

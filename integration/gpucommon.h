@@ -646,6 +646,10 @@ struct GPURenderDriver {
 		const int rc = mtsgpu_group_render(group, bs, /* ordered_reduce = */ box ? 0 : 1, &cancelFlag);
 		if (rc == MTSGPU_ECANCEL) return false;
 		if (rc != MTSGPU_OK) SLog(EError, "libmtsgpu: %s", mtsgpu_group_last_error(group));
+		/* a collective that could not be used is not an error (the films were added up in member order instead), but
+		 * the user should learn why the xGMI reduce did not run */
+		const char *note = mtsgpu_group_reduce_note(group);
+		if (note && note[0]) SLog(EWarn, "libmtsgpu: film reduce fell back to the ordered sum: %s", note);
 
 		/* --- hand the film back as ImageBlocks: every Film plugin (exrfilm, pngfilm, mfilm) and the GUI keep working.
 		 *     The sums of the crop window go out as border-less blocks: the filter has been applied already. --- */

@@ -32,7 +32,7 @@ EXPORTS = [
     "mtsgpu_make_camera_crop", "mtsgpu_hbm_triad", "mtsgpu_sampler_values", "mtsgpu_random_values", "mtsgpu_set_tuning", "mtsgpu_gather_roof",
     "mtsgpu_create_multi", "mtsgpu_group_destroy", "mtsgpu_group_size", "mtsgpu_group_ctx", "mtsgpu_group_last_error",
     "mtsgpu_group_upload_scene", "mtsgpu_group_set_camera", "mtsgpu_group_set_integrator", "mtsgpu_group_set_sampler",
-    "mtsgpu_group_set_rfilter", "mtsgpu_group_render", "mtsgpu_group_last_reduce_kind", "mtsgpu_group_reduce_note", "mtsgpu_bsdf_eval",
+    "mtsgpu_group_set_rfilter", "mtsgpu_group_render", "mtsgpu_group_last_reduce_kind", "mtsgpu_group_reduce_note", "mtsgpu_bsdf_eval", "mtsgpu_replay_roof", "mtsgpu_group_set_tuning",
 ]
 
 
@@ -79,21 +79,34 @@ def built_hash(path=None):
         return None
 
 
+def _probe_hash(lib_path):
+    """mtsgpu_source_hash() of the file at lib_path, asked in a child process (a library already loaded here would answer
+    for the OLD file).  Returns (hash, None) or (None, why the library could not be loaded or asked)."""
+    probe = "import ctypes as C; L = C.CDLL(%r); L.mtsgpu_source_hash.restype = C.c_char_p; print(L.mtsgpu_source_hash().decode())" % lib_path
+    r = subprocess.run([os.sys.executable, "-c", probe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if r.returncode != 0:
+        return None, r.stderr.decode(errors="replace").strip().splitlines()[-1:] or ["exit code %d" % r.returncode]
+    return r.stdout.decode().strip(), None
+
+
 def build(force=False):
     """Compile libmtsgpu.so for gfx950 (hipcc cross-compiles without a GPU).  make is incremental; a binary whose stamped
-    source hash differs from the sources on disk (e.g. a copied-in .so newer than the files) is rebuilt from scratch."""
+    source hash differs from the sources on disk (e.g. a copied-in .so newer than the files) is rebuilt from scratch.  A
+    library that cannot be LOADED is reported as such (with the loader's message), not mistaken for a stale one."""
     csrc = os.path.join(_HERE, "csrc")
-    lib_path = os.path.join(_HERE, "libmtsgpu.so")
+    lib_path = os.path.join(_HERE, "libmtsgpu.so")          # what csrc/Makefile builds; MTSGPU_LIB variants are built by tools/build_variant.sh
     subprocess.check_call(["make", "-C", csrc, "-j4"] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
-    # checked in a child process: a library that is already loaded here would answer for the OLD file
-    probe = "import ctypes as C; L = C.CDLL(%r); L.mtsgpu_source_hash.restype = C.c_char_p; print(L.mtsgpu_source_hash().decode())" % lib_path
-    got = subprocess.run([os.sys.executable, "-c", probe], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().strip()
+    got, why = _probe_hash(lib_path)
+    if why is not None:
+        raise MtsGpuError("libmtsgpu.so was built but cannot be loaded: %s" % "; ".join(why))
     if got != source_hash():
         subprocess.check_call(["make", "-C", csrc, "-j4", "-B"], stdout=subprocess.DEVNULL)
-        got = subprocess.run([os.sys.executable, "-c", probe], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode().strip()
+        got, why = _probe_hash(lib_path)
+        if why is not None:
+            raise MtsGpuError("libmtsgpu.so cannot be loaded after a full rebuild: %s" % "; ".join(why))
         if got != source_hash():
             raise MtsGpuError("libmtsgpu.so reports source hash %r after a full rebuild, the sources hash to %r" % (got, source_hash()))
-    return LIB_PATH
+    return lib_path
 
 
 _lib = None
@@ -149,6 +162,7 @@ def lib():
     L.mtsgpu_random_values.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.mtsgpu_bsdf_eval.argtypes = [vp, C.c_uint32, f32p, C.c_int, C.c_uint32, f32p, f32p]
     L.mtsgpu_hbm_triad.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    L.mtsgpu_replay_roof.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
     L.mtsgpu_create_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     L.mtsgpu_group_destroy.argtypes = [vp]; L.mtsgpu_group_destroy.restype = None
     L.mtsgpu_group_size.argtypes = [vp]
@@ -162,6 +176,7 @@ def lib():
     L.mtsgpu_group_render.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.mtsgpu_group_last_reduce_kind.argtypes = [vp]
     L.mtsgpu_group_reduce_note.argtypes = [vp]; L.mtsgpu_group_reduce_note.restype = C.c_char_p
+    L.mtsgpu_group_set_tuning.argtypes = [vp, C.c_char_p, C.c_long]
     _lib = L
     return L
 
@@ -375,6 +390,15 @@ class MIPathTracer:
         self._chk(lib().mtsgpu_trace_rays(self._ctx, abi.ptr(r, abi.f32p), r.shape[0], int(shadow), abi.ptr(hits, abi.u32p)), "trace_rays")
         return hits
 
+    def replay_roof(self, n, stride=1, reps=3):
+        """mtsgpu_replay_roof: the request stream of n closest-hit rays (every stride-th path record of the frame rendered
+        last) replayed without arithmetic, next to the product kernel on the same rays"""
+        out = (C.c_double * 12)()
+        self._chk(lib().mtsgpu_replay_roof(self._ctx, int(n), int(stride), int(reps), out), "replay_roof")
+        keys = ["rays", "requests", "truncated_rays", "product_ms", "replay_ms", "pair_global", "pair_lds", "node_global", "node_lds",
+                "heads", "tails", "spills"]
+        return dict(zip(keys, list(out)))
+
     def ld_tables(self, pixel_key, spp, depth):
         t1 = np.zeros((depth, spp), dtype=np.float32)
         t2 = np.zeros((depth, spp, 2), dtype=np.float32)
@@ -487,6 +511,11 @@ class DeviceGroup:
 
     def reduce_kind(self):
         return {0: "ordered peer-copy sum", 1: "rccl ncclReduce"}.get(lib().mtsgpu_group_last_reduce_kind(self._g))
+
+    def set_tuning(self, **knobs):
+        """mtsgpu_set_tuning on every member (and the group's own test knob rccl_fail)"""
+        for k, v in knobs.items():
+            self._chk(lib().mtsgpu_group_set_tuning(self._g, k.encode(), int(v)), "group_set_tuning")
 
     def reduce_note(self):
         """why the last render fell back to the ordered sum ("" when it did not)"""

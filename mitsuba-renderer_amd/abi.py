@@ -5,7 +5,7 @@ against the sizes the C compiler reports (mtsgpu_abi_sizeof)."""
 import ctypes as C
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET, BSDF_MIRROR, BSDF_PHONG, BSDF_ROUGHGLASS, BSDF_DIFFTRANS = 0, 1, 2, 3, 4, 5, 6, 7
 BSDF_TWOSIDED = 0x100
 BSDF_NPARAMS = 16
@@ -60,6 +60,8 @@ class Stats(C.Structure):
         ("trace_ms", C.c_double), ("shade_ms", C.c_double), ("total_ms", C.c_double),
         ("path_length_sum", C.c_uint64), ("bin_overflow_retries", C.c_uint64),
         ("trace_union_ms", C.c_double),
+        ("req_pair_global", C.c_uint64), ("req_pair_lds", C.c_uint64), ("req_node_global", C.c_uint64), ("req_node_lds", C.c_uint64),
+        ("req_tail", C.c_uint64), ("req_spill", C.c_uint64), ("req_head", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -68,7 +68,6 @@ void applyTuning(mtsgpu_ctx *c) {
 	c->q.tune_dyn_div = (uint32_t) get("dyn_div", 0);
 	c->q.tune_xcd = (uint32_t) get("xcd_segments", 0);
 	c->q.tune_blocks_per_cu = (uint32_t) get("blocks_per_cu", 0);
-	c->q.tune_step_cap = (uint32_t) get("step_cap", 0);
 	c->q.tune_plain_below = (uint32_t) get("plain_below", 0);
 	if (c->q.tune_xcd) c->q.force_static = 1u;
 }
@@ -118,7 +117,7 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	rc |= devAlloc(c, &c->counterSets, (size_t) kCounterSets * kNumCounters * kCounterStride, o);
 	rc |= devAlloc(c, &c->viewsDev, kNumBins, o);
 	rc |= devAlloc(c, &c->devStats, kNumDevStats, o);
-	rc |= devAlloc(c, &c->q.trace_counts, 8, o);
+	rc |= devAlloc(c, &c->q.trace_counts, kNumTraceCounts, o);
 	rc |= devAlloc(c, &c->spillClosest, (size_t) gridBlocksMax * kTraceBlock * trace_spill_levels(), o);
 	rc |= devAlloc(c, &c->spillShadow, (size_t) gridBlocksMax * kTraceBlock * trace_spill_levels(), o);
 	if (rc) return rc;
@@ -126,7 +125,8 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	c->q.spill_stride = gridBlocksMax * kTraceBlock;
 	c->q.n_cus = c->nCUs; c->q.force_static = 0;
 	applyTuning(c);
-	HIPCHK(c, hipMemset(c->q.trace_counts, 0, 8 * sizeof(unsigned long long)));
+	HIPCHK(c, hipMemset(c->q.trace_counts, 0, kNumTraceCounts * sizeof(unsigned long long)));
+	c->q.rec = c->q.rec_len = nullptr; c->q.rec_cap = 0;
 	c->pathCap = cap;
 	return 0;
 }
@@ -531,9 +531,12 @@ void collectTimings(mtsgpu_ctx *c) {
 }
 
 int fetchTraceCounts(mtsgpu_ctx *c) {
-	unsigned long long h[8];
+	unsigned long long h[kNumTraceCounts];
 	HIPCHK(c, hipMemcpy(h, c->q.trace_counts, sizeof(h), hipMemcpyDeviceToHost));
 	c->stats.n_inner = h[0]; c->stats.n_leaf = h[1]; c->stats.n_idx = h[2]; c->stats.n_tri_tested = h[3];
+	c->stats.req_pair_global = h[kCntPairGlobal]; c->stats.req_pair_lds = h[kCntPairLds];
+	c->stats.req_node_global = h[kCntNodeGlobal]; c->stats.req_node_lds = h[kCntNodeLds];
+	c->stats.req_tail = h[kCntTail]; c->stats.req_spill = h[kCntSpill]; c->stats.req_head = h[kCntHead];
 	if (getenv("MTSGPU_DEBUG"))     // SIMD utilisation of the traversal loops: lane steps / lane slots issued
 		fprintf(stderr, "[mtsgpu] lanes: inner %llu/%llu (%.3f)  leaf-prims %llu/%llu (%.3f)  outer %llu/%llu (%.3f)  batch slots %llu\n",
 		        h[0], h[4], h[4] ? (double) h[0] / h[4] : 0.0, h[2], h[5], h[5] ? (double) h[2] / h[5] : 0.0,
@@ -819,20 +822,7 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 				}
 			}
 		}
-		if (MG_LEAF_SPLIT) {
-			// heads (dwords 0..3) first, then the 32-byte tails: one allocation, two views
-			const size_t nE = (size_t) sc->n_indices + 1;
-			std::vector<uint32_t> split(12 * nE, 0u);
-			for (size_t e = 0; e < nE; ++e) {
-				std::memcpy(&split[4 * e], &ta[12 * e], 16);
-				std::memcpy(&split[4 * nE + 8 * e], &ta[12 * e + 4], 32);
-			}
-			rc |= upload(c, (const uint32_t **) &d.leaf_ta, split.data(), split.size());
-			d.leaf_tail = d.leaf_ta ? d.leaf_ta + nE : nullptr;
-		} else {
-			rc |= upload(c, (const uint32_t **) &d.leaf_ta, ta.data(), ta.size());
-			d.leaf_tail = d.leaf_ta;
-		}
+		rc |= upload(c, (const uint32_t **) &d.leaf_ta, ta.data(), ta.size());
 		// per-primitive position / normal records for the shading kernels
 		const size_t TS = 4 * (size_t) kTriStride;                    // floats per record (one 128-byte line)
 		std::vector<float> triRec(TS * ((size_t) sc->n_tris + 1), 0.0f);
@@ -1024,7 +1014,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "xcd_segments", 0, 1 }, { "blocks_per_cu", 0, 8 }, { "step_cap", 0, 1 << 20 }, { "plain_below", 0, 1 << 30 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "xcd_segments", 0, 1 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);
@@ -1106,6 +1096,9 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	if (!reuse) {
 		rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, pixels.size()); if (rc) return rc;
 		HIPCHK(c, hipMemcpyAsync(c->pixelList, pixels.data(), pixels.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		// valid only once the copy has landed: a frame that leaves early (cancel, an error) and a caller that then switches
+		// streams (mtsgpu_set_stream) must not find a list that is marked valid but not ordered before its next use
+		HIPCHK(c, hipStreamSynchronize(c->stream));
 		c->renderListValid = true;
 	}
 
@@ -1121,7 +1114,7 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, slotsPerPass * 2 * c->ldDepth * spp); if (rc) return rc;
 	}
 	rc = ensureSampleArrays(c, slotsPerPass, slotsPerPass * spp); if (rc) return rc;
-	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 8 * sizeof(unsigned long long), c->stream));
+	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, kNumTraceCounts * sizeof(unsigned long long), c->stream));
 	DConfig cfg = makeConfig(c, false);
 	cfg.pix_w = keyW; cfg.pix_off = off;
 	HIPCHK(c, hipMemsetAsync(c->pathLen, 0, sizeof(unsigned long long), c->stream));
@@ -1149,7 +1142,9 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 			// whole tiles only: a block gathers from all samples of its tile
 			size_t acc = 0;
 			while (tileCursor < tiles.size() && (acc == 0 || acc + (size_t) tiles[tileCursor].w * tiles[tileCursor].h <= slotsPerPass)) {
-				tiles[tileCursor].slot_base = (uint32_t) acc;                 // slot inside this pass
+				// slot inside this pass.  The cached tile list is updated in place: every tile passes through this line in
+				// every frame before its record is uploaded below, so nothing of an earlier frame's passes survives
+				tiles[tileCursor].slot_base = (uint32_t) acc;
 				acc += (size_t) tiles[tileCursor].w * tiles[tileCursor].h;
 				++tileCursor;
 			}
@@ -1227,7 +1222,7 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 	}
 	launch_iota(c->stream, c->queueA, n);
-	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, 8 * sizeof(unsigned long long), c->stream));
+	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, kNumTraceCounts * sizeof(unsigned long long), c->stream));
 	hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
 	if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
 	HIPCHK(c, hipMemsetAsync(c->q.counters, 0, kNumCounters * kCounterStride * sizeof(uint32_t), c->stream));     // dynamic batch head
@@ -1240,6 +1235,83 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 	if (shadow) c->stats.rays_shadow = n; else c->stats.rays_closest = n;
 	collectTimings(c);
 	if (c->countTraversal) { rc = fetchTraceCounts(c); if (rc) return rc; }
+	return 0;
+}
+
+// The replay roof of the closest-hit traversal kernel (include/mtsgpu.h).
+int mtsgpu_replay_roof(mtsgpu_ctx *c, uint32_t n, uint32_t stride, int reps, double *out) {
+	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	if (!c->haveScene) return fail(c, MTSGPU_ESTATE, "no scene uploaded");
+	if (!out || n == 0 || stride == 0 || reps < 1) return fail(c, MTSGPU_EINVAL, "bad argument");
+	if ((uint64_t) n * stride > c->pathCap || ((uint64_t) (n - 1) * stride + 1) * kPathSlots > (1ull << 29))
+		return fail(c, MTSGPU_EINVAL, "replay roof: %u rays x stride %u exceed the path records in memory (%zu) or the 2^29 slots a recorded index can name", n, stride, c->pathCap);
+	HIPCHK(c, hipSetDevice(c->device));
+	hipStream_t s = c->stream;
+	const uint32_t cap = 256;                  // requests kept per ray (C3: 45 on average; longer lists are truncated and counted); % 4 == 0
+	const uint32_t nBatches = (n + 63u) / 64u;
+	uint32_t *rec = nullptr, *recLen = nullptr, *order = nullptr, *tr = nullptr, *batchLen = nullptr, *sink = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	auto cleanup = [&]() {
+		for (uint32_t *p : { rec, recLen, order, tr, batchLen, sink }) if (p) (void) hipFree(p);
+		if (e0) (void) hipEventDestroy(e0);
+		if (e1) (void) hipEventDestroy(e1);
+		c->q.rec = c->q.rec_len = nullptr; c->q.rec_cap = 0;
+	};
+	#define RR_CHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); \
+		return fail(c, MTSGPU_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
+	RR_CHK(hipMalloc((void **) &rec, (size_t) n * cap * 4)); RR_CHK(hipMalloc((void **) &recLen, (size_t) n * 4));
+	RR_CHK(hipMalloc((void **) &order, (size_t) n * 4)); RR_CHK(hipMalloc((void **) &tr, (size_t) nBatches * cap * 64 * 4));
+	RR_CHK(hipMalloc((void **) &batchLen, (size_t) nBatches * 4)); RR_CHK(hipMalloc((void **) &sink, 4));
+	RR_CHK(hipEventCreate(&e0)); RR_CHK(hipEventCreate(&e1));
+	// the rays: every stride-th path record of the frame that was rendered last (each holds the last ray of its path)
+	launch_iota_strided(s, c->queueA, n, stride);
+	const size_t counterBytes = kNumCounters * kCounterStride * sizeof(uint32_t);
+	c->q.counters = c->counterSets; c->q.spill = c->spillClosest; c->q.dev_stats = nullptr;
+	// 1. the counting kernel records what every ray asks for
+	RR_CHK(hipMemsetAsync(recLen, 0, (size_t) n * 4, s));
+	RR_CHK(hipMemsetAsync(c->q.trace_counts, 0, kNumTraceCounts * sizeof(unsigned long long), s));
+	RR_CHK(hipMemsetAsync(c->q.counters, 0, counterBytes, s));
+	c->q.rec = rec; c->q.rec_len = recLen; c->q.rec_cap = cap;
+	launch_trace(s, 0, true, false, c->dsc, c->paths, c->q, c->queueA, n, false);
+	c->q.rec = c->q.rec_len = nullptr; c->q.rec_cap = 0;
+	RR_CHK(hipGetLastError());
+	std::vector<uint32_t> len(n);
+	RR_CHK(hipMemcpyAsync(len.data(), recLen, (size_t) n * 4, hipMemcpyDeviceToHost, s));
+	RR_CHK(hipStreamSynchronize(s));
+	unsigned long long cnt[kNumTraceCounts];
+	RR_CHK(hipMemcpy(cnt, c->q.trace_counts, sizeof(cnt), hipMemcpyDeviceToHost));
+	// 2. rays by decreasing list length, 64 to a batch (lanes of a replay wave then finish together); a counting sort
+	std::vector<uint32_t> ord(n), first(cap + 2, 0u);
+	unsigned long long total = 0, truncated = 0;
+	for (uint32_t i = 0; i < n; ++i) { const uint32_t l = std::min(len[i], cap); total += l; if (len[i] > cap) ++truncated; first[cap - l + 1]++; }
+	for (uint32_t l = 0; l <= cap; ++l) first[l + 1] += first[l];
+	for (uint32_t i = 0; i < n; ++i) ord[first[cap - std::min(len[i], cap)]++] = i;
+	RR_CHK(hipMemcpyAsync(order, ord.data(), (size_t) n * 4, hipMemcpyHostToDevice, s));
+	launch_build_replay(s, rec, recLen, order, n, cap, tr, batchLen);
+	RR_CHK(hipGetLastError());
+	// 3. the product kernel and the replay on the same rays, best of `reps`
+	float prodMs = 1e30f, replayMs = 1e30f;
+	for (int i = 0; i <= reps; ++i) {            // round 0 warms up
+		RR_CHK(hipMemsetAsync(c->q.counters, 0, counterBytes, s));
+		RR_CHK(hipEventRecord(e0, s));
+		launch_trace(s, 0, false, false, c->dsc, c->paths, c->q, c->queueA, n, false);
+		RR_CHK(hipEventRecord(e1, s));
+		RR_CHK(hipEventSynchronize(e1));
+		float ms = 0; RR_CHK(hipEventElapsedTime(&ms, e0, e1));
+		if (i && ms < prodMs) prodMs = ms;
+		RR_CHK(hipEventRecord(e0, s));
+		launch_replay(s, c->dsc, c->paths, c->q, tr, batchLen, nBatches, cap, 0u, sink);
+		RR_CHK(hipEventRecord(e1, s));
+		RR_CHK(hipEventSynchronize(e1));
+		RR_CHK(hipEventElapsedTime(&ms, e0, e1));
+		if (i && ms < replayMs) replayMs = ms;
+	}
+	#undef RR_CHK
+	cleanup();
+	out[0] = (double) n; out[1] = (double) total; out[2] = (double) truncated;
+	out[3] = prodMs; out[4] = replayMs;
+	out[5] = (double) cnt[kCntPairGlobal]; out[6] = (double) cnt[kCntPairLds]; out[7] = (double) cnt[kCntNodeGlobal]; out[8] = (double) cnt[kCntNodeLds];
+	out[9] = (double) cnt[kCntHead]; out[10] = (double) cnt[kCntTail]; out[11] = (double) cnt[kCntSpill];
 	return 0;
 }
 

@@ -70,6 +70,7 @@ struct mtsgpu_group {
 	float *staging = nullptr; size_t stagingFloats = 0;   // on members[0]'s device: a peer's film (ordered sum) / the RCCL result
 	int lastReduceKind = 0;
 	std::string reduceNote;                // why the last frame fell back to the ordered sum ("" when it did not)
+	bool testFailReduce = false;           // tests: the next collective reports a failure (mtsgpu_group_set_tuning "rccl_fail")
 	std::string error;
 };
 
@@ -228,8 +229,7 @@ int ensureStaging(mtsgpu_group *g, size_t count) {
 bool reduceWithRccl(mtsgpu_group *g, size_t count, std::string &why) {
 	const int n = (int) g->members.size();
 	mtsgpu_ctx *root = g->members[0];
-	if (ensureStaging(g, count)) { why = g->error; return false; }
-	const char *inject = getenv("MTSGPU_RCCL_FAIL");          // fault injection for tests: "reduce" fails the collective call
+	const bool inject = g->testFailReduce;                   // fault injection for tests (mtsgpu_group_set_tuning "rccl_fail")
 	ncclResult_t r = g->rccl.groupStart();
 	hipError_t he = hipSuccess;
 	if (r == ncclSuccess) {
@@ -237,7 +237,7 @@ bool reduceWithRccl(mtsgpu_group *g, size_t count, std::string &why) {
 			he = hipSetDevice(g->devices[i]);
 			if (he != hipSuccess) break;
 			mtsgpu_ctx *c = g->members[i];
-			if (inject && !strcmp(inject, "reduce")) { r = ncclInternalError; break; }
+			if (inject) { r = ncclInternalError; break; }
 			r = g->rccl.reduce(c->film, i == 0 ? g->staging : c->film, count, ncclFloat, ncclSum, 0, g->comms[i], c->stream);
 		}
 		const ncclResult_t r2 = g->rccl.groupEnd();           // always: an open group would swallow the next frame's calls
@@ -245,7 +245,7 @@ bool reduceWithRccl(mtsgpu_group *g, size_t count, std::string &why) {
 	}
 	if (he != hipSuccess) { why = std::string("hipSetDevice inside the RCCL group: ") + hipGetErrorString(he); return false; }
 	if (r != ncclSuccess) {
-		why = std::string("ncclReduce: ") + (inject && !strcmp(inject, "reduce") ? "failure injected by MTSGPU_RCCL_FAIL" : g->rccl.errorString(r));
+		why = std::string("ncclReduce: ") + (inject ? "failure injected by the rccl_fail test knob" : g->rccl.errorString(r));
 		return false;
 	}
 	for (int i = 0; i < n; ++i) {
@@ -286,6 +286,9 @@ int mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, vol
 			return gfail(g, MTSGPU_ESTATE, "member %d has a different film size", i);
 	if (ordered_reduce == 2 && !ensureComms(g))
 		return gfail(g, MTSGPU_EHIP, "RCCL is not usable: %s", g->rcclNote.c_str());
+	// the staging buffer first: both sums need it, and failing to allocate it says nothing about RCCL
+	if (n > 1 || ordered_reduce == 2)
+		if (int r = ensureStaging(g, count)) return r;
 	if (ordered_reduce != 1) {
 		if (ensureComms(g)) {
 			std::string why;
@@ -305,7 +308,6 @@ int mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, vol
 	for (int i = 1; i < n; ++i) {
 		const float *src = g->members[i]->film;
 		if (g->devices[i] != g->devices[0]) {
-			if (int r = ensureStaging(g, count)) return r;
 			GHIP(g, hipMemcpyPeerAsync(g->staging, g->devices[0], src, g->devices[i], count * sizeof(float), root->stream));
 			src = g->staging;
 		}
@@ -318,6 +320,15 @@ int mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, vol
 }
 
 const char *mtsgpu_group_reduce_note(const mtsgpu_group *g) { return g ? g->reduceNote.c_str() : ""; }
+
+int mtsgpu_group_set_tuning(mtsgpu_group *g, const char *key, long value) {
+	if (!g || !key) return gfail(g, MTSGPU_EINVAL, "null argument");
+	if (!strcmp(key, "rccl_fail")) { g->testFailReduce = value != 0; return 0; }
+	for (size_t i = 0; i < g->members.size(); ++i)
+		if (int r = mtsgpu_set_tuning(g->members[i], key, value))
+			return gfail(g, r, "member %zu: %s", i, mtsgpu_last_error(g->members[i]));
+	return 0;
+}
 
 int mtsgpu_hbm_triad(int device, size_t bytes, int iters, double *gbs) {
 	if (!gbs || bytes < 4096 || iters <= 0) return gfail(nullptr, MTSGPU_EINVAL, "bad triad arguments");

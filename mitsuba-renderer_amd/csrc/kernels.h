@@ -45,14 +45,13 @@ constexpr int kNextWord = kCntNext * kCounterStride, kShadowWord = kCntShadow * 
 constexpr int kShadeBlock = MG_SHADE_BLOCK;
 // device-side frame statistics (u64): rays of the closest-hit / shadow launches, segment-overflow flag, non-empty
 // traversal launches -- what the host counts itself when it reads the queue sizes back every bounce
+constexpr int kNumTraceCounts = 16;
+enum { kCntPairGlobal = 8, kCntPairLds = 9, kCntNodeGlobal = 10, kCntNodeLds = 11, kCntTail = 12, kCntSpill = 13, kCntHead = 14 };
+// request kinds of a recorded ray (DQueues::rec): index in units of the access size into the node array (16-byte sibling
+// pairs, 8-byte nodes), the leaf records (16 bytes) or the path records (16-byte slots; loads of the ray, store of the hit)
+enum : uint32_t { kReqPair = 1, kReqNode = 2, kReqLeaf = 3, kReqRay = 4, kReqHit = 5, kReqNone = 0xFFFFFFFFu };
 enum { kStatClosest = 0, kStatShadow = 1, kStatOverflow = 2, kStatLaunches = 3, kNumDevStats = 4 };
 
-// Layout of the leaf records: 0 = whole 48-byte records; 1 = heads and tails in two arrays (round-3 experiment, rejected:
-// 205 -> 210-215 ms of traversal per C3 frame, profiles/r03b_exp_trace_layouts.txt -- the tail of a record whose plane test
-// passes is an L1 hit on the line its head brought in; in an array of its own it is an L2 miss that costs the fabric a line)
-#ifndef MG_LEAF_SPLIT
-#define MG_LEAF_SPLIT 0
-#endif
 // Scene in HBM (all pointers are device pointers); see DESIGN.md section 3
 struct DScene {
 	const uint2    *nodes;        // 8 B: (left child index << 2 | axis, split) or (1 << 31 | first record, end record)
@@ -60,9 +59,6 @@ struct DScene {
 	// TriAccel of primitive kd_indices[e] (dword 0 = k << 30 | "not an occluder" << 29 | global
 	// primitive id, dword 10 = shape), so a leaf's primitives are one contiguous run
 	const uint4    *leaf_ta;
-	// MG_LEAF_SPLIT: leaf_ta holds only the 16-byte HEADS (dwords 0..3), entry e at leaf_ta[e]; the other 32 bytes of entry e
-	// are leaf_tail[2 e], leaf_tail[2 e + 1].  Eight heads share a 128-byte line instead of 2.67 whole records.
-	const uint4    *leaf_tail;
 	// per-primitive gather record, one 128-byte line (kTriStride float4): p0.xyz p1.xyz p2.xyz -, shape, flags |
 	// n0.xyz n1.xyz n2.xyz | pad -- one line instead of 3 index + 18 scattered vertex fetches; tri_nrm = tri_pos + 3
 	const float4   *tri_pos;
@@ -93,14 +89,14 @@ struct DScene {
 // What k_trace needs of the scene (a kernel argument: the fewer scalar registers it pins, the fewer get spilled)
 struct DTraceScene {
 	const uint2 *nodes;
-	const uint4 *leaf_ta, *leaf_tail;
+	const uint4 *leaf_ta;
 	const uint32_t *shape_bin;
 	uint32_t has_shapes;
 	float aabb_min[3], aabb_max[3];
 };
 inline DTraceScene trace_scene(const DScene &sc) {
 	DTraceScene t;
-	t.nodes = sc.nodes; t.leaf_ta = sc.leaf_ta; t.leaf_tail = sc.leaf_tail; t.shape_bin = sc.shape_bin; t.has_shapes = sc.has_shapes;
+	t.nodes = sc.nodes; t.leaf_ta = sc.leaf_ta; t.shape_bin = sc.shape_bin; t.has_shapes = sc.has_shapes;
 	for (int i = 0; i < 3; ++i) { t.aabb_min[i] = sc.aabb_min[i]; t.aabb_max[i] = sc.aabb_max[i]; }
 	return t;
 }
@@ -188,7 +184,14 @@ struct DQueues {
 	uint32_t *next;               // paths that continue (input of the next closest-hit launch)
 	uint32_t *shadow;             // paths with a pending shadow ray
 	uint32_t *counters;           // the counter set of this bounce, [i * kCounterStride]: i = b * kBinShards + shard for the bins, then kCnt*
-	unsigned long long *trace_counts;  // n_inner, n_leaf, n_idx, n_tri_tested + lane slots of the three loops and batches (u64 x 8)
+	// counting builds (u64 x kNumTraceCounts): n_inner, n_leaf, n_idx, n_tri_tested, the lane slots of the three loops and of
+	// the batches, then the vector-memory requests the kernel ISSUED: sibling pairs from global memory / from the LDS copy,
+	// single nodes (pops) from global memory / from the LDS copy, 16-byte record tails, stack words spilled to HBM, record heads
+	unsigned long long *trace_counts;
+	// counting builds, optional (mtsgpu_replay_roof): ray number r of the queue writes its requests -- kind << 29 | index,
+	// see kReq* -- to rec[r * rec_cap ..] and their number to rec_len[r]
+	uint32_t *rec, *rec_len;
+	uint32_t rec_cap;
 	unsigned long long *dev_stats;     // kStat* (may be NULL)
 	uint32_t *spill;              // traversal stack overflow: [level][thread]; one buffer per traversal mode (the two run concurrently)
 	uint32_t spill_stride;
@@ -203,8 +206,8 @@ struct DQueues {
 	uint32_t tune_dyn_div;             // 1/x of the rounds of a large launch are claimed dynamically (default 4)
 	uint32_t tune_refill;              // refill threshold for coherent launches too (default: 64 there)
 	uint32_t tune_plain_below;         // launches of fewer rays run the plain loops (0 = 8 rounds of the largest grid)
-	uint32_t tune_step_cap;            // experiment builds (MG_EXP_STEP_CAP): leaf visits after which a ray is cut off
-	uint32_t tune_blocks_per_cu;       // experiment: fewer resident workgroups per CU than the kernel allows (0 = all)
+	uint32_t tune_blocks_per_cu;       // experiment: fewer resident workgroups of kTraceBlock threads per CU than trace_blocks_per_cu(mode)
+	                                   // (3 closest-hit / 4 shadow at 512 threads); 0 or a value >= that = all.  Range 0..kTraceBlocksPerCuMax
 	uint32_t tune_xcd;                 // experiment: XCD x (workgroups with blockIdx % 8 == x) takes the x-th eighth of the queue
 };
 
@@ -298,6 +301,15 @@ void launch_path_lengths(hipStream_t s, const DPaths &ps, uint32_t n_paths, unsi
 void launch_triad(hipStream_t s, float4 *a, const float4 *b, const float4 *c, float scale, size_t n, unsigned blocks = 0);
 // random 16-byte gathers, one element per lane and iteration, over (mask_elems + 1) elements
 void launch_gather_roof(hipStream_t s, const uint4 *data, uint32_t mask_elems, int iters, unsigned blocks, uint32_t *sink);
+// Replay roof of k_trace<closest> (mtsgpu_replay_roof): the recorded requests of n rays, re-issued with no arithmetic.
+// order[] lists the rays by decreasing request count; build_replay lays the requests of 64 consecutive rays of that order
+// out as tr[(batch * cap + k) * 64 + lane] (kReqNone past a ray's end) with batch_len[batch] = the longest of the 64
+void launch_build_replay(hipStream_t s, const uint32_t *rec, const uint32_t *rec_len, const uint32_t *order, uint32_t n, uint32_t cap,
+                         uint32_t *tr, uint32_t *batch_len);
+// the persistent grid of k_trace<closest> (same workgroups per CU, same LDS footprint) walks the batches
+void launch_replay(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *tr, const uint32_t *batch_len,
+                   uint32_t n_batches, uint32_t cap, uint32_t zero, uint32_t *sink);
+void launch_iota_strided(hipStream_t s, uint32_t *p, uint32_t n, uint32_t stride);
 // dst[i] += src[i] over n floats (the ordered film sum of a device group)
 void launch_add_film(hipStream_t s, float *dst, const float *src, size_t n);
 // ImageBlock tiles of one context: rect, first sampler slot of the tile inside its pass, block index

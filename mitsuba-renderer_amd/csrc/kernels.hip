@@ -572,50 +572,11 @@ template <int BIT, typename T> __device__ __forceinline__ void st_stream(T *p, c
 	}
 }
 
-// Experiment builds (tools/build_variant.sh): MG_EXP_PAD_DESC / MG_EXP_PAD_LEAF dependent vector instructions added to
-// every descent step / leaf entry measure what one instruction costs in each loop.  Zero in the product.
-#ifndef MG_EXP_PAD_DESC
-#define MG_EXP_PAD_DESC 0
-#endif
-#ifndef MG_EXP_STEP_CAP
-#define MG_EXP_STEP_CAP 0
-#endif
-#ifndef MG_EXP_COUNT_SPILL
-#define MG_EXP_COUNT_SPILL 0      // counting build: the 8th counter holds stack pushes that went to the HBM spill area
-#endif
-#ifndef MG_EXP_PAD_LEAF
-#define MG_EXP_PAD_LEAF 0
-#endif
-#ifndef MG_EXP_PAD_TA
-#define MG_EXP_PAD_TA 0       // experiment (C3 only): N extra random 16-byte L2-resident gathers per descent step, results unused
-#endif
-#ifndef MG_NODE_SC1
-#define MG_NODE_SC1 0      // experiment: sibling pairs fetched past the L1 (see load_pair)
-#endif
-#ifndef MG_EXP_COUNT_CAND
-#define MG_EXP_COUNT_CAND 0      // counting build: counter 7 = primitives whose plane distance passes, counter 6 = those with u >= 0
-#endif
-template <int N> __device__ __forceinline__ void exp_pad(float &x) {
-	#pragma unroll
-	for (int i = 0; i < N; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(x));
-}
-
 #ifndef MG_STACK_LDS
 #define MG_STACK_LDS 10
 #endif
 #ifndef MG_TOP_PAIRS
 #define MG_TOP_PAIRS (MG_TRACE_BLOCK >= 512 ? 1024 : 128)
-#endif
-// MG_STACK2 (round-3 experiment, rejected): a stack entry is TWO dwords -- (far child index << 2 | split axis, split
-// plane) -- instead of the parent's index: a pop then needs no fetch of the parent node to rebuild the exit point (one of
-// the two gathers per pop, 7 of the 65 vector-memory requests per ray on C3).  But the LDS then holds 6 levels instead of
-// 10 in the same bytes and the deeper pushes spill 8 bytes each to HBM: 205 -> 228 ms (profiles/r03b_exp_trace_layouts.txt).
-#ifndef MG_STACK2
-#define MG_STACK2 0
-#endif
-#if MG_STACK2 && !defined(MG_STACK_LDS_SET)
-#undef MG_STACK_LDS
-#define MG_STACK_LDS 6
 #endif
 constexpr int kStackLDS = MG_STACK_LDS;       // stack levels kept in LDS (deeper ones spill: 1 push in 10^4 at 12 levels on C3)
 // The first 2 * kTopPairs device nodes -- the root and the sibling pairs below it in breadth-first order, see
@@ -625,15 +586,10 @@ constexpr int kStackLDS = MG_STACK_LDS;       // stack levels kept in LDS (deepe
 constexpr uint32_t kTopPairs = MG_TOP_PAIRS;
 constexpr int kSpillLevels = 50 - kStackLDS;      // LDS + spill levels = MTS_KD_MAXDEPTH (48, gkdtree.h:35) + 2
 static_assert(kStackLDS >= 1 && kStackLDS + kSpillLevels >= 48 + 2, "the traversal stack must hold every tree the reference can build");
-struct alignas(MG_STACK2 ? 8 : 4) StackWord {
-	uint32_t v[MG_STACK2 ? 2 : 1];
-	__device__ __forceinline__ uint32_t &operator[](int i) { return v[i]; }
-	__device__ __forceinline__ const uint32_t &operator[](int i) const { return v[i]; }
-};
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 
-size_t trace_spill_levels() { return kSpillLevels * (MG_STACK2 ? 2 : 1); }      // in dwords per thread
+size_t trace_spill_levels() { return kSpillLevels; }      // in dwords per thread
 size_t trace_stack_levels() { return kStackLDS + kSpillLevels; }
 uint32_t trace_top_nodes() { return 2u * kTopPairs; }
 
@@ -647,36 +603,33 @@ uint32_t trace_top_nodes() { return 2u * kTopPairs; }
 // what is computed for a ray.
 // `first` is the queue index of the wave's first batch, `stride` the distance to its next one, `static_n` the
 // statically dealt prefix of the queue.
-// leaf record e: its head (k | flags | primitive, n_u, n_v, n_d) and the two halves of its tail
-__device__ __forceinline__ const uint4 *leaf_head(const DTraceScene &sc, uint32_t e) {
-	return MG_LEAF_SPLIT ? &sc.leaf_ta[e] : &sc.leaf_ta[3 * (size_t) e];
-}
-__device__ __forceinline__ const uint4 *leaf_tail(const DTraceScene &sc, uint32_t e, uint32_t half) {
-	return MG_LEAF_SPLIT ? &sc.leaf_tail[2 * (size_t) e + half] : &sc.leaf_ta[3 * (size_t) e + 1 + half];
-}
+// leaf record e (48 bytes): its head (k | flags | primitive, n_u, n_v, n_d) and the two halves of its tail
+__device__ __forceinline__ const uint4 *leaf_head(const DTraceScene &sc, uint32_t e) { return &sc.leaf_ta[3 * (size_t) e]; }
+__device__ __forceinline__ const uint4 *leaf_tail(const DTraceScene &sc, uint32_t e, uint32_t half) { return &sc.leaf_ta[3 * (size_t) e + 1 + half]; }
 
 template <int MODE, bool COUNT, bool BIN>
 __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &ps, const DQueues &q, const TracePlan &plan,
                                            const uint32_t *queue, uint32_t n, const uint32_t first, const uint32_t stride,
-                                           StackWord (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock], const uint4 *s_top) {
+                                           uint32_t (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock], const uint4 *s_top) {
 	// node fetches: from the LDS copy of the top of the tree when the index lies inside it
+	// COUNT: the requests this lane issued (global / served by the LDS copy) and, when q.rec is set, the list of them
+	uint32_t g_pair = 0, l_pair = 0, g_node = 0, l_node = 0, g_tail = 0, g_spill = 0, g_head = 0;
+	uint32_t rec_n = 0, rec_slot = 0;
+	auto rec_add = [&](uint32_t kind, uint32_t idx) {
+		if (COUNT && q.rec) {
+			if (rec_n < q.rec_cap) q.rec[(size_t) rec_slot * q.rec_cap + rec_n] = (kind << 29) | idx;
+			rec_n++;
+		}
+	};
 	auto load_node = [&](uint32_t i) -> uint2 {
-		if (kTopPairs && i < 2u * kTopPairs) return reinterpret_cast<const uint2 *>(s_top)[i];
+		if (kTopPairs && i < 2u * kTopPairs) { if (COUNT) l_node++; return reinterpret_cast<const uint2 *>(s_top)[i]; }
+		if (COUNT) { g_node++; rec_add(kReqNode, i); }
 		return sc.nodes[i];
 	};
 	auto load_pair = [&](uint32_t left) -> uint4 {
-#if MG_NODE_SC1
-		// the pair through a load that does not allocate in the CU's L1 (sc1: served by the L2 like a miss would be):
-		// the 256 lines of the L1 then belong to the leaf records, whose tails are asked for a microsecond after their heads
-		const uint4 *p = (kTopPairs && left < 2u * kTopPairs) ? &s_top[left >> 1] : &reinterpret_cast<const uint4 *>(sc.nodes)[left >> 1];
-		nt_u4 v;
-		asm volatile("flat_load_dwordx4 %0, %1 sc1" : "=v"(v) : "v"(p) : "memory");
-		uint4 out; __builtin_memcpy(&out, &v, 16);
-		return out;
-#else
-		if (kTopPairs && left < 2u * kTopPairs) return s_top[left >> 1];
+		if (kTopPairs && left < 2u * kTopPairs) { if (COUNT) l_pair++; return s_top[left >> 1]; }
+		if (COUNT) { g_pair++; rec_add(kReqPair, left >> 1); }
 		return reinterpret_cast<const uint4 *>(sc.nodes)[left >> 1];
-#endif
 	};
 	// The hashed mailbox decides which of two primitives with equal t is reported (sahkdtree3.h:130-144, :278-283), so
 	// closest-hit rays keep it.  For any-hit rays it only saves repeated tests of a primitive that spans several leaves --
@@ -689,10 +642,6 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 	const uint32_t shard = blockIdx.x % kBinShards;     // contention on a bin counter is spread over kBinShards words
 
 	uint32_t c_inner = 0, c_leaf = 0, c_idx = 0, c_tri = 0;
-	float pad = 0.0f;                      // experiment builds only
-#if MG_EXP_STEP_CAP
-	uint32_t n_visits = 0;
-#endif
 	uint32_t w_inner = 0, w_leaf = 0, w_outer = 0, w_batch = 0;   // COUNT: lane slots issued per loop (64 per wave iteration)
 #define MG_WSLOT(w) do { if (COUNT && lane == (uint32_t) __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) (w) += 64u; } while (0)
 
@@ -716,9 +665,8 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 	float mint = 0, maxt = 0, tmax0 = 0;
 	float enx = 0, eny = 0, enz = 0, exx = 0, exy = 0, exz = 0, ex_t = 0;   // stack[enPt].p, stack[exPt].p, stack[exPt].t
 	int sp = 0;
-	// MG_STACK2: ex_ref = far child << 2 | axis of the current exit point (ex_node is its upper bits), ex_split its plane
+	// the current exit point: ex_node = its far child, ex_ref = its stack word (parent index * 2 + "far child is the right one")
 	uint32_t ex_node = kNullNode, ex_ref = kSentinel, cur = 0;
-	float ex_split = 0;
 	float best_t = MG_INF, best_u = 0, best_v = 0;
 	uint32_t best_prim = kNoPrim, best_shape = 0;
 	// best_shape: shape index of the accepted hit (dword 10 of its record), read while the record is at hand
@@ -803,9 +751,10 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 			const uint32_t taken = (B - nlive < remaining) ? B - nlive : remaining;
 			const uint32_t my = sup_base + r;
 			sup_base += taken; sup_left -= taken;
-			if (!MG_EXP_COUNT_SPILL && !MG_EXP_COUNT_CAND) MG_WSLOT(w_batch);
+			MG_WSLOT(w_batch);
 			if (take) {
 				id = (MODE == 1) ? my : ld_stream<1>(&queue[my]);       // shadow rays are addressed by their queue position
+				if (COUNT && q.rec) { rec_slot = my; rec_n = 0; if (MODE != 1) { rec_add(kReqRay, id * kPathSlots); rec_add(kReqRay, id * kPathSlots + 1); } }
 				float4 a, b;
 				float rmint, rmaxt;
 				if (MODE == 1) {
@@ -845,12 +794,10 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				if (rmaxt < maxt) maxt = rmaxt;
 				if (!(maxt > mint)) go = false;
 				best_t = MG_INF; best_u = 0; best_v = 0; best_prim = kNoPrim; best_shape = 0;
-#if MG_EXP_STEP_CAP
-				n_visits = 0;
-#endif
 				found = false;
 				done = !go;       // a ray that misses the scene's box is finished at once
 				has = go;
+				if (COUNT && q.rec && !go) { if (MODE != 1) rec_add(kReqHit, id * kPathSlots + 2); q.rec_len[rec_slot] = rec_n; }
 				if (go) {
 					if (kMbox) {
 						#pragma unroll
@@ -883,18 +830,9 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					const uint32_t left = nd.x >> 2;            // device nodes hold the absolute index of the left child
 					// both children in one 16-byte load (sibling pairs are 16-byte aligned in the device order), issued
 					// before the case logic below instead of after it: the step is a chain of dependent fetches
-					uint4 pair = load_pair(left);
+					const uint4 pair = load_pair(left);
 					if (COUNT) c_inner++;
 					MG_WSLOT(w_inner);
-					if (MG_EXP_PAD_DESC) exp_pad<MG_EXP_PAD_DESC>(pad);
-					if (MG_EXP_PAD_TA) {
-						// what one more request per step costs: a line of the node array picked by a hash of the step's node
-						#pragma unroll
-						for (int r = 0; r < MG_EXP_PAD_TA; ++r) {
-							const uint4 x = reinterpret_cast<const uint4 *>(sc.nodes)[((left + 0x9E37u * (uint32_t) (r + 1)) * 2654435761u >> 13) & 0x3FFFFu];
-							pad += __uint_as_float(x.x & 1u);
-						}
-					}
 					const float pen = sel3(enx, eny, enz, axis), pex = sel3(exx, exy, exz, axis);
 					const bool A = pen <= split, B = pex <= split, C = pen == split, D = split < pex;
 					//   A &&  B        : left only            (N1-N3, P5, Z2, Z3)
@@ -910,32 +848,18 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					const uint32_t side = side1 ? 1u : 0u;
 					if (push) {
 						// push the current exit point's reference; (cur, far child) becomes the exit point
-						if (MG_STACK2) {
-							StackWord w; w[0] = ex_ref; w[MG_STACK2 ? 1 : 0] = __float_as_uint(ex_split);
-							if (sp < kStackLDS) s_stack[sp][tid] = w;
-							else { reinterpret_cast<StackWord *>(q.spill)[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = w; if (COUNT && MG_EXP_COUNT_SPILL) w_batch++; }
-						} else {
-							if (sp < kStackLDS) s_stack[sp][tid][0] = ex_ref;
-							else { q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref; if (COUNT && MG_EXP_COUNT_SPILL) w_batch++; }
-						}
+						if (sp < kStackLDS) s_stack[sp][tid] = ex_ref;
+						else { q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref; if (COUNT) g_spill++; }
 						++sp;
 						const uint32_t farRight = A ? 1u : 0u;
 						const float distToSplit = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
-						ex_ref = MG_STACK2 ? (((left + farRight) << 2) | (uint32_t) axis) : ((cur << 1) | farRight);
-						ex_split = split;
+						ex_ref = (cur << 1) | farRight;
 						ex_t = distToSplit;
 						const float px = ox + distToSplit * dx, py = oy + distToSplit * dy, pz = oz + distToSplit * dz;
 						exx = (axis == 0) ? split : px; exy = (axis == 1) ? split : py; exz = (axis == 2) ? split : pz;   // selects, not branches
 						ex_node = left + farRight;
 					}
 					cur = left + side;
-#if MG_NODE_SC1
-					{	// the compiler does not know the asm above is a load: wait for it here, with the registers as operands
-						nt_u4 v; __builtin_memcpy(&v, &pair, 16);
-						asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(v) :: "memory");
-						__builtin_memcpy(&pair, &v, 16);
-					}
-#endif
 					nd = side1 ? make_uint2(pair.z, pair.w) : make_uint2(pair.x, pair.y);
 				}
 				// evaluated for all lanes after the step (a lane that did not step sits on a leaf): the flag then is one
@@ -946,7 +870,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				if (!inner) {
 				// --- leaf: test the primitives (sahkdtree3.h:262-288, skdtree.h:244-336) ---
 				if (COUNT && e_cont == kNoPrim) c_leaf++;      // a resumed leaf was counted already
-				if (!MG_EXP_COUNT_CAND) MG_WSLOT(w_outer);
+				MG_WSLOT(w_outer);
 				bool hitShadow = false, more = false;
 				{
 					uint32_t e = (e_cont != kNoPrim) ? e_cont : (nd.x & 0x7FFFFFFFu);     // resume an interrupted leaf
@@ -956,16 +880,15 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					// are only fetched for primitives whose t lies inside [mint, maxt] (triaccel.h:141-149).
 					uint4 A;
 					more = e != last;
-					if (more) A = ld_stream<2>(leaf_head(sc, e));
+					if (more) { A = ld_stream<2>(leaf_head(sc, e)); if (COUNT) { g_head++; rec_add(kReqLeaf, 3u * e); } }
 					// like the descent, the primitive loop stops when fewer than q.leaf_min lanes have entries left;
 					// those lanes keep their position (e_cont) and go on in the next round
 					do { if (more) {
 						uint4 An = A;
-						if (e + 1 != last) An = ld_stream<2>(leaf_head(sc, e + 1));      // next record's head in flight
+						if (e + 1 != last) { An = ld_stream<2>(leaf_head(sc, e + 1)); if (COUNT) { g_head++; rec_add(kReqLeaf, 3u * (e + 1)); } }      // next record's head in flight
 						const uint32_t prim = A.x & 0x1FFFFFFFu, k = A.x >> 30;
 						if (COUNT) c_idx++;
 						MG_WSLOT(w_leaf);
-						if (MG_EXP_PAD_LEAF) exp_pad<MG_EXP_PAD_LEAF>(pad);
 						// Flat form of the mailbox test + TriAccel::rayIntersect: the plane distance t is computed for
 						// every entry (selects, no branches) and masked afterwards; only the barycentric part, which
 						// needs the rest of the record, is conditional.
@@ -977,6 +900,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						if (sc.has_shapes && k == 3u && A.y != 0u && fresh && occl) {     // has_shapes is uniform: one scalar branch
 							// a non-triangle shape (skdtree.h:287-296 / :328-332); A.y = shape type, B = centre + radius
 							const uint4 B = *leaf_tail(sc, e, 0);
+							if (COUNT) { g_tail++; rec_add(kReqLeaf, 3u * e + 1u); }
 							const V3 ctr(__uint_as_float(B.x), __uint_as_float(B.y), __uint_as_float(B.z));
 							const float rad = __uint_as_float(B.w);
 							if (MODE != 0) {
@@ -997,9 +921,9 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
 						const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
 						if (ok && !(t < mint || t > maxt)) {
-							if (COUNT && MG_EXP_COUNT_CAND) w_batch++;
 							const uint4 B = ld_stream<2>(leaf_tail(sc, e, 0));
 							const uint4 C = ld_stream<2>(leaf_tail(sc, e, 1));         // c_nu, c_nv, shape index, -
+							if (COUNT) { g_tail += 2u; rec_add(kReqLeaf, 3u * e + 1u); rec_add(kReqLeaf, 3u * e + 2u); }
 							const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
 							const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
 							const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
@@ -1007,7 +931,6 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 							const float hv = o_v + t * d_v - a_v;
 							const float u = hv * b_nu + hu * b_nv;
 							const float v = hu * c_nu + hv * c_nv;
-							if (COUNT && MG_EXP_COUNT_CAND && u >= 0) w_outer++;
 							if (u >= 0 && v >= 0 && u + v <= 1.0f) {
 								if (MODE != 0) hitShadow = true;
 								maxt = t;      // a later hit with equal t replaces this one (t > maxt rejects)
@@ -1034,51 +957,38 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						finished = true;
 					} else {
 						--sp;
-						nd = load_node(cur);         // in flight together with the parent's node below (MG_STACK2: the only fetch)
-						StackWord sw;
-						if (MG_STACK2) sw = (sp < kStackLDS) ? s_stack[sp][tid]
-						                                     : reinterpret_cast<const StackWord *>(q.spill)[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
-						else sw[0] = (sp < kStackLDS) ? s_stack[sp][tid][0] : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
-						const uint32_t ref = sw[0];
+						nd = load_node(cur);         // in flight together with the parent's node below
+						const uint32_t ref = (sp < kStackLDS) ? s_stack[sp][tid] : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
 						if (ref == kSentinel) {
 							ex_t = tmax0; exx = ox + tmax0 * dx; exy = oy + tmax0 * dy; exz = oz + tmax0 * dz;
 							ex_node = kNullNode; ex_ref = kSentinel;
 						} else {
-							int axis; float split;
-							if (MG_STACK2) {
-								axis = (int) (ref & 3u); split = __uint_as_float(sw[MG_STACK2 ? 1 : 0]);
-								ex_node = ref >> 2;
-							} else {
-								const uint32_t parent = ref >> 1;
-								const uint2 pn = load_node(parent);
-								axis = (int) (pn.x & 3u);
-								split = __uint_as_float(pn.y);
-								ex_node = (pn.x >> 2) + (ref & 1u);
-							}
+							// the exit point is a function of (parent node, ray): rebuilt with the reference's formulas (sahkdtree3.h:233,248-249)
+							const uint2 pn = load_node(ref >> 1);
+							const int axis = (int) (pn.x & 3u);
+							const float split = __uint_as_float(pn.y);
+							ex_node = (pn.x >> 2) + (ref & 1u);
 							ex_t = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
 							const float px = ox + ex_t * dx, py = oy + ex_t * dy, pz = oz + ex_t * dz;
 							exx = (axis == 0) ? split : px; exy = (axis == 1) ? split : py; exz = (axis == 2) ? split : pz;
-							ex_ref = ref; ex_split = split;
+							ex_ref = ref;
 						}
 					}
 				}
-#if MG_EXP_STEP_CAP
-				// experiment (WRONG RESULTS, timing only): rays are cut off after q.tune_step_cap leaf visits, to see how
-				// much of a short launch is the tail of its few longest rays
-				if (q.tune_step_cap && ++n_visits > q.tune_step_cap) finished = true;
-#endif
-				if (finished) { has = false; done = true; found = (MODE == 0) ? (best_prim != kNoPrim) : hitShadow; }
+				if (finished) {
+					has = false; done = true; found = (MODE == 0) ? (best_prim != kNoPrim) : hitShadow;
+					if (COUNT && q.rec) { if (MODE != 1) rec_add(kReqHit, id * kPathSlots + 2); q.rec_len[rec_slot] = rec_n; }
+				}
 				}
 			}
 		}
 	}
 
-	if ((MG_EXP_PAD_DESC || MG_EXP_PAD_LEAF || MG_EXP_PAD_TA) && pad == -1.0f) q.trace_counts[7] = 1ull;      // keeps the padding alive
 	if (COUNT) {
 		// wave reduction, then one atomic per wave and counter
-		unsigned long long v[8] = { c_inner, c_leaf, c_idx, c_tri, w_inner, w_leaf, w_outer, w_batch };
+		unsigned long long v[15] = { c_inner, c_leaf, c_idx, c_tri, w_inner, w_leaf, w_outer, w_batch, g_pair, l_pair, g_node, l_node, g_tail, g_spill, g_head };
 		#pragma unroll
-		for (int k = 0; k < 8; ++k) {
+		for (int k = 0; k < 15; ++k) {
 			unsigned long long x = v[k];
 			for (int off = 32; off > 0; off >>= 1)
 				x += __shfl_down(x, off);
@@ -1091,7 +1001,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 template <int MODE, bool COUNT, bool BIN>
 __global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(MODE)) void k_trace(DTraceScene sc, DPaths ps, DQueues q,
                                                           const uint32_t *queue, uint32_t n_host, const uint32_t *n_dev) {
-	__shared__ StackWord s_stack[kStackLDS][kTraceBlock];
+	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
 	__shared__ uint32_t s_mbox[(MODE == 0 || COUNT) ? 8 : 1][kTraceBlock];
 	__shared__ uint4 s_top[kTopPairs ? kTopPairs : 1];
 	// the number of rays: known to the host, or left in device memory by the kernel that filled the queue
@@ -2443,6 +2353,78 @@ __global__ __launch_bounds__(256, 7) void k_gather_roof(const uint4 *data, uint3
 	if (acc == 0xDEADBEEFu) sink[0] = acc;
 }
 
+// ---- replay roof of the closest-hit traversal (mtsgpu_replay_roof) ----
+// The requests a counting launch recorded for n rays (DQueues::rec), laid out for coalesced reading: 64 rays of similar
+// length per batch, entries 4 g .. 4 g + 3 of lane l in the uint4 tr[(batch * cap / 4 + g) * 64 + l] (cap % 4 == 0).
+__global__ void k_build_replay(const uint32_t *rec, const uint32_t *rec_len, const uint32_t *order, uint32_t n, uint32_t cap,
+                               uint32_t *tr, uint32_t *batch_len) {
+	const uint32_t b = blockIdx.x, l = threadIdx.x;       // one wave per batch
+	const uint32_t r = b * 64u + l;
+	const uint32_t ray = r < n ? order[r] : 0u;
+	const uint32_t len = r < n ? min(rec_len[ray], cap) : 0u;
+	uint32_t longest = len;
+	for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t) __shfl_xor((int) longest, off));
+	longest = (longest + 3u) & ~3u;
+	if (l == 0) batch_len[b] = longest;
+	uint4 *out = reinterpret_cast<uint4 *>(tr) + (size_t) b * (cap / 4u) * 64u + l;
+	for (uint32_t k = 0; k < longest; k += 4u) {
+		uint32_t e[4];
+		#pragma unroll
+		for (uint32_t j = 0; j < 4u; ++j) e[j] = (k + j < len) ? rec[(size_t) ray * cap + k + j] : kReqNone;
+		out[(size_t) (k / 4u) * 64u] = make_uint4(e[0], e[1], e[2], e[3]);
+	}
+}
+// The same requests as a pure throughput test: every lane walks the list of its ray and issues one 16-byte load per entry
+// from the line the traversal asked for (a single 8-byte node is read as the aligned pair that holds it, the store of the
+// hit as a load of its slot), eight in flight per lane, NO dependence between them and no arithmetic -- what the memory
+// system (TA, L1, L2, fabric, HBM) needs for this set of lines in this order from this grid.  The traversal itself cannot
+// go faster than this however it is written; it goes slower by what its chains of dependent fetches (a descent step needs
+// the node before it) and its arithmetic cost on top.  Same grid, same workgroup size and the LDS footprint of
+// k_trace<closest>, so the same number of waves is resident.  One coalesced 16-byte read of the list per four requests
+// comes on top.
+__global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(0)) void k_replay(const uint2 *nodes, const uint4 *leaf_ta, float4 *paths,
+                                                                                const uint32_t *tr, const uint32_t *batch_len,
+                                                                                uint32_t n_batches, uint32_t cap, uint32_t zero, uint32_t *sink) {
+	__shared__ uint32_t s_pad[kStackLDS + 8][kTraceBlock];
+	__shared__ uint4 s_top[kTopPairs ? kTopPairs : 1];
+	for (uint32_t t = threadIdx.x; t < kTopPairs; t += kTraceBlock) s_top[t] = reinterpret_cast<const uint4 *>(nodes)[t];
+	s_pad[threadIdx.x & 7u][threadIdx.x] = zero;
+	__syncthreads();
+	const uint32_t lane = lane_id();
+	const uint32_t wave = blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6), n_waves = gridDim.x * (kTraceBlock / 64u);
+	uint32_t acc = s_top[threadIdx.x % (kTopPairs ? kTopPairs : 1)].x & s_pad[threadIdx.x & 7u][threadIdx.x];
+	const char *bNodes = reinterpret_cast<const char *>(nodes), *bLeaf = reinterpret_cast<const char *>(leaf_ta), *bPaths = reinterpret_cast<const char *>(paths);
+	// one entry -> the address of its 16-byte chunk (selects, no branches: the wave issues ONE load instruction per entry)
+	auto address = [&](uint32_t e) -> const uint4 * {
+		const uint32_t kind = e >> 29, idx = e & 0x1FFFFFFFu;
+		const char *base = (kind == kReqLeaf) ? bLeaf : ((kind == kReqRay || kind == kReqHit) ? bPaths : bNodes);
+		const size_t off = (kind == kReqNode) ? (size_t) (idx >> 1) * 16u : (size_t) idx * 16u;
+		return reinterpret_cast<const uint4 *>(base + off);
+	};
+	for (uint32_t b = wave; b < n_batches; b += n_waves) {
+		const uint32_t groups = batch_len[b] / 4u;
+		const uint4 *t = reinterpret_cast<const uint4 *>(tr) + (size_t) b * (cap / 4u) * 64u + lane;
+		const uint4 none = make_uint4(kReqNone, kReqNone, kReqNone, kReqNone);
+		for (uint32_t g = 0; g < groups; g += 2u) {
+			const uint4 c0 = t[(size_t) g * 64u], c1 = (g + 1u < groups) ? t[(size_t) (g + 1u) * 64u] : none;
+			const uint32_t e[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+			uint4 p[8];
+			#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				p[j] = make_uint4(0u, 0u, 0u, 0u);
+				if (e[j] != kReqNone) p[j] = *address(e[j]);
+			}
+			#pragma unroll
+			for (int j = 0; j < 8; ++j) acc ^= p[j].x ^ p[j].y ^ p[j].z ^ p[j].w;
+		}
+	}
+	if (acc == 0xDEADBEEFu) sink[0] = acc;
+}
+__global__ void k_iota_strided(uint32_t *p, uint32_t n, uint32_t stride) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) p[i] = i * stride;
+}
+
 __global__ void k_add_film(float *dst, const float *src, size_t n) {
 	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) dst[i] += src[i];
@@ -2648,6 +2630,18 @@ void launch_triad(hipStream_t s, float4 *a, const float4 *b, const float4 *c, fl
 }
 void launch_gather_roof(hipStream_t s, const uint4 *data, uint32_t mask_elems, int iters, unsigned blocks, uint32_t *sink) {
 	hipLaunchKernelGGL(k_gather_roof, dim3(blocks), dim3(256), 0, s, data, mask_elems, iters, sink);
+}
+void launch_build_replay(hipStream_t s, const uint32_t *rec, const uint32_t *rec_len, const uint32_t *order, uint32_t n, uint32_t cap,
+                         uint32_t *tr, uint32_t *batch_len) {
+	if (n) hipLaunchKernelGGL(k_build_replay, dim3(blocks_for(n, 64)), dim3(64), 0, s, rec, rec_len, order, n, cap, tr, batch_len);
+}
+void launch_replay(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *tr, const uint32_t *batch_len,
+                   uint32_t n_batches, uint32_t cap, uint32_t zero, uint32_t *sink) {
+	const unsigned blocks = std::min<unsigned>(blocks_for(n_batches, kTraceBlock / 64), q.n_cus * trace_blocks_per_cu(0));
+	if (blocks) hipLaunchKernelGGL(k_replay, dim3(blocks), dim3(kTraceBlock), 0, s, sc.nodes, sc.leaf_ta, ps.base, tr, batch_len, n_batches, cap, zero, sink);
+}
+void launch_iota_strided(hipStream_t s, uint32_t *p, uint32_t n, uint32_t stride) {
+	if (n) hipLaunchKernelGGL(k_iota_strided, dim3(blocks_for(n, 256)), dim3(256), 0, s, p, n, stride);
 }
 void launch_add_film(hipStream_t s, float *dst, const float *src, size_t n) {
 	if (n) hipLaunchKernelGGL(k_add_film, dim3(blocks_for(n, 256)), dim3(256), 0, s, dst, src, n);

@@ -145,11 +145,11 @@ def test_group_keeps_the_frame_when_the_collective_fails(gpu_lib, mts, monkeypat
     ref = g.film()
     assert g.render(ordered_reduce=2) and g.reduce_kind() == "rccl ncclReduce" and g.reduce_note() == ""
     assert np.array_equal(g.film().view(np.uint32), ref.view(np.uint32))
-    monkeypatch.setenv("MTSGPU_RCCL_FAIL", "reduce")
+    g.set_tuning(rccl_fail=1)
     assert g.render(ordered_reduce=2)
     assert g.reduce_kind() == "ordered peer-copy sum" and "injected" in g.reduce_note()
     assert np.array_equal(g.film().view(np.uint32), ref.view(np.uint32))
-    monkeypatch.delenv("MTSGPU_RCCL_FAIL")
+    g.set_tuning(rccl_fail=0)
     assert g.render() and np.array_equal(g.film().view(np.uint32), ref.view(np.uint32))
 
 

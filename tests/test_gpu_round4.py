@@ -1,0 +1,102 @@
+"""GPU tests, fourth set: the measurement hooks added in round 4 (issued-request counters, replay roof) and the
+pipeline changes of the round, each against the oracle or against an invariant of the traversal."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_issued_request_counters_add_up(gpu_lib, mts):
+    """Counting build: every inner-node step fetches exactly one sibling pair (from global memory or from the LDS copy of
+    the top of the tree), every pop fetches the popped node and -- unless the stack entry is the sentinel -- its parent
+    (n_inner itself is checked against the oracle's count in test_traversal_counters_match_oracle)"""
+    sd = mts.scenes.cornell_c3(grid=48, sphere_subdiv=3)
+    scene = mts.Scene(sd)
+    cam = mts.PerspectiveCamera.for_description(sd, 96, 96)
+    it = mts.MIPathTracer(maxDepth=8)
+    it.preprocess(scene, cam, sampler="ldsampler", sampleCount=4, seed=3)
+    it.set_options(count_traversal=True)
+    assert it.render()
+    st = it.stats()
+    rays = st["rays_closest"] + st["rays_shadow"]
+    assert rays > 0 and st["n_inner"] > 0
+    assert st["req_pair_global"] + st["req_pair_lds"] == st["n_inner"]
+    pops_max = st["n_leaf"]                      # a ray pops at most once per leaf it visits
+    nodes = st["req_node_global"] + st["req_node_lds"]
+    assert 0 < nodes <= 2 * pops_max + rays      # + the root, fetched once per ray
+    assert st["req_tail"] <= 2 * st["n_idx"] and st["req_head"] >= st["n_idx"]
+
+
+def test_replay_roof_replays_what_the_kernel_asked_for(gpu_lib, mts):
+    """mtsgpu_replay_roof: the recorded lists hold exactly the requests the counters saw (pairs + nodes from global
+    memory, heads, tails, two loads of the ray and the store of the hit per ray), and both timings are positive"""
+    sd = mts.scenes.cornell_c3(grid=48, sphere_subdiv=3)
+    scene = mts.Scene(sd)
+    cam = mts.PerspectiveCamera.for_description(sd, 128, 128)
+    it = mts.MIPathTracer(maxDepth=8)
+    it.preprocess(scene, cam, sampler="ldsampler", sampleCount=8, seed=3)
+    assert it.render()
+    film = it.film().copy()
+    n = 128 * 128 * 8 // 2
+    rr = it.replay_roof(n, stride=2, reps=1)
+    assert rr["rays"] == n and rr["truncated_rays"] == 0
+    assert rr["requests"] == rr["pair_global"] + rr["node_global"] + rr["heads"] + rr["tails"] + 3 * n
+    assert rr["product_ms"] > 0 and rr["replay_ms"] > 0
+    # the measurement leaves the renderer usable: the next frame is the same film
+    it.clear_film()
+    assert it.render()
+    assert np.array_equal(it.film().view(np.uint32), film.view(np.uint32))
+    with pytest.raises(mts.MtsGpuError):
+        it.replay_roof(1 << 30, stride=4)
+
+
+def _bench(args, timeout=900):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_line_carries_the_group_form_and_the_replay_roof(gpu_lib, mts, tmp_path):
+    """bench.py on one GPU, small frame: the JSON line has the one-process device-group timing (`group`, rendered by a
+    fresh child process after the ranks have finished) with a film equal to the unsharded render bit for bit, the
+    replay roof with frac <= 1, and a CPU baseline that says what an ungated host would extrapolate to"""
+    out = str(tmp_path / "group.npy")
+    rec = _bench(["--res", "256", "--grid", "48", "--spp", "16", "--steps", "1", "--warmup", "1", "--host-kd",
+                  "--no-1spp", "--no-cpu-baseline", "--dump-group-film", out])
+    g = rec["group"]
+    assert "error" not in g, g
+    assert g["group_ms_per_step"] > 0 and g["value"] > 0 and g["devices"] == [0]
+    rq = rec["roofline_requests"]
+    assert rq["note"] is None and 0 < rq["frac"] <= 1.0, rq
+    assert rq["issued_requests_per_ray"] > 0 and rq["lds_served_requests_per_ray"] > 0
+    assert rec["roofline"]["frac"] > 0 and rec["roofline_shade"]["frac"] > 0
+    sd = mts.scenes.cornell_c3(grid=48, sphere_subdiv=5)
+    it = mts.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth)
+    it.preprocess(mts.Scene(sd), mts.PerspectiveCamera.for_description(sd, 256, 256), sampler="ldsampler", sampleCount=16, seed=0x5EED)
+    assert it.render()
+    assert np.array_equal(np.load(out).view(np.uint32), it.film().view(np.uint32))
+
+
+def test_bench_over_two_gpus_uses_the_nccl_backend(gpu_lib, mts, tmp_path):
+    """`bench.py --gpus 2` as the driver starts it (no --devices): the ranks form an RCCL process group, rank 0's reduced film
+    equals the unsharded render, and the group child renders the same film through mtsgpu_group_render over both GPUs.
+    Needs two GPUs: skipped on the one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: the nccl branch of bench.py needs two")
+    out, gout = str(tmp_path / "film.npy"), str(tmp_path / "group.npy")
+    rec = _bench(["--gpus", "2", "--res", "128", "--grid", "24", "--spp", "4", "--steps", "1", "--warmup", "0", "--host-kd",
+                  "--no-1spp", "--no-cpu-baseline", "--dump-film", out, "--dump-group-film", gout])
+    assert rec["n_gpus"] == 2 and len(rec["rank_ms"]) == 2
+    assert "error" not in rec["group"], rec["group"]
+    sd = mts.scenes.cornell_c3(grid=24, sphere_subdiv=5)
+    it = mts.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth)
+    it.preprocess(mts.Scene(sd), mts.PerspectiveCamera.for_description(sd, 128, 128), sampler="ldsampler", sampleCount=8, seed=0x5EED)
+    assert it.render()
+    assert np.array_equal(np.load(out).view(np.uint32), it.film().view(np.uint32))
+    assert np.array_equal(np.load(gout).view(np.uint32), it.film().view(np.uint32))

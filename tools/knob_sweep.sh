@@ -3,7 +3,7 @@
 #   bash tools/knob_sweep.sh gpurun_out/knobs.txt
 # (refill_min set through mtsgpu_set_tuning also applies to the coherent first bounce, whose rule is 64: compare its rows with each other)
 out=$1; : > $out
-run() { echo "== $*" >> $out; python tools/bounce_times.py 64 1024 "$@" 2>/dev/null | tail -1 >> $out; }
+run() { echo "== $*" >> $out; python3 tools/bounce_times.py 64 1024 "$@" 2>>${out%.txt}.err | tail -1 >> $out; }
 run
 for v in 4 6 8 12 16; do run desc_min=$v; done
 for v in 4 6 8 12 16; do run leaf_min=$v; done

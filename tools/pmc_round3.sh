@@ -1,5 +1,5 @@
 #!/bin/bash
-# Where the waves of k_trace wait: four PMC passes over one untimed 64-spp C3 frame (run on the GPU box from the repo root):
+# Where the waves of k_trace wait: five PMC passes over one untimed 64-spp C3 frame (run on the GPU box from the repo root):
 #   bash tools/pmc_round3.sh <tag>
 tag=${1:-r03}
 root=$(pwd)
