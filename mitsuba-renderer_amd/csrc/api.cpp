@@ -800,10 +800,11 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 		// TriAccel records re-laid out in leaf order (one contiguous run per leaf, no index
 		// indirection on the device); non-occluders are shapes without a BSDF
 		// (Shape::isOccluder, shape.h:324)
-		std::vector<uint32_t> ta(12 * (size_t) sc->n_indices + 12, 0u);
+		const size_t LS = 4 * (size_t) kLeafStride;                 // dwords per record slot
+		std::vector<uint32_t> ta(LS * ((size_t) sc->n_indices + 1), 0u);
 		for (uint32_t e = 0; e < sc->n_indices; ++e) {
 			const uint32_t prim = sc->kd_indices[e];
-			uint32_t *dst = &ta[12 * (size_t) e];
+			uint32_t *dst = &ta[LS * (size_t) e];
 			std::memcpy(dst, sc->triaccel + 12 * (size_t) prim, 48);
 			// dword 0 = k<<30 | non-occluder<<29 | primitive id (the head of the record decides everything
 			// up to the plane distance); dword 10 stays the shape index

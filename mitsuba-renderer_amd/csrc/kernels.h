@@ -27,6 +27,10 @@ constexpr unsigned trace_blocks_per_cu(int mode) { return (mode == 0 ? 24u : 32u
 constexpr unsigned trace_waves_per_simd(int mode) { return trace_blocks_per_cu(mode) * (kTraceBlock / 64) / 4; }
 constexpr unsigned kTraceBlocksPerCuMax = 2048 / kTraceBlock;      // largest persistent traversal grid: 32 waves per CU
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
+// uint4 per leaf record: the 48-byte TriAccel records lie back to back (2.67 per 128-byte line; three of eight straddle two
+// lines).  Measured and rejected (round 4, profiles/r04d_exp_trace_leaf_record_fetch.txt): one record per 64 bytes, so that
+// a tail always lies on the line of its head: 194.2 -> 196.7 ms of traversal per C3 frame (fewer heads per line).
+constexpr uint32_t kLeafStride = 3;
 constexpr int kTriStride = 8;         // float4 per primitive record: one 128-byte line holds positions AND normals
 constexpr int kLumStride = 32;        // MTSGPU_LUM_NPARAMS
 constexpr int kCounterStride = 32;    // one 128-byte line per queue counter (atomics on one line serialise)

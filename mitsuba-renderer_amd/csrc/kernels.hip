@@ -603,9 +603,9 @@ uint32_t trace_top_nodes() { return 2u * kTopPairs; }
 // what is computed for a ray.
 // `first` is the queue index of the wave's first batch, `stride` the distance to its next one, `static_n` the
 // statically dealt prefix of the queue.
-// leaf record e (48 bytes): its head (k | flags | primitive, n_u, n_v, n_d) and the two halves of its tail
-__device__ __forceinline__ const uint4 *leaf_head(const DTraceScene &sc, uint32_t e) { return &sc.leaf_ta[3 * (size_t) e]; }
-__device__ __forceinline__ const uint4 *leaf_tail(const DTraceScene &sc, uint32_t e, uint32_t half) { return &sc.leaf_ta[3 * (size_t) e + 1 + half]; }
+// leaf record e (48 bytes at a stride of kLeafStride x 16): its head (k | flags | primitive, n_u, n_v, n_d) and the two halves of its tail
+__device__ __forceinline__ const uint4 *leaf_head(const DTraceScene &sc, uint32_t e) { return &sc.leaf_ta[kLeafStride * (size_t) e]; }
+__device__ __forceinline__ const uint4 *leaf_tail(const DTraceScene &sc, uint32_t e, uint32_t half) { return &sc.leaf_ta[kLeafStride * (size_t) e + 1 + half]; }
 
 template <int MODE, bool COUNT, bool BIN>
 __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &ps, const DQueues &q, const TracePlan &plan,
@@ -880,12 +880,12 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					// are only fetched for primitives whose t lies inside [mint, maxt] (triaccel.h:141-149).
 					uint4 A;
 					more = e != last;
-					if (more) { A = ld_stream<2>(leaf_head(sc, e)); if (COUNT) { g_head++; rec_add(kReqLeaf, 3u * e); } }
+					if (more) { A = ld_stream<2>(leaf_head(sc, e)); if (COUNT) { g_head++; rec_add(kReqLeaf, kLeafStride * e); } }
 					// like the descent, the primitive loop stops when fewer than q.leaf_min lanes have entries left;
 					// those lanes keep their position (e_cont) and go on in the next round
 					do { if (more) {
 						uint4 An = A;
-						if (e + 1 != last) { An = ld_stream<2>(leaf_head(sc, e + 1)); if (COUNT) { g_head++; rec_add(kReqLeaf, 3u * (e + 1)); } }      // next record's head in flight
+						if (e + 1 != last) { An = ld_stream<2>(leaf_head(sc, e + 1)); if (COUNT) { g_head++; rec_add(kReqLeaf, kLeafStride * (e + 1)); } }      // next record's head in flight
 						const uint32_t prim = A.x & 0x1FFFFFFFu, k = A.x >> 30;
 						if (COUNT) c_idx++;
 						MG_WSLOT(w_leaf);
@@ -900,7 +900,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						if (sc.has_shapes && k == 3u && A.y != 0u && fresh && occl) {     // has_shapes is uniform: one scalar branch
 							// a non-triangle shape (skdtree.h:287-296 / :328-332); A.y = shape type, B = centre + radius
 							const uint4 B = *leaf_tail(sc, e, 0);
-							if (COUNT) { g_tail++; rec_add(kReqLeaf, 3u * e + 1u); }
+							if (COUNT) { g_tail++; rec_add(kReqLeaf, kLeafStride * e + 1u); }
 							const V3 ctr(__uint_as_float(B.x), __uint_as_float(B.y), __uint_as_float(B.z));
 							const float rad = __uint_as_float(B.w);
 							if (MODE != 0) {
@@ -923,7 +923,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						if (ok && !(t < mint || t > maxt)) {
 							const uint4 B = ld_stream<2>(leaf_tail(sc, e, 0));
 							const uint4 C = ld_stream<2>(leaf_tail(sc, e, 1));         // c_nu, c_nv, shape index, -
-							if (COUNT) { g_tail += 2u; rec_add(kReqLeaf, 3u * e + 1u); rec_add(kReqLeaf, 3u * e + 2u); }
+							if (COUNT) { g_tail += 2u; rec_add(kReqLeaf, kLeafStride * e + 1u); rec_add(kReqLeaf, kLeafStride * e + 2u); }
 							const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
 							const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
 							const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
