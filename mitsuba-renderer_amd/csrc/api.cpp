@@ -47,6 +47,13 @@ template <typename T> int upload(mtsgpu_ctx *ctx, const T **dst, const T *src, s
 
 void freeAll(std::vector<void *> &v) { for (void *p : v) (void) hipFree(p); v.clear(); }
 
+// The events that order the two streams of a context against each other (shading of bounce b -> its shadow rays on the
+// second stream -> shading of bounce b + 1): both streams run on one device, so a device-scope release is all they need
+#ifndef MG_EV_DEVICE
+#define MG_EV_DEVICE 0
+#endif
+constexpr unsigned kOrderEventFlags = hipEventDisableTiming | (MG_EV_DEVICE ? hipEventReleaseToDevice : 0u);
+
 uint32_t roundToPow2(uint32_t v) { uint32_t r = 1; while (r < v) r <<= 1; return r; }
 
 uint32_t squareAtLeast(uint32_t v) { uint32_t i = 1; while ((uint64_t) i * i < v) ++i; return i * i; }
@@ -69,6 +76,7 @@ void applyTuning(mtsgpu_ctx *c) {
 	c->q.tune_xcd = (uint32_t) get("xcd_segments", 0);
 	c->q.tune_blocks_per_cu = (uint32_t) get("blocks_per_cu", 0);
 	c->q.tune_plain_below = (uint32_t) get("plain_below", 0);
+	c->q.tune_dyn_min_rounds = (uint32_t) get("dyn_min_rounds", 0);
 	if (c->q.tune_xcd) c->q.force_static = 1u;
 }
 
@@ -375,10 +383,14 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 			if (shadowPending) HIPCHK(c, hipStreamWaitEvent(s1, c->evShadow[(b - 1) & 1], 0));
 			rc = timed(c->shadeEvents, c->shadeEvUsed, s1, 0); if (rc) return rc;
 			launch_prep(s1, set, prev, c->viewsDev, c->q.bin_seg_cap, c->devStats);
-			BinView none{};
-			for (int bin = 0; bin < kNumBins; ++bin)
-				if (c->binMask & (1u << bin))
-					launch_shade(s1, bin, c->dsc, c->paths, cfg, c->q, none, c->viewsDev, upper);
+			if (cfg.dr_mode == 0 && tuningOr(c, "shade_fused", 1) != 0) {
+				launch_shade_all(s1, c->dsc, c->paths, cfg, c->q, c->viewsDev, c->binMask & ((1u << kNumBins) - 1u), upper);
+			} else {
+				BinView none{};
+				for (int bin = 0; bin < kNumBins; ++bin)
+					if (c->binMask & (1u << bin))
+						launch_shade(s1, bin, c->dsc, c->paths, cfg, c->q, none, c->viewsDev, upper);
+			}
 			rc = timed(c->shadeEvents, c->shadeEvUsed, s1, 1); if (rc) return rc;
 			HIPCHK(c, hipGetLastError());
 			HIPCHK(c, hipEventRecord(c->evShade[b & 1], s1));
@@ -585,8 +597,8 @@ int mtsgpu_create(int device, mtsgpu_ctx **out) {
 	{
 		bool ok = hipStreamCreate(&c->stream2) == hipSuccess && hipEventCreateWithFlags(&c->evCount, hipEventDisableTiming) == hipSuccess;
 		for (int i = 0; i < 2 && ok; ++i)
-			ok = hipEventCreateWithFlags(&c->evShade[i], hipEventDisableTiming) == hipSuccess
-			  && hipEventCreateWithFlags(&c->evShadow[i], hipEventDisableTiming) == hipSuccess;
+			ok = hipEventCreateWithFlags(&c->evShade[i], kOrderEventFlags) == hipSuccess
+			  && hipEventCreateWithFlags(&c->evShadow[i], kOrderEventFlags) == hipSuccess;
 		if (!ok) { mtsgpu_destroy(c); return fail(nullptr, MTSGPU_EHIP, "stream / event creation failed"); }
 	}
 	if (hipHostMalloc((void **) &c->hostCounters, (kNumCounters * kCounterStride + 4) * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
@@ -1015,7 +1027,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "xcd_segments", 0, 1 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "xcd_segments", 0, 1 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);

@@ -210,6 +210,7 @@ struct DQueues {
 	uint32_t tune_dyn_div;             // 1/x of the rounds of a large launch are claimed dynamically (default 4)
 	uint32_t tune_refill;              // refill threshold for coherent launches too (default: 64 there)
 	uint32_t tune_plain_below;         // launches of fewer rays run the plain loops (0 = 8 rounds of the largest grid)
+	uint32_t tune_dyn_min_rounds;      // launches of at least this many rounds claim their last rounds dynamically (0 = 8)
 	uint32_t tune_blocks_per_cu;       // experiment: fewer resident workgroups of kTraceBlock threads per CU than trace_blocks_per_cu(mode)
 	                                   // (3 closest-hit / 4 shadow at 512 threads); 0 or a value >= that = all.  Range 0..kTraceBlocksPerCuMax
 	uint32_t tune_xcd;                 // experiment: XCD x (workgroups with blockIdx % 8 == x) takes the x-th eighth of the queue
@@ -244,7 +245,7 @@ __host__ __device__ inline TracePlan trace_plan(uint32_t n, int mode, const DQue
 	const uint32_t rounds = perRound ? n / perRound : 0u;
 	const uint32_t dynDiv = q.tune_dyn_div ? q.tune_dyn_div : 4u;
 	// small launches stay fully static: their waves finish together and would hit the counter in one burst
-	const bool dynamic = rounds >= 8u && !q.force_static;
+	const bool dynamic = rounds >= (q.tune_dyn_min_rounds ? q.tune_dyn_min_rounds : 8u) && !q.force_static;
 	uint32_t dynRounds = dynamic ? rounds / dynDiv : 0u;
 	if (dynamic && dynRounds < 1u) dynRounds = 1u;
 	p.static_n = dynamic ? (rounds - dynRounds) * perRound : n;
@@ -292,6 +293,10 @@ struct BinView { uint32_t prefix[kBinShards + 1]; };
 void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
                   const DQueues &q, const BinView &view, const BinView *views_dev = nullptr, uint32_t n_bound = 0,
                   const uint32_t *bin_ids = nullptr);
+// device-driven bounces, path integrator / one-sample direct integrator: all bins of bin_mask in one launch; views_dev as
+// above, n_bound bounds the sum of the bin sizes
+void launch_shade_all(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg, const DQueues &q,
+                      const BinView *views_dev, uint32_t bin_mask, uint32_t n_bound);
 // device-driven bounces: per-bin views from the shard counters of the closest-hit launch that just ran (`cur`), and
 // the counter set of the next bounce zeroed
 void launch_prep(hipStream_t s, const uint32_t *cur, uint32_t *next_set, BinView *views_dev, uint32_t bin_seg_cap,

@@ -34,6 +34,33 @@ __device__ __forceinline__ float sel3(float x, float y, float z, int axis) {
 	return axis == 0 ? x : (axis == 1 ? y : z);
 }
 
+// MG_NT: non-temporal hints on data that is touched once per launch -- bit 0: path records, ray
+// and id queues in k_trace; bit 1: leaf records in k_trace; bit 2: records and queues in k_shade -- so that they do not
+// push the tree out of the L1 / L2
+#ifndef MG_NT
+#define MG_NT 4      // measured (64-spp C3 frame): bit 0 +12 ms, bit 1 +120 ms (the leaf records live in the L2), bit 2 -3.6 ms
+#endif
+typedef uint32_t nt_u4 __attribute__((ext_vector_type(4)));
+template <int BIT, typename T> __device__ __forceinline__ T ld_stream(const T *p) {
+	if (MG_NT & BIT) {
+		static_assert(sizeof(T) == 16 || sizeof(T) == 4, "16-byte or 4-byte objects");
+		T out;
+		if (sizeof(T) == 16) { const nt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4 *>(p)); __builtin_memcpy(&out, &v, 16); }
+		else { const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p)); __builtin_memcpy(&out, &v, 4); }
+		return out;
+	}
+	return *p;
+}
+template <int BIT, typename T> __device__ __forceinline__ void st_stream(T *p, const T &v) {
+	if (MG_NT & BIT) {
+		static_assert(sizeof(T) == 16 || sizeof(T) == 4, "16-byte or 4-byte objects");
+		if (sizeof(T) == 16) { nt_u4 x; __builtin_memcpy(&x, &v, 16); __builtin_nontemporal_store(x, reinterpret_cast<nt_u4 *>(p)); }
+		else { uint32_t x; __builtin_memcpy(&x, &v, 4); __builtin_nontemporal_store(x, reinterpret_cast<uint32_t *>(p)); }
+	} else {
+		*p = v;
+	}
+}
+
 __global__ void k_fill_u32(uint32_t *p, uint32_t v, size_t n) {
 	size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) p[i] = v;
@@ -394,11 +421,17 @@ size_t random_state_bytes() { return 3 * sizeof(MtRandom); }
 // ===========================================================================
 // K1: camera samples (integrator.cpp:154-166, perspective.cpp:77-112)
 // ===========================================================================
-__global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pixel_list, uint32_t n_slots,
-                           const uint32_t *explicit_samples, uint32_t n_paths, uint32_t *queue) {
+// The records leave through LDS: a lane that stores its own record slot by slot touches 64 different lines with every store
+// instruction (eight instructions, 512 line requests per wave, every line written in eight pieces); instead eight lanes
+// write one record together -- whole 128-byte lines, eight records per instruction -- as k_shade does.
+constexpr int kGenBlock = 256;
+__global__ __launch_bounds__(kGenBlock) void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pixel_list, uint32_t n_slots,
+                                                        const uint32_t *explicit_samples, uint32_t n_paths, uint32_t *queue) {
+	__shared__ float4 s_rec[kGenBlock / 64][64 * (kPathSlots + 1)];      // rows of 9 float4: conflict-free both ways
 	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-	if (id >= n_paths)
-		return;
+	float4 *rows = s_rec[threadIdx.x >> 6];
+	float4 *row = rows + lane_id() * (kPathSlots + 1);
+	if (id < n_paths) {
 	uint32_t slot, j, pixel;
 	if (explicit_samples) {
 		// film pixel (x, y) of the crop window -> key in the full film's raster grid
@@ -462,14 +495,27 @@ __global__ void k_generate(DScene sc, DPaths ps, DConfig cfg, const uint32_t *pi
 	     w[4] * ld.x + w[5] * ld.y + w[6] * ld.z,
 	     w[8] * ld.x + w[9] * ld.y + w[10] * ld.z);
 
-	ps.ray_o(id) = make_float4(o.x, o.y, o.z, mint);
-	ps.ray_d(id) = make_float4(d.x, d.y, d.z, maxt);
-	ps.thr(id) = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(1));   // depth = 1 (integrator.h:186-191)
+	row[0] = make_float4(o.x, o.y, o.z, mint);                         // ray_o
+	row[1] = make_float4(d.x, d.y, d.z, maxt);                         // ray_d
+	row[2] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(kNoPrim));  // hit: none yet
+	row[3] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(1));        // thr; depth = 1 (integrator.h:186-191)
 	const uint32_t flags = F_EMITTED | F_FIRST | (smp.d1 << F_D1_SHIFT) | (smp.d2 << F_D2_SHIFT);
-	ps.Li(id) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(flags));
-	ps.misc(id) = make_uint4((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32), j, pixel);
-	ps.spos(id) = make_float4(sx, sy, 0.0f, 0.0f);
+	row[4] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(flags));    // Li
+	row[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                      // bsdf
+	reinterpret_cast<uint4 &>(row[6]) = make_uint4((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32), j, pixel);   // misc
+	row[7] = make_float4(sx, sy, 0.0f, 0.0f);                          // spos
 	queue[id] = id;
+	}
+	// program order suffices inside a wave (every row is written and read by the same wave)
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+	const uint32_t sub = lane_id() & 7u, grp = lane_id() >> 3;
+	const uint32_t wave_first = id - lane_id();                         // path id of lane 0 of this wave
+	#pragma unroll
+	for (int r = 0; r < 8; ++r) {
+		const uint32_t src = grp + 8u * r;
+		if (wave_first + src < n_paths)
+			st_stream<4>(&ps.base[(size_t) (wave_first + src) * kPathSlots + sub], rows[src * (kPathSlots + 1) + sub]);
+	}
 }
 
 
@@ -545,33 +591,6 @@ __device__ __forceinline__ bool sphere_occludes(V3 center, float radius, V3 ro, 
 // free), levels beyond kStackLDS spill to HBM.  The 8-entry hashed mailbox
 // (sahkdtree3.h:130-144) is kept (LDS) because it decides equal-t ties.
 // ===========================================================================
-// MG_NT: non-temporal hints on data that is touched once per launch -- bit 0: path records, ray
-// and id queues in k_trace; bit 1: leaf records in k_trace; bit 2: records and queues in k_shade -- so that they do not
-// push the tree out of the L1 / L2
-#ifndef MG_NT
-#define MG_NT 4      // measured (64-spp C3 frame): bit 0 +12 ms, bit 1 +120 ms (the leaf records live in the L2), bit 2 -3.6 ms
-#endif
-typedef uint32_t nt_u4 __attribute__((ext_vector_type(4)));
-template <int BIT, typename T> __device__ __forceinline__ T ld_stream(const T *p) {
-	if (MG_NT & BIT) {
-		static_assert(sizeof(T) == 16 || sizeof(T) == 4, "16-byte or 4-byte objects");
-		T out;
-		if (sizeof(T) == 16) { const nt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4 *>(p)); __builtin_memcpy(&out, &v, 16); }
-		else { const uint32_t v = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p)); __builtin_memcpy(&out, &v, 4); }
-		return out;
-	}
-	return *p;
-}
-template <int BIT, typename T> __device__ __forceinline__ void st_stream(T *p, const T &v) {
-	if (MG_NT & BIT) {
-		static_assert(sizeof(T) == 16 || sizeof(T) == 4, "16-byte or 4-byte objects");
-		if (sizeof(T) == 16) { nt_u4 x; __builtin_memcpy(&x, &v, 16); __builtin_nontemporal_store(x, reinterpret_cast<nt_u4 *>(p)); }
-		else { uint32_t x; __builtin_memcpy(&x, &v, 4); __builtin_nontemporal_store(x, reinterpret_cast<uint32_t *>(p)); }
-	} else {
-		*p = v;
-	}
-}
-
 #ifndef MG_STACK_LDS
 #define MG_STACK_LDS 10
 #endif
@@ -2149,7 +2168,6 @@ __device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, c
                                   // triangle) was measured at 66 ms instead of 44 ms per frame: partial lines cost a read-modify-write
 #endif
 
-template <int BT, bool ROUNDS>
 #ifndef MG_SHADE_WAVES
 #define MG_SHADE_WAVES 0
 #endif
@@ -2158,16 +2176,23 @@ template <int BT, bool ROUNDS>
 #else
 #define MG_SHADE_BOUNDS __launch_bounds__(kShadeBlock)
 #endif
-__global__ MG_SHADE_BOUNDS void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, BinView view_host,
-                                                       const BinView *views_dev, const uint32_t *bin_ids) {
-	__shared__ uint32_t s_cnt[2][kShadeBlock / 64];
-	__shared__ uint32_t s_base[2];
-	__shared__ float4 s_rows[kShadeBlock / 64][64 * kRowStride];
-	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-	// the bin's segment sizes: a kernel argument when the host read the counters back, otherwise what k_prep wrote
-	const uint32_t *prefix = views_dev ? views_dev[BT].prefix : view_host.prefix;
+// the workgroup's LDS: per-wave counts and the two queue offsets of the stream compaction, the staged path records
+struct ShadeShared {
+	uint32_t cnt[2][kShadeBlock / 64];
+	uint32_t base[2];
+	float4 rows[kShadeBlock / 64][64 * kRowStride];
+};
+// One workgroup of k_shade: the paths block * kShadeBlock .. of the material queue whose segment sizes are `prefix`
+// (prefix[kBinShards] entries in kBinShards segments of bin_ids)
+template <int BT, bool ROUNDS>
+__device__ __forceinline__ void shade_block(const DScene &sc, const DPaths &ps, const DConfig &cfg, const DQueues &q, const uint32_t *prefix,
+                                            const uint32_t *bin_ids, const uint32_t block, ShadeShared &sh) {
+	uint32_t (&s_cnt)[2][kShadeBlock / 64] = sh.cnt;
+	uint32_t (&s_base)[2] = sh.base;
+	float4 (&s_rows)[kShadeBlock / 64][64 * kRowStride] = sh.rows;
+	const uint32_t gtid = block * kShadeBlock + threadIdx.x;
 	const uint32_t total = prefix[kBinShards];
-	if (blockIdx.x * blockDim.x >= total)
+	if (block * kShadeBlock >= total)
 		return;                            // (uniform) a grid sized for the worst case
 	const bool active = gtid < total;
 	uint32_t id = 0u;
@@ -2270,6 +2295,43 @@ __global__ MG_SHADE_BOUNDS void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueu
 	}
 }
 
+template <int BT, bool ROUNDS>
+__global__ MG_SHADE_BOUNDS void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueues q, BinView view_host,
+                                                       const BinView *views_dev, const uint32_t *bin_ids) {
+	__shared__ ShadeShared sh;
+	// the bin's segment sizes: a kernel argument when the host read the counters back, otherwise what k_prep wrote
+	shade_block<BT, ROUNDS>(sc, ps, cfg, q, views_dev ? views_dev[BT].prefix : view_host.prefix, bin_ids, blockIdx.x, sh);
+}
+
+// All material queues of a bounce in ONE launch (device-driven bounces): the workgroups are dealt to the bins in bin order,
+// ceil(size / kShadeBlock) each, the sizes read from what k_prep left in device memory.  A frame of few paths is a chain of
+// short launches, and a launch of k_shade -- 1024 threads and 148 KB of LDS per workgroup -- costs 10-20 us even when
+// nearly all of its worst-case grid exits at once: one launch per bounce instead of one per BSDF type present.
+__global__ MG_SHADE_BOUNDS void k_shade_all(DScene sc, DPaths ps, DConfig cfg, DQueues q, const BinView *views_dev, uint32_t bin_mask) {
+	__shared__ ShadeShared sh;
+	uint32_t block = blockIdx.x;
+	int bin = -1;
+	for (int b = 0; b < kNumBins; ++b) {
+		if (!((bin_mask >> b) & 1u)) continue;
+		const uint32_t nb = (views_dev[b].prefix[kBinShards] + kShadeBlock - 1u) / kShadeBlock;
+		if (block < nb) { bin = b; break; }
+		block -= nb;
+	}
+	if (bin < 0) return;
+	const uint32_t *prefix = views_dev[bin].prefix, *ids = q.bin(bin);
+	switch (bin) {
+		case 0: shade_block<0, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 1: shade_block<1, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 2: shade_block<2, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 3: shade_block<3, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 4: shade_block<4, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 5: shade_block<5, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 6: shade_block<6, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 7: shade_block<7, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		default: shade_block<kNumBsdfTypes, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+	}
+}
+
 // ===========================================================================
 // K7: ImageBlock::putSample with the tabulated box filter
 // (include/mitsuba/render/imageblock.h:80-138, src/librender/rfilter.cpp:40-69).
@@ -2283,6 +2345,11 @@ __global__ void k_accumulate(DPaths ps, DConfig cfg, uint32_t n_slots, uint32_t 
 	const int W = cfg.width, H = cfg.height;
 	// TabulatedFilter of the box filter: size 0.5, factor = 15 / 0.5, table = 1 inside, 0 on the border row
 	const float fsize = 0.5f, factor = 15 / fsize;
+	// The film pixel being added to stays in registers while consecutive samples fall on it (with the box filter: all
+	// samples of the lane's pixel): one load and one store per pixel instead of one of each per sample.  The sums are formed
+	// in the same order as before, sample by sample, so the film keeps its bits.
+	float *cur = nullptr;
+	float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
 	for (uint32_t j = 0; j < spp; ++j) {
 		const size_t id = (size_t) slot * spp + j;
 		const float4 L = ps.Li(id);
@@ -2307,12 +2374,17 @@ __global__ void k_accumulate(DPaths ps, DConfig cfg, uint32_t n_slots, uint32_t 
 				if (weight == 0.0f)
 					continue;
 				float *px = film + 5 * ((size_t) (y - cfg.crop_y) * W + (x - cfg.crop_x));
-				px[0] += L.x * weight; px[1] += L.y * weight; px[2] += L.z * weight;
-				px[3] += alpha * weight;
-				px[4] += weight;
+				if (px != cur) {
+					if (cur) { cur[0] = a0; cur[1] = a1; cur[2] = a2; cur[3] = a3; cur[4] = a4; }
+					cur = px; a0 = px[0]; a1 = px[1]; a2 = px[2]; a3 = px[3]; a4 = px[4];
+				}
+				a0 += L.x * weight; a1 += L.y * weight; a2 += L.z * weight;
+				a3 += alpha * weight;
+				a4 += weight;
 			}
 		}
 	}
+	if (cur) { cur[0] = a0; cur[1] = a1; cur[2] = a2; cur[3] = a3; cur[4] = a4; }
 	}
 	if (path_len) {
 		for (int off = 32; off > 0; off >>= 1)
@@ -2553,7 +2625,7 @@ void launch_bsdf_eval(hipStream_t s, uint32_t type, const float *params, int op,
 void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg,
                      const uint32_t *pixel_list, uint32_t n_slots, const uint32_t *explicit_samples,
                      uint32_t n_paths, uint32_t *queue) {
-	if (n_paths) hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths, 256)), dim3(256), 0, s, sc, ps, cfg,
+	if (n_paths) hipLaunchKernelGGL(k_generate, dim3(blocks_for(n_paths, kGenBlock)), dim3(kGenBlock), 0, s, sc, ps, cfg,
 	                                pixel_list, n_slots, explicit_samples, n_paths, queue);
 }
 
@@ -2616,6 +2688,14 @@ void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, co
 		default: MG_SHADE(kNumBsdfTypes); break;
 	}
 	#undef MG_SHADE
+}
+
+void launch_shade_all(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg, const DQueues &q,
+                      const BinView *views_dev, uint32_t bin_mask, uint32_t n_bound) {
+	if (!n_bound || !bin_mask) return;
+	// every bin rounds its size up to whole workgroups
+	const unsigned blocks = blocks_for(n_bound, kShadeBlock) + (unsigned) __builtin_popcount(bin_mask);
+	hipLaunchKernelGGL(k_shade_all, dim3(blocks), dim3(kShadeBlock), 0, s, sc, ps, cfg, q, views_dev, bin_mask);
 }
 
 void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,

@@ -10,6 +10,7 @@ if knobs.pop("debug", "0") == "1":
     os.environ["MTSGPU_DEBUG"] = "1"
 count = knobs.pop("count", "0") == "1"
 sampler = knobs.pop("sampler", "ldsampler")
+timing = knobs.pop("timing", "1") == "1"      # timing=0: no HIP events around the launches (the frame as bench.py times it)
 sd = pkg.scenes.cornell_c3()
 scene = pkg.Scene(sd, None, gpu_binning=True, gpu_exact=True)
 cam = pkg.PerspectiveCamera.for_description(sd, res, res)
@@ -17,7 +18,7 @@ it = pkg.MIPathTracer(maxDepth=sd.max_depth)
 it.preprocess(scene, cam, sampler=sampler, sampleCount=spp, seed=0x5EED)
 if knobs:
     it.set_tuning(**{k: int(v) for k, v in knobs.items()})
-it.set_options(time_kernels=True, count_traversal=count)
+it.set_options(time_kernels=timing, count_traversal=count)
 assert it.render()                      # warm-up (allocations)
 sys.stderr.write("---- frame ----\n")
 if "quiet" not in os.environ.get("MTSGPU_BT", ""):
