@@ -73,9 +73,11 @@ void applyTuning(mtsgpu_ctx *c) {
 	c->q.tune_refill = c->tuning.count("refill_min") ? 1u : 0u;
 	c->q.tune_batch = (uint32_t) get("batch", 0);
 	c->q.tune_dyn_div = (uint32_t) get("dyn_div", 0);
+	c->q.tune_xcd = (uint32_t) get("xcd_segments", 0);
 	c->q.tune_blocks_per_cu = (uint32_t) get("blocks_per_cu", 0);
 	c->q.tune_plain_below = (uint32_t) get("plain_below", 0);
 	c->q.tune_dyn_min_rounds = (uint32_t) get("dyn_min_rounds", 0);
+	if (c->q.tune_xcd) c->q.force_static = 1u;
 }
 
 // size of the full film the crop window lies in (film.cpp:33-41); without a crop window the film itself
@@ -106,9 +108,7 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	auto &o = c->pathAllocs;
 	int rc = 0;
 	rc |= devAlloc(c, &c->paths.base, cap * kPathSlots, o);
-	// the queues k_shade fills are blocked (DQueues::next): every bin of a bounce rounds up to whole blocks
-	const size_t qcap = cap + (size_t) (kNumBins + 1) * kShadeBlock;
-	rc |= devAlloc(c, &c->paths.shq_o, qcap, o); rc |= devAlloc(c, &c->paths.shq_d, qcap, o); rc |= devAlloc(c, &c->paths.shq_nee, qcap, o);
+	rc |= devAlloc(c, &c->paths.shq_o, cap, o); rc |= devAlloc(c, &c->paths.shq_d, cap, o); rc |= devAlloc(c, &c->paths.shq_nee, cap, o);
 	// With static dealing every shard (workgroups with blockIdx % kBinShards == s) sees at most 1/kBinShards of the
 	// 256-ray batches plus one per workgroup, and all of them may land in one bin.  The dynamically claimed tail of a
 	// large launch (a quarter of the queue) goes to whichever waves are free, so a shard can take more than its share:
@@ -120,11 +120,8 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	c->q.bin_stride = (uint32_t) (segCap * kBinShards);
 	if (segCap * kBinShards > 0xFFFFFFFFull) return fail(c, MTSGPU_EINVAL, "pass too large");
 	c->q.bin_seg_cap = (uint32_t) segCap;
-	rc |= devAlloc(c, &c->queueA, qcap, o); rc |= devAlloc(c, &c->queueB, qcap, o);
-	rc |= devAlloc(c, &c->q.shadow, qcap, o);
-	// block counts of the two queues k_shade fills (twice the blocks a pass can have: see runDirectRounds)
-	const size_t cntCap = 2 * (cap / kShadeBlock + kNumBins + 2);
-	rc |= devAlloc(c, &c->q.next_cnt, cntCap, o); rc |= devAlloc(c, &c->q.shadow_cnt, cntCap, o);
+	rc |= devAlloc(c, &c->queueA, cap, o); rc |= devAlloc(c, &c->queueB, cap, o);
+	rc |= devAlloc(c, &c->q.shadow, cap, o);
 	rc |= devAlloc(c, &c->counterSets, (size_t) kCounterSets * kNumCounters * kCounterStride, o);
 	rc |= devAlloc(c, &c->viewsDev, kNumBins, o);
 	rc |= devAlloc(c, &c->devStats, kNumDevStats, o);
@@ -138,7 +135,6 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	applyTuning(c);
 	HIPCHK(c, hipMemset(c->q.trace_counts, 0, kNumTraceCounts * sizeof(unsigned long long)));
 	c->q.rec = c->q.rec_len = nullptr; c->q.rec_cap = 0;
-	c->q.in_cnt = nullptr; c->q.n_real = nullptr; c->q.totals_by_atomics = 0u;
 	c->pathCap = cap;
 	return 0;
 }
@@ -228,20 +224,10 @@ int readCounters(mtsgpu_ctx *c) {
 }
 
 
-// The out blocks of one bounce's shading (DQueues::next): bin after bin, whole workgroups each.  Returns their number; times
-// kShadeBlock it is the blocked length of the two queues the shading fills.
-uint32_t assignOutBlocks(BinView *views, int nBins) {
-	uint32_t blocks = 0;
-	for (int b = 0; b < nBins; ++b) { views[b].first_block = blocks; blocks += (views[b].prefix[kBinShards] + kShadeBlock - 1u) / kShadeBlock; }
-	return blocks;
-}
-
 // Closest-hit launch over queue[0..n) with the material sort, then the per-bin segment sizes (one blocking read of the
 // counters).  A shard segment that overflowed (possible only with dynamically claimed batches, see ensurePaths) makes
 // the launch run again with static dealing: tracing a ray twice writes the same hit twice.
-// in_cnt: the queue is blocked (DQueues::next) and n its blocked length.  views[] come back with their out blocks assigned
-// (bin after bin); *out_blocks = their number
-int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent, BinView *views, const uint32_t *in_cnt, uint32_t *out_blocks) {
+int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent, BinView *views) {
 	hipStream_t s = c->stream;
 	const size_t counterBytes = kNumCounters * kCounterStride * sizeof(uint32_t);
 	for (int attempt = 0; attempt < 2; ++attempt) {
@@ -249,7 +235,7 @@ int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent,
 		c->q.force_static = attempt ? 1u : 0u;
 		hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
 		if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
-		launch_trace(s, 0, c->countTraversal && attempt == 0, true, c->dsc, c->paths, c->q, queue, n, coherent, nullptr, in_cnt);
+		launch_trace(s, 0, c->countTraversal && attempt == 0, true, c->dsc, c->paths, c->q, queue, n, coherent);
 		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
 		c->q.force_static = 0;
 		HIPCHK(c, hipGetLastError());
@@ -267,7 +253,7 @@ int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent,
 			views[b].prefix[kBinShards] = acc;
 		}
 		if (attempt == 0 && c->tuning.count("test_retry") && c->tuning["test_retry"]) overflow = true;   // exercises the retry (tests)
-		if (!overflow) { *out_blocks = assignOutBlocks(views, kNumBins); return 0; }
+		if (!overflow) return 0;
 		c->stats.bin_overflow_retries++;
 	}
 	return fail(c, MTSGPU_EHIP, "internal: bin segment overflow with static dealing");
@@ -282,10 +268,10 @@ int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatil
 	hipStream_t s = c->stream;
 	DConfig cfg = cfg0;
 	const size_t counterBytes = kNumCounters * kCounterStride * sizeof(uint32_t);
-	auto timedTrace = [&](int mode, bool bin, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *in_cnt) -> int {
+	auto timedTrace = [&](int mode, bool bin, const uint32_t *queue, uint32_t n, bool coherent) -> int {
 		hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
 		if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
-		launch_trace(s, mode, c->countTraversal, bin, c->dsc, c->paths, c->q, queue, n, coherent, nullptr, in_cnt);
+		launch_trace(s, mode, c->countTraversal, bin, c->dsc, c->paths, c->q, queue, n, coherent);
 		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
 		HIPCHK(c, hipGetLastError());
 		c->stats.trace_launches++;
@@ -294,27 +280,16 @@ int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatil
 	HIPCHK(c, hipMemsetAsync(c->q.counters, 0, counterBytes, s));
 	c->q.next = c->queueB;
 	BinView views[kNumBins];
-	uint32_t outBlocks = 0;
-	int rc = traceAndBin(c, c->queueA, nPaths, true, views, nullptr, &outBlocks); if (rc) return rc;
+	int rc = traceAndBin(c, c->queueA, nPaths, true, views); if (rc) return rc;
 	c->stats.rays_closest += nPaths;
-	const uint32_t blockedLen = outBlocks * (uint32_t) kShadeBlock;      // of the queues every round fills
 	auto shadeRound = [&](int mode, int index, bool withTerminal) -> int {
 		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
 		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, counterBytes, s));     // the bins stay as they are; views[] holds their sizes
-		// a round that leaves a bin out must still leave zero counts in that bin's out blocks
-		if (!withTerminal) {
-			const uint32_t nb = (views[kNumBins - 1].prefix[kBinShards] + kShadeBlock - 1u) / kShadeBlock;
-			if (nb) {
-				HIPCHK(c, hipMemsetAsync(c->q.next_cnt + views[kNumBins - 1].first_block, 0, nb * sizeof(uint32_t), s));
-				HIPCHK(c, hipMemsetAsync(c->q.shadow_cnt + views[kNumBins - 1].first_block, 0, nb * sizeof(uint32_t), s));
-			}
-		}
 		if (sev) HIPCHK(c, hipEventRecord(sev[0], s));
 		cfg.dr_mode = mode; cfg.dr_index = index;
 		for (int b = 0; b < (withTerminal ? kNumBins : kNumBsdfTypes); ++b)
 			launch_shade(s, b, c->dsc, c->paths, cfg, c->q, views[b]);
 		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
-		launch_sum_blocks(s, c->q.next_cnt, c->q.shadow_cnt, outBlocks, c->q.counters);
 		HIPCHK(c, hipGetLastError());
 		return readCounters(c);
 	};
@@ -324,7 +299,7 @@ int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatil
 		rc = shadeRound(1, j, j == 0); if (rc) return rc;
 		const uint32_t nShadow = c->hostCounters[kShadowWord];
 		if (nShadow) {
-			rc = timedTrace(1, false, c->q.shadow, blockedLen, true, c->q.shadow_cnt); if (rc) return rc;
+			rc = timedTrace(1, false, c->q.shadow, nShadow, true); if (rc) return rc;
 			c->stats.rays_shadow += nShadow;
 		}
 	}
@@ -334,18 +309,16 @@ int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatil
 		rc = shadeRound(2, j, false); if (rc) return rc;
 		const uint32_t nNext = c->hostCounters[kNextWord];
 		if (!nNext) continue;
-		rc = timedTrace(0, false, c->queueB, blockedLen, false, c->q.next_cnt); if (rc) return rc;
+		rc = timedTrace(0, false, c->queueB, nNext, false); if (rc) return rc;
 		c->stats.rays_closest += nNext;
-		// what the sampled rays hit: the material-independent tail of the shading kernel over the (blocked) ray queue; it
-		// produces no rays, and its own out blocks lie behind the ones in use
+		// what the sampled rays hit: the material-independent tail of the shading kernel over the ray queue
 		BinView tail;
 		tail.prefix[0] = 0;
-		for (int k = 1; k <= kBinShards; ++k) tail.prefix[k] = blockedLen;
-		tail.first_block = outBlocks;
+		for (int k = 1; k <= kBinShards; ++k) tail.prefix[k] = nNext;
 		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
 		if (sev) HIPCHK(c, hipEventRecord(sev[0], s));
 		cfg.dr_mode = 3; cfg.dr_index = j;
-		launch_shade(s, kNumBsdfTypes, c->dsc, c->paths, cfg, c->q, tail, nullptr, 0, c->queueB, c->q.next_cnt);
+		launch_shade(s, kNumBsdfTypes, c->dsc, c->paths, cfg, c->q, tail, nullptr, 0, c->queueB);
 		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
 		HIPCHK(c, hipGetLastError());
 	}
@@ -370,14 +343,12 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 	const size_t setBytes = (size_t) kNumCounters * kCounterStride * sizeof(uint32_t);
 	HIPCHK(c, hipMemsetAsync(c->counterSets, 0, kCounterSets * setBytes, s1));
 	c->q.dev_stats = c->devStats;        // cleared by the caller (one frame may take several passes)
-	c->q.totals_by_atomics = 1u;
 	c->devStatsUsed = true;
 	// MIPathTracer traces at most maxDepth rays per path (path.cpp:87), the one-sample direct integrator two
 	const int limit = cfg.integrator == 1 ? 2 : (cfg.max_depth > 0 ? cfg.max_depth : 0x7FFFFFFF);
 	const int chunk = (int) tuningOr(c, "chunk", 8);
 	uint32_t *cur = c->queueA, *nxt = c->queueB;
 	uint32_t upper = nPaths;                   // what the host knows about the queue sizes
-	const uint32_t blockSlack = (uint32_t) (kNumBins + 1) * kShadeBlock;      // a blocked queue: every bin rounds up to whole blocks
 	bool shadowPending = false;
 	int b = 0;
 	// Every way out of this function -- cancel, a failed HIP call, the normal end -- leaves the context as the host-driven
@@ -388,7 +359,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 		mtsgpu_ctx *c; hipStream_t s2; const bool &pending;
 		~Restore() {
 			if (pending) (void) hipStreamSynchronize(s2);
-			c->q.dev_stats = nullptr; c->q.counters = c->counterSets; c->q.spill = c->spillClosest; c->q.totals_by_atomics = 0u;
+			c->q.dev_stats = nullptr; c->q.counters = c->counterSets; c->q.spill = c->spillClosest;
 		}
 	} restore{ c, s2, shadowPending };
 	auto timed = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used, hipStream_t s, int which) -> int {
@@ -405,11 +376,8 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 			uint32_t *set = counterSet(c, b), *prev = counterSet(c, b - 1);
 			c->q.counters = set; c->q.next = nxt; c->q.spill = c->spillClosest;
 			int rc = timed(c->traceEvents, c->traceEvUsed, s1, 0); if (rc) return rc;
-			// bounce 0 traces the dense queue k_generate wrote; later ones the blocked queue of the previous shading, whose
-			// blocked length k_prep left in that bounce's counter set (its real length stands next to it)
-			if (b == 0) launch_trace(s1, 0, c->countTraversal, true, c->dsc, c->paths, c->q, cur, upper, true);
-			else launch_trace(s1, 0, c->countTraversal, true, c->dsc, c->paths, c->q, cur, upper + blockSlack, false,
-			                  prev + (size_t) kVirtWord, c->q.next_cnt, prev + (size_t) kNextWord);
+			launch_trace(s1, 0, c->countTraversal, true, c->dsc, c->paths, c->q, cur, upper, b == 0,
+			             b == 0 ? nullptr : prev + (size_t) kNextWord);
 			rc = timed(c->traceEvents, c->traceEvUsed, s1, 1); if (rc) return rc;
 			// the shading of this bounce adds to Li after the shadow rays of the previous one have (path.cpp:124 before :80)
 			if (shadowPending) HIPCHK(c, hipStreamWaitEvent(s1, c->evShadow[(b - 1) & 1], 0));
@@ -430,8 +398,8 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 			HIPCHK(c, hipStreamWaitEvent(s2, c->evShade[b & 1], 0));
 			DQueues q2 = c->q; q2.spill = c->spillShadow;
 			rc = timed(c->traceEvents, c->traceEvUsed, s2, 0); if (rc) return rc;
-			launch_trace(s2, 1, c->countTraversal, false, c->dsc, c->paths, q2, c->q.shadow, upper + blockSlack, b == 0,
-			             set + (size_t) kVirtWord, c->q.shadow_cnt, set + (size_t) kShadowWord);
+			launch_trace(s2, 1, c->countTraversal, false, c->dsc, c->paths, q2, c->q.shadow, upper, b == 0,
+			             set + (size_t) kShadowWord);
 			rc = timed(c->traceEvents, c->traceEvUsed, s2, 1); if (rc) return rc;
 			HIPCHK(c, hipGetLastError());
 			HIPCHK(c, hipEventRecord(c->evShadow[b & 1], s2));
@@ -477,8 +445,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 	// measured on the 64-spp frame: two chip-filling persistent grids at once run 15 % slower than one after the other
 	// (they evict each other's working set), so the overlap is reserved for the short launches of device-driven frames
 	const bool overlap = tuningOr(c, "overlap", 0) != 0;
-	uint32_t nQ = nPaths;                     // rays in the queue
-	uint32_t lenQ = nPaths;                   // its length: the same for the dense queue of camera rays, the blocked length afterwards
+	uint32_t nQ = nPaths;
 	uint32_t *cur = c->queueA, *nxt = c->queueB;
 	bool first = true;       // camera rays and their shadow rays are coherent: plain 64-ray batches win there
 	hipStream_t s = c->stream, s2 = overlap ? c->stream2 : c->stream;
@@ -494,8 +461,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		c->q.next = nxt;
 		// closest hit + material sort
 		BinView views[kNumBins];
-		uint32_t outBlocks = 0;
-		int rc = traceAndBin(c, cur, lenQ, first, views, first ? nullptr : c->q.next_cnt, &outBlocks); if (rc) return rc;
+		int rc = traceAndBin(c, cur, nQ, first, views); if (rc) return rc;
 		c->stats.rays_closest += nQ;
 		// the shading of this bounce adds to Li after the shadow rays of the previous one have (path.cpp:124 before :80)
 		if (shadowPending && overlap) HIPCHK(c, hipStreamWaitEvent(s, c->evShadow[(b - 1) & 1], 0));
@@ -505,18 +471,16 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		for (int bin = 0; bin < kNumBins; ++bin)
 			launch_shade(s, bin, c->dsc, c->paths, cfg, c->q, views[bin]);
 		if (sev) HIPCHK(c, hipEventRecord(sev[1], s));
-		launch_sum_blocks(s, c->q.next_cnt, c->q.shadow_cnt, outBlocks, c->q.counters);
 		HIPCHK(c, hipGetLastError());
 		rc = readCounters(c); if (rc) return rc;
 		const uint32_t nNext = c->hostCounters[kNextWord], nShadow = c->hostCounters[kShadowWord];
-		const uint32_t blockedLen = outBlocks * (uint32_t) kShadeBlock;      // of the two queues the shading just filled
 		// shadow rays of this bounce (they add the direct-light term before the next bounce adds its own); on the second
 		// stream, so that the closest-hit launch of the next bounce runs next to them -- the shading above has completed
 		if (nShadow) {
 			DQueues q2 = c->q; q2.spill = c->spillShadow;
 			hipEvent_t *ev2 = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
 			if (ev2) HIPCHK(c, hipEventRecord(ev2[0], s2));
-			launch_trace(s2, 1, c->countTraversal, false, c->dsc, c->paths, q2, c->q.shadow, blockedLen, first, nullptr, c->q.shadow_cnt);
+			launch_trace(s2, 1, c->countTraversal, false, c->dsc, c->paths, q2, c->q.shadow, nShadow, first);
 			if (ev2) HIPCHK(c, hipEventRecord(ev2[1], s2));
 			HIPCHK(c, hipGetLastError());
 			if (overlap) HIPCHK(c, hipEventRecord(c->evShadow[b & 1], s2));
@@ -538,7 +502,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 			        nQ, a, a > 0 ? nQ / a / 1e6 : 0.0, b2, nShadow, c2, c2 > 0 ? nShadow / c2 / 1e6 : 0.0);
 		}
 		std::swap(cur, nxt);
-		nQ = nNext; lenQ = blockedLen;
+		nQ = nNext;
 		first = false;
 	}
 	if (shadowPending && overlap) HIPCHK(c, hipStreamWaitEvent(s, c->evShadow[(b - 1) & 1], 0));
@@ -1063,7 +1027,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "xcd_segments", 0, 1 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);

@@ -36,13 +36,13 @@ constexpr int kLumStride = 32;        // MTSGPU_LUM_NPARAMS
 constexpr int kCounterStride = 32;    // one 128-byte line per queue counter (atomics on one line serialise)
 constexpr int kBsdfNParams = 16;      // MTSGPU_BSDF_NPARAMS
 constexpr int kBinShards = 16;        // the closest-hit kernel appends to bins[b] through 16 independent segments
-constexpr int kNumCounters = kNumBins * kBinShards + 5;   // bins x shards, next, shadow, dynamic heads of the two traversal launches, virtual queue length
+constexpr int kNumCounters = kNumBins * kBinShards + 4;   // bins x shards, next, shadow, dynamic heads of the two traversal launches
 // Two sets of counters, used by alternate bounces: the shadow rays of bounce b are traced (second stream) while the
 // closest-hit launch of bounce b + 1 already fills the next set
 constexpr int kCounterSets = 2;
-constexpr int kCntNext = kNumBins * kBinShards, kCntShadow = kCntNext + 1, kCntDynClosest = kCntNext + 2, kCntDynShadow = kCntNext + 3, kCntVirt = kCntNext + 4;
+constexpr int kCntNext = kNumBins * kBinShards, kCntShadow = kCntNext + 1, kCntDynClosest = kCntNext + 2, kCntDynShadow = kCntNext + 3;
 // word offsets of the two queue counters of k_shade inside a counter set (one 128-byte line each)
-constexpr int kNextWord = kCntNext * kCounterStride, kShadowWord = kCntShadow * kCounterStride, kVirtWord = kCntVirt * kCounterStride;
+constexpr int kNextWord = kCntNext * kCounterStride, kShadowWord = kCntShadow * kCounterStride;
 #ifndef MG_SHADE_BLOCK
 #define MG_SHADE_BLOCK 1024     // 512: two atomics-bound milliseconds more per 64-spp frame (one reservation per workgroup)
 #endif
@@ -185,20 +185,8 @@ struct DQueues {
 	uint32_t bin_stride;
 	uint32_t bin_seg_cap;
 	__host__ __device__ uint32_t *bin(int b) const { return bins_base + (size_t) b * bin_stride; }
-	// The two queues k_shade fills -- paths that continue (input of the next closest-hit launch) and pending shadow rays -- are
-	// BLOCKED: workgroup number w of a bounce's shading (all its bins in bin order, `out block`) owns the entries
-	// [w * kShadeBlock, (w + 1) * kShadeBlock) of both, packs what it produces at the front of them and leaves the counts in
-	// next_cnt[w] / shadow_cnt[w].  No position depends on another workgroup, so no returning atomic and no wait for one;
-	// the holes at the ends of the blocks cost the consumer nothing but a look at the count (k_trace skips them).  The
-	// counters kCntNext / kCntShadow still receive the totals (non-returning adds: statistics, loop termination).
-	uint32_t *next;
-	uint32_t *shadow;
-	uint32_t *next_cnt, *shadow_cnt;
-	// k_trace, k_shade: the queue being READ is blocked like that when in_cnt is set (entry i is valid iff
-	// i % kShadeBlock < in_cnt[i / kShadeBlock]); nullptr = a dense queue
-	const uint32_t *in_cnt;
-	const uint32_t *n_real;       // device-driven bounces: where the real number of rays stands (statistics; n_dev is the blocked length)
-	uint32_t totals_by_atomics;   // k_shade adds its counts to kCntNext / kCntShadow itself (device-driven bounces); 0: k_sum_blocks follows
+	uint32_t *next;               // paths that continue (input of the next closest-hit launch)
+	uint32_t *shadow;             // paths with a pending shadow ray
 	uint32_t *counters;           // the counter set of this bounce, [i * kCounterStride]: i = b * kBinShards + shard for the bins, then kCnt*
 	// counting builds (u64 x kNumTraceCounts): n_inner, n_leaf, n_idx, n_tri_tested, the lane slots of the three loops and of
 	// the batches, then the vector-memory requests the kernel ISSUED: sibling pairs from global memory / from the LDS copy,
@@ -225,6 +213,7 @@ struct DQueues {
 	uint32_t tune_dyn_min_rounds;      // launches of at least this many rounds claim their last rounds dynamically (0 = 8)
 	uint32_t tune_blocks_per_cu;       // experiment: fewer resident workgroups of kTraceBlock threads per CU than trace_blocks_per_cu(mode)
 	                                   // (3 closest-hit / 4 shadow at 512 threads); 0 or a value >= that = all.  Range 0..kTraceBlocksPerCuMax
+	uint32_t tune_xcd;                 // experiment: XCD x (workgroups with blockIdx % 8 == x) takes the x-th eighth of the queue
 };
 
 // How one traversal launch over n rays is scheduled.  A pure function of (n, mode, q): the host evaluates it to size
@@ -295,29 +284,22 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 // n_dev == NULL: n rays, grid sized for them.  n_dev != NULL: the count is read from device memory by the kernel and n
 // is only its upper bound (device-driven bounces: the host never learns the queue sizes)
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
-                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *n_dev = nullptr,
-                  const uint32_t *in_cnt = nullptr, const uint32_t *n_real = nullptr);
-// in_cnt: the queue is blocked (DQueues::next) and n is its blocked length; n_real (device-driven bounces): where the number
-// of rays it really holds stands
+                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *n_dev = nullptr);
 // prefix[s] = number of entries of the bin in segments < s (prefix[kBinShards] = total)
-// first_block: the out block (DQueues::next) of the bin's first workgroup = workgroups of the bins before it
-struct BinView { uint32_t prefix[kBinShards + 1]; uint32_t first_block; };
+struct BinView { uint32_t prefix[kBinShards + 1]; };
 // views_dev == NULL: the bin has view.prefix[kBinShards] entries.  Otherwise the view is views_dev[bin] (written by
 // k_prep on the device) and n_bound bounds its size
 // bin_ids: the bin's id segments (q.bin(bin) unless the caller shades another queue)
 void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
                   const DQueues &q, const BinView &view, const BinView *views_dev = nullptr, uint32_t n_bound = 0,
-                  const uint32_t *bin_ids = nullptr, const uint32_t *in_cnt = nullptr);
-// in_cnt: bin_ids is a blocked queue (the ray queue a round of MIDirectIntegrator shades), view.prefix[*] its blocked length
+                  const uint32_t *bin_ids = nullptr);
 // device-driven bounces, path integrator / one-sample direct integrator: all bins of bin_mask in one launch; views_dev as
 // above, n_bound bounds the sum of the bin sizes
 void launch_shade_all(hipStream_t s, const DScene &sc, const DPaths &ps, const DConfig &cfg, const DQueues &q,
                       const BinView *views_dev, uint32_t bin_mask, uint32_t n_bound);
 // device-driven bounces: per-bin views from the shard counters of the closest-hit launch that just ran (`cur`), and
 // the counter set of the next bounce zeroed
-void launch_sum_blocks(hipStream_t s, const uint32_t *next_cnt, const uint32_t *shadow_cnt, uint32_t n_blocks, uint32_t *counters);
-// ... and the blocked length of the queues this bounce's shading will fill, left in cur[kVirtWord]
-void launch_prep(hipStream_t s, uint32_t *cur, uint32_t *next_set, BinView *views_dev, uint32_t bin_seg_cap,
+void launch_prep(hipStream_t s, const uint32_t *cur, uint32_t *next_set, BinView *views_dev, uint32_t bin_seg_cap,
                  unsigned long long *dev_stats);
 // path_len (may be NULL): u64 sum of the final path depths (the avgPathLength statistic, path.cpp:212-213)
 void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,

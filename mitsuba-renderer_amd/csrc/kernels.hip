@@ -605,7 +605,6 @@ constexpr int kStackLDS = MG_STACK_LDS;       // stack levels kept in LDS (deepe
 constexpr uint32_t kTopPairs = MG_TOP_PAIRS;
 constexpr int kSpillLevels = 50 - kStackLDS;      // LDS + spill levels = MTS_KD_MAXDEPTH (48, gkdtree.h:35) + 2
 static_assert(kStackLDS >= 1 && kStackLDS + kSpillLevels >= 48 + 2, "the traversal stack must hold every tree the reference can build");
-constexpr uint32_t kDynClaim = 4;          // batches per dynamic claim of a blocked queue (k_trace's ray supply)
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 
@@ -676,15 +675,8 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 	const uint32_t B = plan.batch, static_n = plan.static_n;
 	const uint64_t limitMask = (B >= 64u) ? ~0ull : ((1ull << B) - 1ull);
 	uint32_t next_static = first;           // queue index of this wave's next static batch (uniform)
-	// A blocked queue has its holes at the ENDS of its blocks, and a round of the grid is a whole number of blocks: a wave that
-	// kept its place in every round would meet the same position inside a block every time -- the waves at the block ends
-	// nothing but holes (a shadow queue is half holes), the others all the rays.  So the waves move on by one batch per
-	// round: round r hands wave w the batch (w + r) mod (waves of the grid).
-	const uint32_t n_slots = stride / B;    // waves of the grid
-	uint32_t slot = first / B, round_base = 0;
 	uint32_t sup_base = 0, sup_left = 0;    // the chunk being handed out: queue[sup_base .. sup_base + sup_left)
 	bool dyn_done = static_n >= n;          // nothing (left) to claim dynamically
-	uint32_t dyn_next = 0, dyn_chunks = 0;  // what is left of the last dynamic claim: dyn_chunks batches from queue index dyn_next on
 	const uint32_t refill_min = plan.refill_min, desc_min = plan.desc_min, leaf_min = plan.leaf_min;
 
 	uint32_t id = 0;
@@ -708,45 +700,17 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 		const uint32_t nlive = (uint32_t) __popcll(liveMask);
 		const bool wantRays = nlive == 0u || B - nlive >= refill_min;
 		if (wantRays && sup_left == 0u) {
-			// next chunk: a batch of the static share, or one claimed from the shared tail of the queue.  A blocked queue
-			// (q.in_cnt) has holes at the ends of its blocks: a chunk never straddles two blocks (kShadeBlock % B == 0), what
-			// it holds is the block's count minus the chunk's offset, and empty chunks are passed over
-			bool got;
-			do {
-				got = false;
-				if (q.in_cnt ? round_base < static_n : next_static < static_n) {
-					if (q.in_cnt) {
-						next_static = round_base + slot * B;       // < 2^32: round_base + stride <= static_n + stride
-						round_base += stride; slot = (slot + 1u == n_slots) ? 0u : slot + 1u;
-					}
-					sup_base = next_static; sup_left = next_static >= static_n ? 0u : ((static_n - next_static < B) ? static_n - next_static : B);
-					if (!q.in_cnt) next_static += stride;
-					got = true;
-				} else if (dyn_chunks != 0u || !dyn_done) {
-					if (dyn_chunks == 0u) {
-						// one returning atomic claims kDynClaim batches of a blocked queue (its holes make the same rays cost more
-						// claims, and one counter word takes ~88 per microsecond), one batch of a dense queue
-						const uint32_t per = q.in_cnt ? kDynClaim : 1u;
-						uint32_t b = 0;
-						if (lane == 0) b = atomicAdd(&q.counters[(MODE == 0 ? kCntDynClosest : kCntDynShadow) * kCounterStride], 1u);
-						b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
-						const unsigned long long base = (unsigned long long) static_n + (unsigned long long) B * per * b;
-						if (base < n) { dyn_next = (uint32_t) base; dyn_chunks = per; }
-						else dyn_done = true;
-					}
-					if (dyn_chunks != 0u) {
-						--dyn_chunks;
-						if (dyn_next < n) { sup_base = dyn_next; sup_left = (n - dyn_next < B) ? n - dyn_next : B; dyn_next += B; got = true; }
-						else dyn_chunks = 0u;
-					}
-				}
-				if (got && q.in_cnt) {
-					const uint32_t ub = (uint32_t) __builtin_amdgcn_readfirstlane((int) sup_base);
-					const uint32_t have = q.in_cnt[ub / (uint32_t) kShadeBlock], off = ub % (uint32_t) kShadeBlock;
-					const uint32_t valid = have > off ? have - off : 0u;
-					if (valid < sup_left) sup_left = valid;
-				}
-			} while (got && sup_left == 0u);
+			// next chunk: a batch of the static share, or one claimed from the shared tail of the queue
+			if (next_static < static_n) {
+				sup_base = next_static; sup_left = (static_n - next_static < B) ? static_n - next_static : B; next_static += stride;
+			} else if (!dyn_done) {
+				uint32_t b = 0;
+				if (lane == 0) b = atomicAdd(&q.counters[(MODE == 0 ? kCntDynClosest : kCntDynShadow) * kCounterStride], 1u);
+				b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
+				const unsigned long long base = (unsigned long long) static_n + (unsigned long long) B * b;
+				if (base < n) { sup_base = (uint32_t) base; sup_left = (n - sup_base < B) ? n - sup_base : B; }
+				else dyn_done = true;
+			}
 		}
 		const uint32_t remaining = sup_left;
 		if (nlive == 0u || (remaining != 0u && wantRays)) {
@@ -1064,46 +1028,36 @@ __global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(MODE)) void k_tra
 	const TracePlan plan = trace_plan(n, MODE, q);
 	if (blockIdx.x >= plan.blocks)
 		return;                            // a grid sized for the worst case: nothing left for this workgroup
-	// a blocked queue can have length without holding a ray (every path of the bounce ended): nothing to do then
-	const uint32_t n_real = q.n_real ? (uint32_t) __builtin_amdgcn_readfirstlane((int) *q.n_real) : n;
-	if (n_real == 0u)
-		return;
 	if (q.dev_stats && blockIdx.x == 0 && threadIdx.x == 0) {
-		atomicAdd(&q.dev_stats[MODE == 0 ? kStatClosest : kStatShadow], (unsigned long long) n_real);
+		atomicAdd(&q.dev_stats[MODE == 0 ? kStatClosest : kStatShadow], (unsigned long long) n);
 		atomicAdd(&q.dev_stats[kStatLaunches], 1ull);
 	}
-	const uint32_t first = (blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6)) * plan.batch;
-	const uint32_t stride = plan.blocks * (kTraceBlock / 64u) * plan.batch;      // queue entries per round of the grid
+	TracePlan p2 = plan;
+	uint32_t lo = 0, hi = n, bi = blockIdx.x, nb = plan.blocks;
+	if (q.tune_xcd && (plan.blocks & 7u) == 0u) {
+		// experiment: contiguous eighths of the queue per XCD (workgroups are dealt to the XCDs round robin), so that a
+		// queue sorted by where its rays end keeps the deep part of the tree of one region in ONE L2
+		const uint32_t xcd = blockIdx.x & 7u;
+		const uint32_t seg = (((n + 7u) / 8u) + plan.batch - 1u) / plan.batch * plan.batch;
+		lo = xcd * seg < n ? xcd * seg : n; hi = lo + seg < n ? lo + seg : n;
+		bi = blockIdx.x >> 3; nb = plan.blocks >> 3;
+		p2.static_n = hi;
+	}
+	const uint32_t first = lo + (bi * (kTraceBlock / 64u) + (threadIdx.x >> 6)) * plan.batch;
+	const uint32_t stride = nb * (kTraceBlock / 64u) * plan.batch;      // queue entries per round of the grid
 	if (kTopPairs) {
 		// the device tree is padded to at least 2 * kTopPairs nodes (mtsgpu_upload_scene)
 		for (uint32_t t = threadIdx.x; t < kTopPairs; t += kTraceBlock) s_top[t] = reinterpret_cast<const uint4 *>(sc.nodes)[t];
 		__syncthreads();
 	}
-	trace_body<MODE, COUNT, BIN>(sc, ps, q, plan, queue, n, first, stride, s_stack, s_mbox, s_top);
-}
-
-// The totals of the two blocked queues a bounce's shading filled: the sums of their block counts, into the queue counters
-// (one workgroup; what the host reads back once per bounce)
-__global__ __launch_bounds__(1024) void k_sum_blocks(const uint32_t *next_cnt, const uint32_t *shadow_cnt, uint32_t n_blocks, uint32_t *counters) {
-	__shared__ uint32_t s_sum[2][16];
-	uint32_t a = 0, b = 0;
-	for (uint32_t i = threadIdx.x; i < n_blocks; i += 1024u) { a += next_cnt[i]; b += shadow_cnt[i]; }
-	for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-	if (lane_id() == 0) { s_sum[0][threadIdx.x >> 6] = a; s_sum[1][threadIdx.x >> 6] = b; }
-	__syncthreads();
-	if (threadIdx.x < 2) {
-		uint32_t t = 0;
-		for (int w = 0; w < 16; ++w) t += s_sum[threadIdx.x][w];
-		counters[threadIdx.x == 0 ? kNextWord : kShadowWord] = t;
-	}
+	trace_body<MODE, COUNT, BIN>(sc, ps, q, p2, queue, hi, first, stride, s_stack, s_mbox, s_top);
 }
 
 // Device-driven bounces: the per-bin views k_shade needs, from the shard counters the closest-hit launch left in `cur`
 // (what the host computes from a read-back otherwise), and the counter set of the NEXT bounce cleared.  One workgroup.
-__global__ __launch_bounds__(256) void k_prep(uint32_t *cur, uint32_t *next_set, BinView *views, uint32_t bin_seg_cap,
+__global__ __launch_bounds__(256) void k_prep(const uint32_t *cur, uint32_t *next_set, BinView *views, uint32_t bin_seg_cap,
                                               unsigned long long *dev_stats) {
 	__shared__ uint32_t s_cnt[kNumBins * kBinShards];
-	__shared__ uint32_t s_tot[kNumBins];
 	const uint32_t t = threadIdx.x;
 	if (t < (uint32_t) (kNumBins * kBinShards)) {
 		const uint32_t c = cur[t * kCounterStride];
@@ -1120,15 +1074,6 @@ __global__ __launch_bounds__(256) void k_prep(uint32_t *cur, uint32_t *next_set,
 			acc += c < bin_seg_cap ? c : bin_seg_cap;      // entries beyond the capacity were dropped (and flagged)
 		}
 		views[t].prefix[kBinShards] = acc;
-		s_tot[t] = acc;
-	}
-	__syncthreads();
-	if (t == 0) {
-		// the out blocks of this bounce's shading: bin after bin, whole workgroups; their number x kShadeBlock is the
-		// blocked length of the two queues it fills (read by the traversal launches that follow as their ray count)
-		uint32_t blocks = 0;
-		for (int b = 0; b < kNumBins; ++b) { views[b].first_block = blocks; blocks += (s_tot[b] + kShadeBlock - 1u) / kShadeBlock; }
-		cur[kVirtWord] = blocks * (uint32_t) kShadeBlock;
 	}
 }
 
@@ -2231,24 +2176,25 @@ __device__ __forceinline__ void shade_path(const DScene &sc, const DPaths &ps, c
 #else
 #define MG_SHADE_BOUNDS __launch_bounds__(kShadeBlock)
 #endif
-// the workgroup's LDS: the per-wave counts of the stream compaction and the staged path records
+// the workgroup's LDS: per-wave counts and the two queue offsets of the stream compaction, the staged path records
 struct ShadeShared {
 	uint32_t cnt[2][kShadeBlock / 64];
+	uint32_t base[2];
 	float4 rows[kShadeBlock / 64][64 * kRowStride];
 };
 // One workgroup of k_shade: the paths block * kShadeBlock .. of the material queue whose segment sizes are `prefix`
 // (prefix[kBinShards] entries in kBinShards segments of bin_ids)
 template <int BT, bool ROUNDS>
 __device__ __forceinline__ void shade_block(const DScene &sc, const DPaths &ps, const DConfig &cfg, const DQueues &q, const uint32_t *prefix,
-                                            const uint32_t *bin_ids, const uint32_t block, const uint32_t out_block, ShadeShared &sh) {
+                                            const uint32_t *bin_ids, const uint32_t block, ShadeShared &sh) {
 	uint32_t (&s_cnt)[2][kShadeBlock / 64] = sh.cnt;
+	uint32_t (&s_base)[2] = sh.base;
 	float4 (&s_rows)[kShadeBlock / 64][64 * kRowStride] = sh.rows;
 	const uint32_t gtid = block * kShadeBlock + threadIdx.x;
 	const uint32_t total = prefix[kBinShards];
 	if (block * kShadeBlock >= total)
 		return;                            // (uniform) a grid sized for the worst case
-	// a blocked input queue (q.in_cnt: the ray queue a round of MIDirectIntegrator shades) has holes at the ends of its blocks
-	const bool active = gtid < total && (!q.in_cnt || threadIdx.x < q.in_cnt[block]);
+	const bool active = gtid < total;
 	uint32_t id = 0u;
 	if (active) {
 		int seg = 0;
@@ -2320,38 +2266,29 @@ __device__ __forceinline__ void shade_block(const DScene &sc, const DPaths &ps, 
 		if (((actMask >> src) & 1ull) && (MG_SHADE_ALL_SLOTS || (sub != 2u && sub != 7u))) st_stream<4>(&ps.base[(size_t) sid * kPathSlots + sub], rows[shade_row_index(src, sub)]);
 	}
 
-	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue.  Both queues are blocked
-	// (kernels.h, DQueues::next): this workgroup owns the entries [out_block * kShadeBlock, + kShadeBlock) of each, packs its
-	// survivors and its shadow rays at the front -- ballot + prefix popcount inside each wave, the wave counts summed through
-	// LDS -- and leaves the two counts for the traversal kernels.  No position depends on another workgroup: the returning
-	// atomic on a queue counter that used to reserve the slots (one word takes ~88 of them per microsecond, and every wave of
-	// the workgroup waited for its round trip between two barriers) is gone; the totals go out as non-returning adds.
+	// stream compaction: survivors -> next closest-hit queue, shadow rays -> shadow queue.
+	// ballot + prefix popcount inside each wave, an LDS scan across the waves, ONE atomic per workgroup and queue
+	// (a queue counter is a single word: every atomic on it serialises, which is why the workgroups are as large as
+	// they can be: 1024 threads, 43.6 -> 41.9 ms per 64-spp frame against 512).  Measured and rejected: both queues
+	// reserved with one 64-bit atomic on a shared word (43.4 ms); the reservation issued before the records are written
+	// back so that its round trip hides under those stores (45 ms: the extra barrier delays the stores of every wave)
 	const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
 	const unsigned long long mN = __ballot(continues), mS = __ballot(wantShadow);
 	if (lane == 0) { s_cnt[0][wave] = (uint32_t) __popcll(mN); s_cnt[1][wave] = (uint32_t) __popcll(mS); }
 	__syncthreads();
-	uint32_t offN = 0, offS = 0, totN = 0, totS = 0;
-	#pragma unroll
-	for (uint32_t w = 0; w < (uint32_t) (kShadeBlock / 64); ++w) {
-		const uint32_t a = s_cnt[0][w], b = s_cnt[1][w];
-		if (w < wave) { offN += a; offS += b; }
-		totN += a; totS += b;
+	if (threadIdx.x < 2) {
+		uint32_t total = 0;
+		for (int w = 0; w < kShadeBlock / 64; ++w) total += s_cnt[threadIdx.x][w];
+		s_base[threadIdx.x] = total ? atomicAdd(&q.counters[threadIdx.x == 0 ? kNextWord : kShadowWord], total) : 0u;
 	}
-	const uint32_t out0 = out_block * (uint32_t) kShadeBlock;
-	if (threadIdx.x == 0) {
-		q.next_cnt[out_block] = totN; q.shadow_cnt[out_block] = totS;
-		// the totals: device-driven bounces (few workgroups) add them up here; a large frame sums the block counts in a kernel
-		// of its own (k_sum_blocks) -- tens of thousands of adds on one word cost a millisecond per launch
-		if (q.totals_by_atomics) {
-			if (totN) atomicAdd(&q.counters[kNextWord], totN);
-			if (totS) atomicAdd(&q.counters[kShadowWord], totS);
-		}
-	}
+	__syncthreads();
+	uint32_t offN = s_base[0], offS = s_base[1];
+	for (uint32_t w = 0; w < wave; ++w) { offN += s_cnt[0][w]; offS += s_cnt[1][w]; }
 	const unsigned long long below = (1ull << lane) - 1ull;
-	if (continues) q.next[out0 + offN + (uint32_t) __popcll(mN & below)] = id;
+	if (continues) q.next[offN + (uint32_t) __popcll(mN & below)] = id;
 	if (wantShadow) {
 		// the shadow ray lives in queue order (coalesced for both kernels); the path id rides in nee.w
-		const uint32_t pos = out0 + offS + (uint32_t) __popcll(mS & below);
+		const uint32_t pos = offS + (uint32_t) __popcll(mS & below);
 		st_stream<4>(&ps.shq_o[pos], make_float4(shO.x, shO.y, shO.z, 0.0f));
 		st_stream<4>(&ps.shq_d[pos], make_float4(shD.x, shD.y, shD.z, 0.0f));
 		st_stream<4>(&ps.shq_nee[pos], make_float4(neeV.x, neeV.y, neeV.z, __uint_as_float(id)));
@@ -2363,8 +2300,7 @@ __global__ MG_SHADE_BOUNDS void k_shade(DScene sc, DPaths ps, DConfig cfg, DQueu
                                                        const BinView *views_dev, const uint32_t *bin_ids) {
 	__shared__ ShadeShared sh;
 	// the bin's segment sizes: a kernel argument when the host read the counters back, otherwise what k_prep wrote
-	const BinView &view = views_dev ? views_dev[BT] : view_host;
-	shade_block<BT, ROUNDS>(sc, ps, cfg, q, view.prefix, bin_ids, blockIdx.x, view.first_block + blockIdx.x, sh);
+	shade_block<BT, ROUNDS>(sc, ps, cfg, q, views_dev ? views_dev[BT].prefix : view_host.prefix, bin_ids, blockIdx.x, sh);
 }
 
 // All material queues of a bounce in ONE launch (device-driven bounces): the workgroups are dealt to the bins in bin order,
@@ -2384,15 +2320,15 @@ __global__ MG_SHADE_BOUNDS void k_shade_all(DScene sc, DPaths ps, DConfig cfg, D
 	if (bin < 0) return;
 	const uint32_t *prefix = views_dev[bin].prefix, *ids = q.bin(bin);
 	switch (bin) {
-		case 0: shade_block<0, false>(sc, ps, cfg, q, prefix, ids, block, blockIdx.x, sh); break;
-		case 1: shade_block<1, false>(sc, ps, cfg, q, prefix, ids, block, blockIdx.x, sh); break;
-		case 2: shade_block<2, false>(sc, ps, cfg, q, prefix, ids, block, blockIdx.x, sh); break;
-		case 3: shade_block<3, false>(sc, ps, cfg, q, prefix, ids, block, blockIdx.x, sh); break;
-		case 4: shade_block<4, false>(sc, ps, cfg, q, prefix, ids, block, blockIdx.x, sh); break;
-		case 5: shade_block<5, false>(sc, ps, cfg, q, prefix, ids, block, blockIdx.x, sh); break;
-		case 6: shade_block<6, false>(sc, ps, cfg, q, prefix, ids, block, blockIdx.x, sh); break;
-		case 7: shade_block<7, false>(sc, ps, cfg, q, prefix, ids, block, blockIdx.x, sh); break;
-		default: shade_block<kNumBsdfTypes, false>(sc, ps, cfg, q, prefix, ids, block, blockIdx.x, sh); break;
+		case 0: shade_block<0, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 1: shade_block<1, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 2: shade_block<2, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 3: shade_block<3, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 4: shade_block<4, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 5: shade_block<5, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 6: shade_block<6, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		case 7: shade_block<7, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
+		default: shade_block<kNumBsdfTypes, false>(sc, ps, cfg, q, prefix, ids, block, sh); break;
 	}
 }
 
@@ -2711,12 +2647,10 @@ static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, co
 }
 
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
-                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *n_dev,
-                  const uint32_t *in_cnt, const uint32_t *n_real) {
+                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *n_dev) {
 	if (!n) return;
 	DQueues qq = q;
 	qq.coherent = coherent ? 1u : 0u;
-	qq.in_cnt = in_cnt; qq.n_real = n_real;
 	if (n_dev)
 		qq.force_static = 1u;        // no dynamically claimed batches: the material-queue segments cannot overflow then
 	if (mode == 0) {
@@ -2729,26 +2663,19 @@ void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &s
 	}
 }
 
-void launch_sum_blocks(hipStream_t s, const uint32_t *next_cnt, const uint32_t *shadow_cnt, uint32_t n_blocks, uint32_t *counters) {
-	hipLaunchKernelGGL(k_sum_blocks, dim3(1), dim3(1024), 0, s, next_cnt, shadow_cnt, n_blocks, counters);
-}
-
-void launch_prep(hipStream_t s, uint32_t *cur, uint32_t *next_set, BinView *views_dev, uint32_t bin_seg_cap,
+void launch_prep(hipStream_t s, const uint32_t *cur, uint32_t *next_set, BinView *views_dev, uint32_t bin_seg_cap,
                  unsigned long long *dev_stats) {
 	hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, s, cur, next_set, views_dev, bin_seg_cap, dev_stats);
 }
 
 void launch_shade(hipStream_t s, int bin, const DScene &sc, const DPaths &ps, const DConfig &cfg,
-                  const DQueues &q, const BinView &view, const BinView *views_dev, uint32_t n_bound, const uint32_t *bin_ids,
-                  const uint32_t *in_cnt) {
+                  const DQueues &q, const BinView &view, const BinView *views_dev, uint32_t n_bound, const uint32_t *bin_ids) {
 	const uint32_t n = views_dev ? n_bound : view.prefix[kBinShards];
 	if (!n) return;
 	if (!bin_ids) bin_ids = q.bin(bin);
-	DQueues qq = q;
-	qq.in_cnt = in_cnt; qq.n_real = nullptr;
 	const dim3 g(blocks_for(n, kShadeBlock)), b(kShadeBlock);
-	#define MG_SHADE(BT) do { if (cfg.dr_mode != 0) hipLaunchKernelGGL((k_shade<BT, true>), g, b, 0, s, sc, ps, cfg, qq, view, views_dev, bin_ids); \
-	                          else hipLaunchKernelGGL((k_shade<BT, false>), g, b, 0, s, sc, ps, cfg, qq, view, views_dev, bin_ids); } while (0)
+	#define MG_SHADE(BT) do { if (cfg.dr_mode != 0) hipLaunchKernelGGL((k_shade<BT, true>), g, b, 0, s, sc, ps, cfg, q, view, views_dev, bin_ids); \
+	                          else hipLaunchKernelGGL((k_shade<BT, false>), g, b, 0, s, sc, ps, cfg, q, view, views_dev, bin_ids); } while (0)
 	switch (bin) {
 		case 0: MG_SHADE(0); break;
 		case 1: MG_SHADE(1); break;
@@ -2768,9 +2695,7 @@ void launch_shade_all(hipStream_t s, const DScene &sc, const DPaths &ps, const D
 	if (!n_bound || !bin_mask) return;
 	// every bin rounds its size up to whole workgroups
 	const unsigned blocks = blocks_for(n_bound, kShadeBlock) + (unsigned) __builtin_popcount(bin_mask);
-	DQueues qq = q;
-	qq.in_cnt = nullptr; qq.n_real = nullptr;
-	hipLaunchKernelGGL(k_shade_all, dim3(blocks), dim3(kShadeBlock), 0, s, sc, ps, cfg, qq, views_dev, bin_mask);
+	hipLaunchKernelGGL(k_shade_all, dim3(blocks), dim3(kShadeBlock), 0, s, sc, ps, cfg, q, views_dev, bin_mask);
 }
 
 void launch_accumulate(hipStream_t s, const DPaths &ps, const DConfig &cfg, uint32_t n_slots,
