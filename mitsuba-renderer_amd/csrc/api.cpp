@@ -73,11 +73,9 @@ void applyTuning(mtsgpu_ctx *c) {
 	c->q.tune_refill = c->tuning.count("refill_min") ? 1u : 0u;
 	c->q.tune_batch = (uint32_t) get("batch", 0);
 	c->q.tune_dyn_div = (uint32_t) get("dyn_div", 0);
-	c->q.tune_xcd = (uint32_t) get("xcd_segments", 0);
 	c->q.tune_blocks_per_cu = (uint32_t) get("blocks_per_cu", 0);
 	c->q.tune_plain_below = (uint32_t) get("plain_below", 0);
 	c->q.tune_dyn_min_rounds = (uint32_t) get("dyn_min_rounds", 0);
-	if (c->q.tune_xcd) c->q.force_static = 1u;
 }
 
 // size of the full film the crop window lies in (film.cpp:33-41); without a crop window the film itself
@@ -1027,7 +1025,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "xcd_segments", 0, 1 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);

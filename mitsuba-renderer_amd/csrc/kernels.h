@@ -213,7 +213,6 @@ struct DQueues {
 	uint32_t tune_dyn_min_rounds;      // launches of at least this many rounds claim their last rounds dynamically (0 = 8)
 	uint32_t tune_blocks_per_cu;       // experiment: fewer resident workgroups of kTraceBlock threads per CU than trace_blocks_per_cu(mode)
 	                                   // (3 closest-hit / 4 shadow at 512 threads); 0 or a value >= that = all.  Range 0..kTraceBlocksPerCuMax
-	uint32_t tune_xcd;                 // experiment: XCD x (workgroups with blockIdx % 8 == x) takes the x-th eighth of the queue
 };
 
 // How one traversal launch over n rays is scheduled.  A pure function of (n, mode, q): the host evaluates it to size

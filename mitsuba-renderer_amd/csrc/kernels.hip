@@ -1032,25 +1032,14 @@ __global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(MODE)) void k_tra
 		atomicAdd(&q.dev_stats[MODE == 0 ? kStatClosest : kStatShadow], (unsigned long long) n);
 		atomicAdd(&q.dev_stats[kStatLaunches], 1ull);
 	}
-	TracePlan p2 = plan;
-	uint32_t lo = 0, hi = n, bi = blockIdx.x, nb = plan.blocks;
-	if (q.tune_xcd && (plan.blocks & 7u) == 0u) {
-		// experiment: contiguous eighths of the queue per XCD (workgroups are dealt to the XCDs round robin), so that a
-		// queue sorted by where its rays end keeps the deep part of the tree of one region in ONE L2
-		const uint32_t xcd = blockIdx.x & 7u;
-		const uint32_t seg = (((n + 7u) / 8u) + plan.batch - 1u) / plan.batch * plan.batch;
-		lo = xcd * seg < n ? xcd * seg : n; hi = lo + seg < n ? lo + seg : n;
-		bi = blockIdx.x >> 3; nb = plan.blocks >> 3;
-		p2.static_n = hi;
-	}
-	const uint32_t first = lo + (bi * (kTraceBlock / 64u) + (threadIdx.x >> 6)) * plan.batch;
-	const uint32_t stride = nb * (kTraceBlock / 64u) * plan.batch;      // queue entries per round of the grid
+	const uint32_t first = (blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6)) * plan.batch;
+	const uint32_t stride = plan.blocks * (kTraceBlock / 64u) * plan.batch;      // queue entries per round of the grid
 	if (kTopPairs) {
 		// the device tree is padded to at least 2 * kTopPairs nodes (mtsgpu_upload_scene)
 		for (uint32_t t = threadIdx.x; t < kTopPairs; t += kTraceBlock) s_top[t] = reinterpret_cast<const uint4 *>(sc.nodes)[t];
 		__syncthreads();
 	}
-	trace_body<MODE, COUNT, BIN>(sc, ps, q, p2, queue, hi, first, stride, s_stack, s_mbox, s_top);
+	trace_body<MODE, COUNT, BIN>(sc, ps, q, plan, queue, n, first, stride, s_stack, s_mbox, s_top);
 }
 
 // Device-driven bounces: the per-bin views k_shade needs, from the shard counters the closest-hit launch left in `cur`

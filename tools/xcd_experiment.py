@@ -5,6 +5,10 @@ orders, with and without `xcd_segments` (XCD x = workgroups with blockIdx % 8 ==
 queue).  Every XCD has its own 4 MB L2 and the deep part of the tree (nodes + leaf records: 57 MB) is what misses
 in it, so the question is whether handing each XCD the rays of ONE region of the scene turns misses into hits.
 
+The `xcd_segments` tuning knob this script drives was part of k_trace up to commit 95795f9 and was taken out once the
+result was in (profiles/r04a_exp_xcd_queues_*.txt: L2 hit rate 0.58 -> 0.80, kernel time unchanged); check that commit out
+to run it again.
+
   python3 tools/xcd_experiment.py            best-of-3 kernel time per order (HIP events)
   python3 tools/xcd_experiment.py --pmc      one launch per order, no warm-up: under
         rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum ... the i-th k_trace dispatch is the i-th label printed
