@@ -434,6 +434,7 @@ def main():
         # HBM traffic of the traversal launches from a separate PMC pass of the same frame (profiles/); only a
         # record taken with exactly these kernel sources counts
         traffic = None
+        l2 = {"l2_hit_rate": None, "l2_miss_per_ray": None}
         traffic_note = "no PMC record for these kernel sources (tools/profile_round.sh writes profiles/*_traffic.json)"
         try:
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
@@ -442,6 +443,7 @@ def main():
                 if tj.get("kernel_source_hash") == kernel_source_hash() and world == 1 and not strong \
                         and tj["workload"] == {"grid": args.grid, "res": args.res, "spp": args.spp}:
                     traffic = tj["hbm_bytes_per_launch"]; traffic_note = "profiles/" + f
+                    l2 = {"l2_hit_rate": tj.get("l2_hit_rate"), "l2_miss_per_ray": tj.get("l2_miss_per_ray")}
                     break
         except Exception:
             pass
@@ -497,6 +499,7 @@ def main():
                 "kernel": "k_trace (closest-hit + shadow kd-tree traversal)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                "l2_hit_rate": l2["l2_hit_rate"], "l2_miss_per_ray": l2["l2_miss_per_ray"],     # TCC_HIT / TCC_MISS of the same record
                 "peak_measured_triad": triad, "frac_of_triad": achieved / triad if triad else None,
                 "algorithmic_bytes_per_launch": bytes_per_step / max(counts["trace_launches"], 1),
                 "algorithmic_bytes_per_step": bytes_per_step, "bytes_per_ray": bytes_per_step / max(rays, 1),

@@ -19,6 +19,18 @@ def total(sub, counter, prefix):
 fetch, n1 = total("pmc_fetch", "FETCH_SIZE", "k_trace")
 write, n2 = total("pmc_write", "WRITE_SIZE", "k_trace")
 launches = max(n1, n2, 1)
+# L2 hits and misses of the same launches (pmc_mem pass) and the frame's ray count (STATS line of tools/pmc_workload.py)
+hit, _ = total("pmc_mem", "TCC_HIT_sum", "k_trace")
+miss, _ = total("pmc_mem", "TCC_MISS_sum", "k_trace")
+rays = None
+try:
+    import ast, re
+    for line in open(os.path.join(d, "pmc_mem.log")):
+        if line.startswith("STATS"):
+            st = ast.literal_eval(line[len("STATS "):line.index(" algorithmic_bytes")])
+            rays = st["rays_closest"] + st["rays_shadow"]
+except Exception:
+    pass
 out = {
     "workload": {"grid": 320, "res": 1024, "spp": 64},
     "kernel_source_hash": bench.kernel_source_hash(),
@@ -29,6 +41,9 @@ out = {
     "launches_per_frame": launches,
     "hbm_bytes_per_launch": (2 * fetch + write) * 1024 / launches,
     "hbm_bytes_per_launch_uncorrected": (fetch + write) * 1024 / launches,
+    "tcc_hit": hit, "tcc_miss": miss, "rays_per_frame": rays,
+    "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
+    "l2_miss_per_ray": miss / rays if rays else None,
 }
 path = os.path.join(ROOT, "profiles", "%s_traffic.json" % tag)
 json.dump(out, open(path, "w"), indent=1)
