@@ -764,76 +764,47 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	c->haveScene = false;
 	DScene d{};
 	int rc = 0;
-	std::vector<uint8_t> lastOfLeaf((size_t) sc->n_indices + 1, 0);      // entry e ends the record run of its leaf
 	{
-		// Device tree: one 16-byte RECORD per inner node that a traversal can arrive at by a fetch (the root, then every second
-		// level), holding what TWO descent steps need (kernels.h, "node records"): the node's own split, the splits -- or, for a
-		// leaf, the first entry of its record run -- of its two children, their axes and leaf flags, and the number of the
-		// 64-byte block that holds the slots of the four grandchildren.  A grandchild that is a leaf has a slot that says so.
-		// The first trace_top_nodes() records hold the top levels in breadth-first order (k_trace keeps them in LDS); below,
-		// the blocks follow depth first, so that a subtree's records lie together.  Which node the traversal visits when, and
-		// with which split, is the reference's (gkdtree.h:442-470); only where the numbers live changes.
+		// Device node order.  The first trace_top_nodes() slots hold the root and the sibling pairs below it in
+		// breadth-first order: k_trace keeps that prefix in LDS.  After it, 128-byte lines (16 nodes) are filled with
+		// breadth-first pieces of subtrees ("treelets") so that one L1 miss serves several consecutive traversal steps.
+		// The KDNode encoding is unchanged (siblings adjacent, relative offset to the left child,
+		// gkdtree.h:442-470); only where a node lives changes, which traversal results do not depend on.
 		const uint32_t N = sc->n_nodes;
+		const uint32_t topSlots = trace_top_nodes();
+		std::vector<uint32_t> newIndex(N, 0u);
+		std::vector<uint32_t> stack, cand;           // entries: old index of the left node of a sibling pair
 		auto leftOf = [&](uint32_t i) { return i + ((sc->kd_nodes[2 * (size_t) i] & 0x3FFFFFFCu) >> 2); };
 		auto isLeaf = [&](uint32_t i) { return (sc->kd_nodes[2 * (size_t) i] & 0x80000000u) != 0; };
-		auto axisOf = [&](uint32_t i) { return sc->kd_nodes[2 * (size_t) i] & 3u; };
-		auto splitOf = [&](uint32_t i) { return sc->kd_nodes[2 * (size_t) i + 1]; };
-		bool sharedEntries = false;
-		auto leafFirst = [&](uint32_t i) -> uint32_t {
-			const uint32_t start = sc->kd_nodes[2 * (size_t) i] & 0x7FFFFFFFu, end = sc->kd_nodes[2 * (size_t) i + 1];
-			if (start == end) return kEmptyLeaf;
-			// the end of a leaf's run is marked in its last record, so two leaves must not share entries
-			for (uint32_t e = start; e < end; ++e) { if (lastOfLeaf[e] & 2) sharedEntries = true; lastOfLeaf[e] |= 2; }
-			lastOfLeaf[end - 1] |= 1;
-			return start;
-		};
-		if ((uint64_t) sc->n_indices + 1 >= (uint64_t) kEmptyLeaf) return fail(c, MTSGPU_EINVAL, "kd-tree too large: more than 2^28 index entries");
-		(void) N;
-		const uint32_t topRecs = trace_top_nodes();
-		std::vector<uint32_t> recs(16, 0u);               // block 0: slot 0 = the root, three unused slots
-		auto emptySlot = [&](size_t slot) { recs[4 * slot] = 3u; recs[4 * slot + 1] = kEmptyLeaf; recs[4 * slot + 2] = recs[4 * slot + 3] = 0u; };
-		for (size_t k = 0; k < 4; ++k) emptySlot(k);
-		struct Item { uint32_t host, slot; };
-		std::vector<Item> fifo, lifo;
+		uint32_t pos = 2;                            // slot 0 = root, slot 1 = padding
+		newIndex[0] = 0;
+		if (!isLeaf(0)) cand.push_back(leftOf(0));
 		size_t head = 0;
-		fifo.push_back({ 0u, 0u });
-		while (head < fifo.size() || !lifo.empty()) {
-			Item it;
-			if (head < fifo.size()) it = fifo[head++]; else { it = lifo.back(); lifo.pop_back(); }
-			const uint32_t h = it.host;
-			uint32_t *R = &recs[4 * (size_t) it.slot];
-			if (isLeaf(h)) { R[0] = 3u; R[1] = leafFirst(h); R[2] = R[3] = 0u; continue; }
-			const uint32_t ch[2] = { leftOf(h), leftOf(h) + 1 };
-			uint32_t w0 = axisOf(h), s[2];
-			for (int k = 0; k < 2; ++k) {
-				if (isLeaf(ch[k])) { w0 |= 1u << (6 + k); s[k] = leafFirst(ch[k]); }
-				else { w0 |= axisOf(ch[k]) << (2 + 2 * k); s[k] = splitOf(ch[k]); }
+		while (head < cand.size() || !stack.empty()) {
+			if (head == cand.size()) { cand.clear(); head = 0; cand.push_back(stack.back()); stack.pop_back(); }
+			const uint32_t l = cand[head++];
+			newIndex[l] = pos; newIndex[l + 1] = pos + 1;
+			pos += 2;
+			for (uint32_t k = 0; k < 2; ++k)
+				if (!isLeaf(l + k)) cand.push_back(leftOf(l + k));
+			const bool full = pos < topSlots ? false : (pos == topSlots || (pos & 15u) == 0u);
+			if (full) {
+				// region full: the remaining frontier becomes the roots of later treelets (depth-first order)
+				for (size_t k = cand.size(); k > head; --k) stack.push_back(cand[k - 1]);
+				cand.clear(); head = 0;
 			}
-			if (!isLeaf(ch[0]) || !isLeaf(ch[1])) {
-				const size_t block = recs.size() / 16;
-				if (block >= (1u << 24)) return fail(c, MTSGPU_EINVAL, "kd-tree too large: more than 2^24 record blocks");
-				recs.resize(recs.size() + 16, 0u);
-				R = &recs[4 * (size_t) it.slot];                 // the vector may have moved
-				for (size_t k = 0; k < 4; ++k) emptySlot(4 * block + k);
-				w0 |= (uint32_t) block << 8;
-				// the top of the tree breadth first (it must fill the LDS prefix), everything below depth first
-				const bool top = recs.size() / 4 <= topRecs;
-				for (int k = 1; k >= 0; --k)
-					if (!isLeaf(ch[k]))
-						for (int z = 1; z >= 0; --z) {
-							const Item child{ leftOf(ch[k]) + (uint32_t) z, (uint32_t) (4 * block + 2 * k + z) };
-							if (top) fifo.push_back(child); else lifo.push_back(child);
-						}
-			}
-			R[0] = w0; R[1] = splitOf(h); R[2] = s[0]; R[3] = s[1];
 		}
-		if (recs.size() / 4 < topRecs) {                       // the LDS prefix is always there to copy
-			const size_t from = recs.size() / 4;
-			recs.resize(4 * (size_t) topRecs, 0u);
-			for (size_t k = from; k < topRecs; ++k) emptySlot(k);
+		const uint32_t total = std::max<uint32_t>(pos, std::max(2u, topSlots));      // the LDS prefix is always there to copy
+		if (total >= (1u << 29)) return fail(c, MTSGPU_EINVAL, "kd-tree too large");
+		std::vector<uint32_t> dev(2 * (size_t) total, 0u);
+		dev[2] = 0x80000000u; dev[3] = 0u;           // padding slot: empty leaf, never referenced
+		for (uint32_t i = 0; i < N; ++i) {
+			const uint32_t a = sc->kd_nodes[2 * (size_t) i], b = sc->kd_nodes[2 * (size_t) i + 1];
+			uint32_t *o = &dev[2 * (size_t) newIndex[i]];
+			if (a & 0x80000000u) { o[0] = a; o[1] = b; }
+			else { o[0] = (a & 3u) | (newIndex[leftOf(i)] << 2); o[1] = b; }     // absolute left-child index (< 2^29)
 		}
-		if (sharedEntries) return fail(c, MTSGPU_EINVAL, "kd-tree: two leaves share entries of the index list");
-		rc |= upload(c, (const uint32_t **) &d.nodes, recs.data(), recs.size());
+		rc |= upload(c, (const uint32_t **) &d.nodes, dev.data(), dev.size());
 	}
 	{
 		// TriAccel records re-laid out in leaf order (one contiguous run per leaf, no index
@@ -847,10 +818,9 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 			std::memcpy(dst, sc->triaccel + 12 * (size_t) prim, 48);
 			// dword 0 = k<<30 | non-occluder<<29 | primitive id (the head of the record decides everything
 			// up to the plane distance); dword 10 stays the shape index
-			if (prim >= (1u << 28)) return fail(c, MTSGPU_EINVAL, "more than 2^28 primitives");
+			if (prim >= (1u << 29)) return fail(c, MTSGPU_EINVAL, "more than 2^29 primitives");
 			const bool isShape = dst[0] == MTSGPU_KNOTRIANGLE;
-			// dword 0 = k << 30 | non-occluder << 29 | "last record of its leaf" << 28 | primitive id
-			dst[0] = (std::min(dst[0], 3u) << 30) | (sc->shape_bsdf[dst[10]] < 0 ? 0x20000000u : 0u) | ((lastOfLeaf[e] & 1) ? kLeafLastBit : 0u) | prim;
+			dst[0] = (std::min(dst[0], 3u) << 30) | (sc->shape_bsdf[dst[10]] < 0 ? 0x20000000u : 0u) | prim;
 			dst[11] = 0;
 			if ((dst[0] >> 30) == 3u) {
 				// k == 3: a degenerate triangle (dword 1 = 0) or a non-triangle shape (dword 1 = shape type,

@@ -27,8 +27,6 @@ constexpr unsigned trace_blocks_per_cu(int mode) { return (mode == 0 ? 24u : 32u
 constexpr unsigned trace_waves_per_simd(int mode) { return trace_blocks_per_cu(mode) * (kTraceBlock / 64) / 4; }
 constexpr unsigned kTraceBlocksPerCuMax = 2048 / kTraceBlock;      // largest persistent traversal grid: 32 waves per CU
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
-constexpr uint32_t kEmptyLeaf = 0x0FFFFFFFu;     // "first entry" of a leaf without entries (entries are numbered below 2^28 - 1)
-constexpr uint32_t kLeafLastBit = 0x10000000u;   // dword 0 of a leaf record: the last record of its leaf's run
 // uint4 per leaf record: the 48-byte TriAccel records lie back to back (2.67 per 128-byte line; three of eight straddle two
 // lines).  Measured and rejected (round 4, profiles/r04d_exp_trace_leaf_record_fetch.txt): one record per 64 bytes, so that
 // a tail always lies on the line of its head: 194.2 -> 196.7 ms of traversal per C3 frame (fewer heads per line).
@@ -60,14 +58,7 @@ enum { kStatClosest = 0, kStatShadow = 1, kStatOverflow = 2, kStatLaunches = 3, 
 
 // Scene in HBM (all pointers are device pointers); see DESIGN.md section 3
 struct DScene {
-	// NODE RECORDS, 16 B (mtsgpu_upload_scene builds them from the reference's 8-byte nodes).  A record belongs to an inner
-	// node X that a traversal arrives at by a fetch -- the root, then every second level -- and holds what TWO descent steps
-	// need: x = axis of X | axis of its left child << 2 | of its right child << 4 | "left child is a leaf" << 6 | "right child
-	// is a leaf" << 7 | block << 8; y = split plane of X; z, w = split plane of the left / right child, or, for a leaf child,
-	// the first entry of its record run (kEmptyLeaf: none).  The slots 4 block .. 4 block + 3 of the same array belong to the
-	// four grandchildren (left-left, left-right, right-left, right-right): a record again, or, for a leaf, x = 3 and y = its
-	// first entry.  The end of a leaf's run is marked in its last record (kLeafLastBit).
-	const uint4    *nodes;
+	const uint2    *nodes;        // 8 B: (left child index << 2 | axis, split) or (1 << 31 | first record, end record)
 	// TriAccel records in LEAF ORDER: entry e of the kd-tree index list holds the 48-byte
 	// TriAccel of primitive kd_indices[e] (dword 0 = k << 30 | "not an occluder" << 29 | global
 	// primitive id, dword 10 = shape), so a leaf's primitives are one contiguous run
@@ -101,7 +92,7 @@ struct DScene {
 
 // What k_trace needs of the scene (a kernel argument: the fewer scalar registers it pins, the fewer get spilled)
 struct DTraceScene {
-	const uint4 *nodes;
+	const uint2 *nodes;
 	const uint4 *leaf_ta;
 	const uint32_t *shape_bin;
 	uint32_t has_shapes;

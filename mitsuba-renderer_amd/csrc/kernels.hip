@@ -592,10 +592,10 @@ __device__ __forceinline__ bool sphere_occludes(V3 center, float radius, V3 ro, 
 // (sahkdtree3.h:130-144) is kept (LDS) because it decides equal-t ties.
 // ===========================================================================
 #ifndef MG_STACK_LDS
-#define MG_STACK_LDS 7
+#define MG_STACK_LDS 10
 #endif
 #ifndef MG_TOP_PAIRS
-#define MG_TOP_PAIRS 344      // node records in LDS: 86 blocks of 4 = levels 0, 2, 4, 6, 8 of the tree (the decisions of its top ten levels)
+#define MG_TOP_PAIRS (MG_TRACE_BLOCK >= 512 ? 1024 : 128)
 #endif
 constexpr int kStackLDS = MG_STACK_LDS;       // stack levels kept in LDS (deeper ones spill: 1 push in 10^4 at 12 levels on C3)
 // The first 2 * kTopPairs device nodes -- the root and the sibling pairs below it in breadth-first order, see
@@ -605,12 +605,12 @@ constexpr int kStackLDS = MG_STACK_LDS;       // stack levels kept in LDS (deepe
 constexpr uint32_t kTopPairs = MG_TOP_PAIRS;
 constexpr int kSpillLevels = 50 - kStackLDS;      // LDS + spill levels = MTS_KD_MAXDEPTH (48, gkdtree.h:35) + 2
 static_assert(kStackLDS >= 1 && kStackLDS + kSpillLevels >= 48 + 2, "the traversal stack must hold every tree the reference can build");
-enum : uint32_t { kRefSlot = 0, kRefLeft = 1, kRefRight = 2, kRefLeaf = 3 };     // what lies behind an exit point (trace_body)
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
+constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 
-size_t trace_spill_levels() { return 2 * kSpillLevels; }      // in dwords per thread (a stack entry is two)
+size_t trace_spill_levels() { return kSpillLevels; }      // in dwords per thread
 size_t trace_stack_levels() { return kStackLDS + kSpillLevels; }
-uint32_t trace_top_nodes() { return kTopPairs; }
+uint32_t trace_top_nodes() { return 2u * kTopPairs; }
 
 // Persistent waves: the grid is sized to fill the chip once and every wave walks its own 64-ray
 // batches of the queue with a private cursor (no work-queue atomic: a single head word saturates at
@@ -629,7 +629,7 @@ __device__ __forceinline__ const uint4 *leaf_tail(const DTraceScene &sc, uint32_
 template <int MODE, bool COUNT, bool BIN>
 __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &ps, const DQueues &q, const TracePlan &plan,
                                            const uint32_t *queue, uint32_t n, const uint32_t first, const uint32_t stride,
-                                           uint2 (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock], const uint4 *s_top) {
+                                           uint32_t (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock], const uint4 *s_top) {
 	// node fetches: from the LDS copy of the top of the tree when the index lies inside it
 	// COUNT: the requests this lane issued (global / served by the LDS copy) and, when q.rec is set, the list of them
 	uint32_t g_pair = 0, l_pair = 0, g_node = 0, l_node = 0, g_tail = 0, g_spill = 0, g_head = 0;
@@ -640,11 +640,15 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 			rec_n++;
 		}
 	};
-	// a node record (kernels.h): from the LDS copy of the top of the tree when the index lies inside it
-	auto load_rec = [&](uint32_t i) -> uint4 {
-		if (kTopPairs && i < kTopPairs) { if (COUNT) l_pair++; return s_top[i]; }
-		if (COUNT) { g_pair++; rec_add(kReqPair, i); }
+	auto load_node = [&](uint32_t i) -> uint2 {
+		if (kTopPairs && i < 2u * kTopPairs) { if (COUNT) l_node++; return reinterpret_cast<const uint2 *>(s_top)[i]; }
+		if (COUNT) { g_node++; rec_add(kReqNode, i); }
 		return sc.nodes[i];
+	};
+	auto load_pair = [&](uint32_t left) -> uint4 {
+		if (kTopPairs && left < 2u * kTopPairs) { if (COUNT) l_pair++; return s_top[left >> 1]; }
+		if (COUNT) { g_pair++; rec_add(kReqPair, left >> 1); }
+		return reinterpret_cast<const uint4 *>(sc.nodes)[left >> 1];
 	};
 	// The hashed mailbox decides which of two primitives with equal t is reported (sahkdtree3.h:130-144, :278-283), so
 	// closest-hit rays keep it.  For any-hit rays it only saves repeated tests of a primitive that spans several leaves --
@@ -680,20 +684,13 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 	float mint = 0, maxt = 0, tmax0 = 0;
 	float enx = 0, eny = 0, enz = 0, exx = 0, exy = 0, exz = 0, ex_t = 0;   // stack[enPt].p, stack[exPt].p, stack[exPt].t
 	int sp = 0;
-	// The current exit point is the split plane of a node the ray has yet to cross: ex_ref says what lies behind it --
-	// value << 4 | axis of that plane << 2 | kind: kRefSlot the slot `value` (a node that has a record of its own, or a leaf
-	// slot), kRefLeft / kRefRight the left / right child of the node whose record is `value` (resume at that record's second
-	// step), kRefLeaf a leaf whose first entry is `value` -- and ex_split is the plane.  Stack entries are such pairs.
-	uint32_t ex_ref = kSentinel, cur = 0;
-	float ex_split = 0;
-	uint4 R = make_uint4(0u, 0u, 0u, 0u);   // the record of the node the lane stands on (index cur)
-	uint32_t sub = 0;                       // 0: both steps of R are still to do; 2 / 3: its first step went left / right
-	uint32_t e_leaf = kEmptyLeaf;           // first entry of the leaf the lane stands on
-	bool inner = false;                     // the lane stands on an inner node (R is valid), otherwise on a leaf (e_leaf)
+	// the current exit point: ex_node = its far child, ex_ref = its stack word (parent index * 2 + "far child is the right one")
+	uint32_t ex_node = kNullNode, ex_ref = kSentinel, cur = 0;
 	float best_t = MG_INF, best_u = 0, best_v = 0;
 	uint32_t best_prim = kNoPrim, best_shape = 0;
 	// best_shape: shape index of the accepted hit (dword 10 of its record), read while the record is at hand
 	uint32_t e_cont = kNoPrim;              // position inside an interrupted leaf
+	uint2 nd = make_uint2(0u, 0u);          // sc.nodes[cur], fetched as soon as cur is known
 	bool found = false;
 	bool has = false;                       // this lane is traversing a ray
 	bool done = false;                      // this lane holds a finished ray that has not been retired yet
@@ -829,10 +826,9 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					enx = ox + mint * dx; eny = oy + mint * dy; enz = oz + mint * dz;      // stack[enPt].p = ray(mint)
 					tmax0 = maxt;
 					ex_t = maxt; exx = ox + maxt * dx; exy = oy + maxt * dy; exz = oz + maxt * dz;
-					ex_ref = kSentinel; ex_split = 0;
-					sp = 0; cur = 0; e_cont = kNoPrim; sub = 0;
-					R = load_rec(0u);
-					inner = (R.x & 3u) != 3u; e_leaf = R.y;          // a tree that is one leaf: the root slot says so
+					ex_node = kNullNode; ex_ref = kSentinel;
+					sp = 0; cur = 0; e_cont = kNoPrim;
+					nd = load_node(0u);
 				}
 			}
 		}
@@ -840,13 +836,20 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 		// ---- one leaf visit of every live lane: descend, test the leaf, pop ----
 		if (has) {
 			{
-				// One step of rayIntersectHavran's inner loop (sahkdtree3.h:196-252) at a node with split plane (axis, split),
-				// written without branches: this loop is bound by instruction issue (exec-mask bookkeeping of a branchy version
-				// costs more than the arithmetic), not by memory.  The entry / exit points are kept as the 3-vectors the
-				// reference stores (ray(t) with the split axis overwritten).  `which` = 1: the node is the one whose record R
-				// is (its children are described by R itself); 2: it is child c1 of that node (its children are the slots
-				// 2 c1, 2 c1 + 1 of R's block).  Returns the side the ray goes on to (1 = right).
-				auto step = [&](const int axis, const float split, const int which, const uint32_t c1) -> uint32_t {
+				bool inner = !(nd.x & 0x80000000u);     // nd = sc.nodes[cur] is part of the lane's state
+				// The descent stops as soon as fewer than q.desc_min lanes are still on inner nodes: the lanes
+				// that wait in a leaf go on, the few stragglers resume their descent in the next round.
+				do { if (inner) {
+					// One step of rayIntersectHavran's inner loop (sahkdtree3.h:196-252), written without
+					// branches: this loop is bound by instruction issue (exec-mask bookkeeping of a branchy
+					// version costs more than the arithmetic), not by memory.  The entry / exit points are
+					// kept as the 3-vectors the reference stores (ray(t) with the split axis overwritten).
+					const float split = __uint_as_float(nd.y);
+					const int axis = (int) (nd.x & 3u);
+					const uint32_t left = nd.x >> 2;            // device nodes hold the absolute index of the left child
+					// both children in one 16-byte load (sibling pairs are 16-byte aligned in the device order), issued
+					// before the case logic below instead of after it: the step is a chain of dependent fetches
+					const uint4 pair = load_pair(left);
 					if (COUNT) c_inner++;
 					MG_WSLOT(w_inner);
 					const float pen = sel3(enx, eny, enz, axis), pex = sel3(exx, exy, exz, axis);
@@ -861,49 +864,26 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					const uint64_t mC = __builtin_amdgcn_ballot_w64(C), mD = __builtin_amdgcn_ballot_w64(D);
 					const bool side1 = __builtin_amdgcn_inverse_ballot_w64(~mA | (~mB & mC));   // go to the right child now
 					const bool push = __builtin_amdgcn_inverse_ballot_w64((mA & ~mB & ~mC) | (~mA & ~mD));
+					const uint32_t side = side1 ? 1u : 0u;
 					if (push) {
-						// push the current exit point; the split plane of this node, with the far child behind it, becomes the exit point
-						const uint2 ent = make_uint2(ex_ref, __float_as_uint(ex_split));
-						if (sp < kStackLDS) s_stack[sp][tid] = ent;
-						else { reinterpret_cast<uint2 *>(q.spill)[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ent; if (COUNT) g_spill++; }
+						// push the current exit point's reference; (cur, far child) becomes the exit point
+						if (sp < kStackLDS) s_stack[sp][tid] = ex_ref;
+						else { q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref; if (COUNT) g_spill++; }
 						++sp;
 						const uint32_t farRight = A ? 1u : 0u;
 						const float distToSplit = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
-						uint32_t ref;
-						if (which == 1) {
-							const bool farLeaf = ((R.x >> (6u + farRight)) & 1u) != 0u;
-							const uint32_t sF = farRight ? R.w : R.z;
-							ref = farLeaf ? ((sF << 4) | kRefLeaf) : ((cur << 4) | (kRefLeft + farRight));
-						} else {
-							ref = (((R.x >> 8) * 4u + 2u * c1 + farRight) << 4) | kRefSlot;
-						}
-						ex_ref = ref | ((uint32_t) axis << 2);
-						ex_split = split;
+						ex_ref = (cur << 1) | farRight;
 						ex_t = distToSplit;
 						const float px = ox + distToSplit * dx, py = oy + distToSplit * dy, pz = oz + distToSplit * dz;
 						exx = (axis == 0) ? split : px; exy = (axis == 1) ? split : py; exz = (axis == 2) ? split : pz;   // selects, not branches
+						ex_node = left + farRight;
 					}
-					return side1 ? 1u : 0u;
-				};
-				// The descent: TWO tree levels per iteration and per fetch.  The record R of the node the lane stands on holds its
-				// own split and the splits of its two children, so the step at the node and the step at the child it leads to need
-				// no memory; what they end on is a slot of R's block, fetched once (a record to go on with, or a leaf).  A child that
-				// is a leaf is known from R itself.  The loop stops as soon as fewer than q.desc_min lanes are still on inner
-				// nodes: the lanes that wait in a leaf go on, the few stragglers resume their descent in the next round.
-				do { if (inner) {
-					uint32_t c = sub & 1u;                             // resuming at the second step: the first one went to child c
-					if (sub == 0u) c = step((int) (R.x & 3u), __uint_as_float(R.y), 1, 0u);
-					const uint32_t sC = c ? R.w : R.z;                 // the child's split, or the first entry of a leaf child
-					if ((R.x >> (6u + c)) & 1u) {
-						inner = false; e_leaf = sC;
-					} else {
-						const uint32_t z = step((int) ((R.x >> (2u + 2u * c)) & 3u), __uint_as_float(sC), 2, c);
-						cur = (R.x >> 8) * 4u + 2u * c + z;
-						R = load_rec(cur);
-						inner = (R.x & 3u) != 3u; e_leaf = R.y;
-					}
-					sub = 0u;
+					cur = left + side;
+					nd = side1 ? make_uint2(pair.z, pair.w) : make_uint2(pair.x, pair.y);
 				}
+				// evaluated for all lanes after the step (a lane that did not step sits on a leaf): the flag then is one
+				// compare on the merged register instead of a value carried through the branch
+				inner = !(nd.x & 0x80000000u);
 				} while ((uint32_t) __popcll(__builtin_amdgcn_ballot_w64(inner)) >= desc_min);
 
 				if (!inner) {
@@ -912,20 +892,20 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				MG_WSLOT(w_outer);
 				bool hitShadow = false, more = false;
 				{
-					uint32_t e = (e_cont != kNoPrim) ? e_cont : e_leaf;     // resume an interrupted leaf
-					// record = 3 x 16 B: A = (k<<30 | non-occluder<<29 | last of its leaf<<28 | prim, n_u, n_v, n_d),
-					// B = (a_u, a_v, b_nu, b_nv), C = (c_nu, c_nv, shape, -).  A alone decides the mailbox test and the plane
-					// distance t; B and C are only fetched for primitives whose t lies inside [mint, maxt] (triaccel.h:141-149).
+					uint32_t e = (e_cont != kNoPrim) ? e_cont : (nd.x & 0x7FFFFFFFu);     // resume an interrupted leaf
+					const uint32_t last = nd.y;
+					// record = 3 x 16 B: A = (k<<30 | non-occluder<<29 | prim, n_u, n_v, n_d), B = (a_u, a_v, b_nu, b_nv),
+					// C = (c_nu, c_nv, shape, -).  A alone decides the mailbox test and the plane distance t; B and C
+					// are only fetched for primitives whose t lies inside [mint, maxt] (triaccel.h:141-149).
 					uint4 A;
-					more = e != kEmptyLeaf;
+					more = e != last;
 					if (more) { A = ld_stream<2>(leaf_head(sc, e)); if (COUNT) { g_head++; rec_add(kReqLeaf, kLeafStride * e); } }
 					// like the descent, the primitive loop stops when fewer than q.leaf_min lanes have entries left;
 					// those lanes keep their position (e_cont) and go on in the next round
 					do { if (more) {
-						const bool lastEntry = (A.x & kLeafLastBit) != 0u;
 						uint4 An = A;
-						if (!lastEntry) { An = ld_stream<2>(leaf_head(sc, e + 1)); if (COUNT) { g_head++; rec_add(kReqLeaf, kLeafStride * (e + 1)); } }      // next record's head in flight
-						const uint32_t prim = A.x & 0x0FFFFFFFu, k = A.x >> 30;
+						if (e + 1 != last) { An = ld_stream<2>(leaf_head(sc, e + 1)); if (COUNT) { g_head++; rec_add(kReqLeaf, kLeafStride * (e + 1)); } }      // next record's head in flight
+						const uint32_t prim = A.x & 0x1FFFFFFFu, k = A.x >> 30;
 						if (COUNT) c_idx++;
 						MG_WSLOT(w_leaf);
 						// Flat form of the mailbox test + TriAccel::rayIntersect: the plane distance t is computed for
@@ -979,9 +959,8 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						if (kMbox) *mslot = prim;         // (re)writing an entry that is already there changes nothing
 						A = An;
 						++e;
-						more = !lastEntry;
 					}
-					more = more && !hitShadow;      // for all lanes: those that did not step had no entry left
+					more = (e != last) && !hitShadow;      // for all lanes: those that did not step have e == last or hitShadow
 					} while ((uint32_t) __popcll(__builtin_amdgcn_ballot_w64(more)) >= leaf_min);
 					e_cont = more ? e : kNoPrim;
 				}
@@ -990,36 +969,29 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				else if (more) { /* leaf not finished yet */ }
 				else if (ex_t > maxt) finished = true;
 				else {
-					// --- pop: the exit point becomes the entry point, what lies behind its plane is where the lane goes on ---
+					// --- pop: the exit point becomes the entry point ---
 					enx = exx; eny = exy; enz = exz;
-					const uint32_t target = ex_ref;
-					if (target == kSentinel) {
+					cur = ex_node;
+					if (cur == kNullNode) {
 						finished = true;
 					} else {
 						--sp;
-						const uint32_t kind = target & 3u, val = target >> 4;
-						if (kind == kRefLeaf) {
-							inner = false; e_leaf = val;                 // a leaf child: known since its parent's record was read
-						} else {
-							cur = val;
-							R = load_rec(val);                         // in flight while the exit point below is rebuilt
-							sub = (kind == kRefSlot) ? 0u : (2u | (kind - kRefLeft));
-						}
-						const uint2 ent = (sp < kStackLDS) ? s_stack[sp][tid]
-						                                   : reinterpret_cast<const uint2 *>(q.spill)[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
-						if (ent.x == kSentinel) {
+						nd = load_node(cur);         // in flight together with the parent's node below
+						const uint32_t ref = (sp < kStackLDS) ? s_stack[sp][tid] : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
+						if (ref == kSentinel) {
 							ex_t = tmax0; exx = ox + tmax0 * dx; exy = oy + tmax0 * dy; exz = oz + tmax0 * dz;
-							ex_ref = kSentinel;
+							ex_node = kNullNode; ex_ref = kSentinel;
 						} else {
-							// the exit point is a function of (its plane, the ray): rebuilt with the reference's formulas (sahkdtree3.h:233,248-249)
-							const int axis = (int) ((ent.x >> 2) & 3u);
-							const float split = __uint_as_float(ent.y);
+							// the exit point is a function of (parent node, ray): rebuilt with the reference's formulas (sahkdtree3.h:233,248-249)
+							const uint2 pn = load_node(ref >> 1);
+							const int axis = (int) (pn.x & 3u);
+							const float split = __uint_as_float(pn.y);
+							ex_node = (pn.x >> 2) + (ref & 1u);
 							ex_t = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
 							const float px = ox + ex_t * dx, py = oy + ex_t * dy, pz = oz + ex_t * dz;
 							exx = (axis == 0) ? split : px; exy = (axis == 1) ? split : py; exz = (axis == 2) ? split : pz;
-							ex_ref = ent.x; ex_split = split;
+							ex_ref = ref;
 						}
-						if (kind != kRefLeaf) { inner = kind != kRefSlot || (R.x & 3u) != 3u; e_leaf = R.y; }
 					}
 				}
 				if (finished) {
@@ -1048,7 +1020,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 template <int MODE, bool COUNT, bool BIN>
 __global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(MODE)) void k_trace(DTraceScene sc, DPaths ps, DQueues q,
                                                           const uint32_t *queue, uint32_t n_host, const uint32_t *n_dev) {
-	__shared__ uint2 s_stack[kStackLDS][kTraceBlock];
+	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
 	__shared__ uint32_t s_mbox[(MODE == 0 || COUNT) ? 8 : 1][kTraceBlock];
 	__shared__ uint4 s_top[kTopPairs ? kTopPairs : 1];
 	// the number of rays: known to the host, or left in device memory by the kernel that filled the queue
@@ -1064,7 +1036,7 @@ __global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(MODE)) void k_tra
 	const uint32_t stride = plan.blocks * (kTraceBlock / 64u) * plan.batch;      // queue entries per round of the grid
 	if (kTopPairs) {
 		// the device tree is padded to at least 2 * kTopPairs nodes (mtsgpu_upload_scene)
-		for (uint32_t t = threadIdx.x; t < kTopPairs; t += kTraceBlock) s_top[t] = sc.nodes[t];
+		for (uint32_t t = threadIdx.x; t < kTopPairs; t += kTraceBlock) s_top[t] = reinterpret_cast<const uint4 *>(sc.nodes)[t];
 		__syncthreads();
 	}
 	trace_body<MODE, COUNT, BIN>(sc, ps, q, plan, queue, n, first, stride, s_stack, s_mbox, s_top);
@@ -2471,12 +2443,12 @@ __global__ void k_build_replay(const uint32_t *rec, const uint32_t *rec_len, con
 // the node before it) and its arithmetic cost on top.  Same grid, same workgroup size and the LDS footprint of
 // k_trace<closest>, so the same number of waves is resident.  One coalesced 16-byte read of the list per four requests
 // comes on top.
-__global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(0)) void k_replay(const uint4 *nodes, const uint4 *leaf_ta, float4 *paths,
+__global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(0)) void k_replay(const uint2 *nodes, const uint4 *leaf_ta, float4 *paths,
                                                                                 const uint32_t *tr, const uint32_t *batch_len,
                                                                                 uint32_t n_batches, uint32_t cap, uint32_t zero, uint32_t *sink) {
-	__shared__ uint32_t s_pad[2 * kStackLDS + 8][kTraceBlock];
+	__shared__ uint32_t s_pad[kStackLDS + 8][kTraceBlock];
 	__shared__ uint4 s_top[kTopPairs ? kTopPairs : 1];
-	for (uint32_t t = threadIdx.x; t < kTopPairs; t += kTraceBlock) s_top[t] = nodes[t];
+	for (uint32_t t = threadIdx.x; t < kTopPairs; t += kTraceBlock) s_top[t] = reinterpret_cast<const uint4 *>(nodes)[t];
 	s_pad[threadIdx.x & 7u][threadIdx.x] = zero;
 	__syncthreads();
 	const uint32_t lane = lane_id();
