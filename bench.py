@@ -454,8 +454,9 @@ def main():
         triad = pkg.hbm_triad_gbs(device)
         gather = pkg.gather_roof(device, 4)
         req_per_step = issued_requests(counts)
-        replay = {"kernel": "k_trace<closest>", "bound": "vector-memory requests: the kernel's own request stream replayed without arithmetic "
-                  "(mtsgpu_replay_roof: same lines in the same per-ray order, node requests chained, same grid and LDS footprint)",
+        replay = {"kernel": "k_trace<closest>", "bound": "vector-memory requests: the kernel's own request stream replayed as a pure throughput test "
+                  "(mtsgpu_replay_roof: the same lines in the same per-ray order, one 16-byte load each, eight independent requests in "
+                  "flight per lane, no arithmetic, same grid and LDS footprint)",
                   "issued_requests_per_ray": req_per_step / max(rays, 1),
                   "lds_served_requests_per_ray": (counts["req_pair_lds"] + counts["req_node_lds"]) / max(rays, 1),
                   "issued_breakdown_per_ray": {"pairs": counts["req_pair_global"] / max(rays, 1), "pop_nodes": counts["req_node_global"] / max(rays, 1),

@@ -347,9 +347,11 @@ int  mtsgpu_gather_roof(int device, size_t footprint_bytes, double *lane_request
 /* Measurement: the REPLAY roof of the closest-hit traversal kernel.  Takes every stride-th of the first n * stride path
  * records in memory -- after mtsgpu_render() each holds the last ray of its path -- traces them once with the counting
  * kernel, which records every vector-memory request of every ray (which sibling pair, node, leaf-record chunk, path-record
- * slot), then times (a) the product kernel and (b) a kernel that re-issues exactly those requests, in the same order per
- * ray, node requests chained like the descent, from the same grid shape, with NO arithmetic, no stack, no mailbox: the
- * time the memory system needs for this request stream.  (b) / (a) is the fraction of its request roof the kernel runs at.
+ * slot), then times (a) the product kernel and (b) a kernel that re-issues exactly those requests as a pure throughput
+ * test: per ray in the recorded order, one 16-byte load per request from the line the traversal asked for, eight
+ * independent requests in flight per lane, the same grid shape and LDS footprint, NO arithmetic, no stack, no mailbox, no
+ * dependence between the requests -- the time the memory system needs for this set of lines.  (b) / (a) is the fraction of
+ * its request roof the kernel runs at.
  * out[12]: rays, recorded requests, rays whose list was truncated (256 requests), product ms, replay ms (best of reps),
  * then the issued-request counters of the sample: pairs global / LDS, nodes global / LDS, record heads, tails, spills.
  * Overwrites the hits of the sampled path records; call after the film has been read. */
