@@ -9,7 +9,7 @@
 #include <random>
 #include <algorithm>
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(512) void k_rw(nt_f4 *recs, const uint32_t *ids, uint32_t n, int write_mode, nt_f4 *dst) {
+template <int BS> __global__ __launch_bounds__(BS) void k_rw(nt_f4 *recs, const uint32_t *ids, uint32_t n, int write_mode, nt_f4 *dst) {
 	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, grp = lane >> 3;
 	uint32_t id = gtid < n ? ids[gtid] : 0u;
@@ -52,16 +52,19 @@ int main() {
 			for (uint32_t i = 0; i < nRuns; ++i) for (int k = 0; k < run; ++k) h[(size_t) i * run + k] = bases[i] * run + k;
 		}
 		hipMemcpy(ids, h.data(), (size_t) n * 4, hipMemcpyHostToDevice);
-		for (int wm = 0; wm < 2; ++wm) {
+		for (int wm = 0; wm < 2; ++wm) for (int bs : { 256, 512, 1024 }) {
+			if (bs != 512 && run != 1) continue;          // the workgroup-size comparison for random ids only
 			float best = 1e30f;
 			for (int rep = 0; rep < 3; ++rep) {
 				hipEventRecord(e0);
-				hipLaunchKernelGGL(k_rw, dim3(n / 512), dim3(512), 0, 0, recs, ids, n, wm, dst);
+				if (bs == 256) hipLaunchKernelGGL(k_rw<256>, dim3(n / 256), dim3(256), 0, 0, recs, ids, n, wm, dst);
+				else if (bs == 512) hipLaunchKernelGGL(k_rw<512>, dim3(n / 512), dim3(512), 0, 0, recs, ids, n, wm, dst);
+				else hipLaunchKernelGGL(k_rw<1024>, dim3(n / 1024), dim3(1024), 0, 0, recs, ids, n, wm, dst);
 				hipEventRecord(e1); hipEventSynchronize(e1);
 				float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
 			}
-			printf("runs of %3d consecutive records, write %-10s: %7.2f ms  %6.0f GB/s (read + write)  %.3f ns per record\n",
-			       run, wm == 0 ? "home" : "sequential", best, 2.0 * n * 128 / (best * 1e-3) / 1e9, best * 1e6 / n);
+			printf("runs of %3d consecutive records, write %-10s, workgroups of %4d: %7.2f ms  %6.0f GB/s (read + write)  %.3f ns per record\n",
+			       run, wm == 0 ? "home" : "sequential", bs, best, 2.0 * n * 128 / (best * 1e-3) / 1e9, best * 1e6 / n);
 		}
 	}
 	return 0;
