@@ -285,7 +285,7 @@ def test_overflow_retry_and_tuning_knobs_do_not_change_results(gpu_lib, mts, orc
     assert np.array_equal(it.film().view(np.uint32), ref.view(np.uint32))
     it.set_tuning(test_retry=0, sync_free=-1)
     for knobs in (dict(refill_min=8), dict(desc_min=1, leaf_min=1), dict(batch=16), dict(dyn_div=1), dict(refill_min=64, batch=64),
-                  dict(sync_free=1), dict(sync_free=0)):
+                  dict(sync_free=1), dict(sync_free=1, shade_fused=0), dict(sync_free=0, shade_fused=1)):
         it.set_tuning(**knobs)
         it.clear_film(); assert it.render()
         assert it.stats()["bin_overflow_retries"] == 0

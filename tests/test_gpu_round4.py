@@ -102,3 +102,19 @@ def test_bench_over_two_gpus_uses_the_nccl_backend(gpu_lib, mts, tmp_path):
     assert it.render()
     assert np.array_equal(np.load(out).view(np.uint32), it.film().view(np.uint32))
     assert np.array_equal(np.load(gout).view(np.uint32), it.film().view(np.uint32))
+
+
+def test_group_tuning_reaches_every_member(gpu_lib, mts):
+    """mtsgpu_group_set_tuning forwards a knob to all members (the film does not change), refuses an unknown one, and keeps
+    its own test knob (`rccl_fail`) to itself"""
+    sd = mts.scenes.cornell_c1()
+    scene = mts.Scene(sd); cam = mts.PerspectiveCamera.for_description(sd, 64, 48)
+    g = mts.DeviceGroup([0, 0], maxDepth=4)
+    g.preprocess(scene, cam, sampler="independent", sampleCount=4)
+    assert g.render()
+    ref = g.film()
+    g.set_tuning(sync_free=0, refill_min=8)
+    assert g.render() and np.array_equal(g.film().view(np.uint32), ref.view(np.uint32))
+    g.set_tuning(rccl_fail=1); g.set_tuning(rccl_fail=0)
+    with pytest.raises(mts.MtsGpuError):
+        g.set_tuning(no_such_knob=1)
