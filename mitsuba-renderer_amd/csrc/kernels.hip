@@ -597,10 +597,6 @@ __device__ __forceinline__ bool sphere_occludes(V3 center, float radius, V3 ro, 
 #ifndef MG_TOP_PAIRS
 #define MG_TOP_PAIRS (MG_TRACE_BLOCK >= 512 ? 1024 : 128)
 #endif
-#ifndef MG_IVL
-#define MG_IVL 1
-#endif
-constexpr float kIvlC = 0x1p-21f;             // 8 units of the last place: the relative part of the descent step's decision margin
 constexpr int kStackLDS = MG_STACK_LDS;       // stack levels kept in LDS (deeper ones spill: 1 push in 10^4 at 12 levels on C3)
 // The first 2 * kTopPairs device nodes -- the root and the sibling pairs below it in breadth-first order, see
 // mtsgpu_upload_scene -- are copied into LDS by every workgroup: each ray's descent from the root starts with 8-9
@@ -649,10 +645,6 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 		if (COUNT) { g_node++; rec_add(kReqNode, i); }
 		return sc.nodes[i];
 	};
-	auto node_quiet = [&](uint32_t i) -> uint2 {         // outside the request counters
-		if (kTopPairs && i < 2u * kTopPairs) return reinterpret_cast<const uint2 *>(s_top)[i];
-		return sc.nodes[i];
-	};
 	auto load_pair = [&](uint32_t left) -> uint4 {
 		if (kTopPairs && left < 2u * kTopPairs) { if (COUNT) l_pair++; return s_top[left >> 1]; }
 		if (COUNT) { g_pair++; rec_add(kReqPair, left >> 1); }
@@ -690,13 +682,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 	uint32_t id = 0;
 	float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, rx = 1, ry = 1, rz = 1;
 	float mint = 0, maxt = 0, tmax0 = 0;
-#if MG_IVL
-	// stack[enPt] and stack[exPt] as (t, reference of the node whose split plane the point lies on); see the descent step
-	float t_en = 0, ex_t = 0, cT = 0;
-	uint32_t en_ref = kSentinel;
-#else
 	float enx = 0, eny = 0, enz = 0, exx = 0, exy = 0, exz = 0, ex_t = 0;   // stack[enPt].p, stack[exPt].p, stack[exPt].t
-#endif
 	int sp = 0;
 	// the current exit point: ex_node = its far child, ex_ref = its stack word (parent index * 2 + "far child is the right one")
 	uint32_t ex_node = kNullNode, ex_ref = kSentinel, cur = 0;
@@ -837,29 +823,9 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						for (int i = 0; i < 8; ++i) s_mbox[i][tid] = 0xFFFFFFFFu;
 					}
 					// entry point (stack[enPt]) and current exit point (stack[exPt]) in registers
-#if MG_IVL
-					t_en = mint; en_ref = kSentinel;       // stack[enPt].p = ray(mint): no coordinate is overwritten by a split plane
-					tmax0 = maxt;
-					ex_t = maxt;
-					{
-						// the constant part of the descent step's decision margin (see there)
-						float T = 0; bool exactOnly = false;
-						#pragma unroll
-						for (int i = 0; i < 3; ++i) {
-							const float ad = fabsf(sel3(dx, dy, dz, i));
-							if (ad != 0) {
-								if (!(ad >= 0x1p-60f)) exactOnly = true;
-								const float orv = fabsf(sel3(ox, oy, oz, i) * sel3(rx, ry, rz, i));
-								if (!(orv <= T)) T = orv;
-							}
-						}
-						cT = exactOnly ? MG_INF : kIvlC * (T + fabsf(mint) + fabsf(maxt)) + 0x1p-80f;
-					}
-#else
 					enx = ox + mint * dx; eny = oy + mint * dy; enz = oz + mint * dz;      // stack[enPt].p = ray(mint)
 					tmax0 = maxt;
 					ex_t = maxt; exx = ox + maxt * dx; exy = oy + maxt * dy; exz = oz + maxt * dz;
-#endif
 					ex_node = kNullNode; ex_ref = kSentinel;
 					sp = 0; cur = 0; e_cont = kNoPrim;
 					nd = load_node(0u);
@@ -886,44 +852,16 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					const uint4 pair = load_pair(left);
 					if (COUNT) c_inner++;
 					MG_WSLOT(w_inner);
-#if MG_IVL
-					const float o_a = sel3(ox, oy, oz, axis), r_a = sel3(rx, ry, rz, axis);
-					const float tau = (split - o_a) * r_a;          // distToSplit (sahkdtree3.h:233)
-					const float margin = __builtin_fmaf(fabsf(tau), kIvlC, cT);
-					const bool amb = !(fabsf(t_en - tau) > margin) || !(fabsf(ex_t - tau) > margin);
-#else
 					const float pen = sel3(enx, eny, enz, axis), pex = sel3(exx, exy, exz, axis);
 					const bool A = pen <= split, B = pex <= split, C = pen == split, D = split < pex;
-#endif
 					//   A &&  B        : left only            (N1-N3, P5, Z2, Z3)
 					//   A && !B &&  C  : right only           (Z1)
 					//   A && !B && !C  : near left, far right (N4)  -> push
 					//  !A &&  D        : right only           (P1-P3, N5)
 					//  !A && !D        : near right, far left (P4)  -> push
 					// the case logic is done on wave masks (SALU) to keep it off the vector pipe
-#if MG_IVL
-					const uint64_t mNeg = __builtin_amdgcn_ballot_w64(r_a < 0);
-					uint64_t mA = __builtin_amdgcn_ballot_w64(t_en < tau) ^ mNeg, mB = __builtin_amdgcn_ballot_w64(ex_t < tau) ^ mNeg;
-					uint64_t mC = 0, mD = ~mB;
-					const uint64_t mAmb = (MG_IVL == 2 && MODE == 1) ? 0ull : __builtin_amdgcn_ballot_w64(amb);      // 2: timing bound only (inexact)
-					if (mAmb != 0) {
-						// rare (1 step in 10^4): the reference's own comparisons for the lanes whose margin is too small
-						bool eA = false, eB = false, eC = false, eD = false;
-						if (amb) {
-							const float d_a = sel3(dx, dy, dz, axis);
-							float pen = o_a + t_en * d_a, pex = o_a + ex_t * d_a;       // ray(t)[axis]
-							if (en_ref != kSentinel) { const uint2 pn = node_quiet(en_ref >> 1); if ((int) (pn.x & 3u) == axis) pen = __uint_as_float(pn.y); }
-							if (ex_ref != kSentinel) { const uint2 pn = node_quiet(ex_ref >> 1); if ((int) (pn.x & 3u) == axis) pex = __uint_as_float(pn.y); }
-							eA = pen <= split; eB = pex <= split; eC = pen == split; eD = split < pex;
-						}
-						mA = (mA & ~mAmb) | __builtin_amdgcn_ballot_w64(eA); mB = (mB & ~mAmb) | __builtin_amdgcn_ballot_w64(eB);
-						mC = __builtin_amdgcn_ballot_w64(eC); mD = (mD & ~mAmb) | __builtin_amdgcn_ballot_w64(eD);
-					}
-					const bool A = __builtin_amdgcn_inverse_ballot_w64(mA);
-#else
 					const uint64_t mA = __builtin_amdgcn_ballot_w64(A), mB = __builtin_amdgcn_ballot_w64(B);
 					const uint64_t mC = __builtin_amdgcn_ballot_w64(C), mD = __builtin_amdgcn_ballot_w64(D);
-#endif
 					const bool side1 = __builtin_amdgcn_inverse_ballot_w64(~mA | (~mB & mC));   // go to the right child now
 					const bool push = __builtin_amdgcn_inverse_ballot_w64((mA & ~mB & ~mC) | (~mA & ~mD));
 					const uint32_t side = side1 ? 1u : 0u;
@@ -933,17 +871,11 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						else { q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid] = ex_ref; if (COUNT) g_spill++; }
 						++sp;
 						const uint32_t farRight = A ? 1u : 0u;
-#if MG_IVL
-						ex_ref = (cur << 1) | farRight;
-						ex_t = tau;
-						cT = margin;        // >= cT + 8u |tau|: the margin of later steps covers the rounding of ray(tau) too
-#else
 						const float distToSplit = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
 						ex_ref = (cur << 1) | farRight;
 						ex_t = distToSplit;
 						const float px = ox + distToSplit * dx, py = oy + distToSplit * dy, pz = oz + distToSplit * dz;
 						exx = (axis == 0) ? split : px; exy = (axis == 1) ? split : py; exz = (axis == 2) ? split : pz;   // selects, not branches
-#endif
 						ex_node = left + farRight;
 					}
 					cur = left + side;
@@ -1043,11 +975,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				else if (ex_t > maxt) finished = true;
 				else {
 					// --- pop: the exit point becomes the entry point ---
-#if MG_IVL
-					t_en = ex_t; en_ref = ex_ref;
-#else
 					enx = exx; eny = exy; enz = exz;
-#endif
 					cur = ex_node;
 					if (cur == kNullNode) {
 						finished = true;
@@ -1056,11 +984,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						nd = load_node(cur);         // in flight together with the parent's node below
 						const uint32_t ref = (sp < kStackLDS) ? s_stack[sp][tid] : q.spill[(size_t) (sp - kStackLDS) * q.spill_stride + gtid];
 						if (ref == kSentinel) {
-#if MG_IVL
-							ex_t = tmax0;
-#else
 							ex_t = tmax0; exx = ox + tmax0 * dx; exy = oy + tmax0 * dy; exz = oz + tmax0 * dz;
-#endif
 							ex_node = kNullNode; ex_ref = kSentinel;
 						} else {
 							// the exit point is a function of (parent node, ray): rebuilt with the reference's formulas (sahkdtree3.h:233,248-249)
@@ -1069,10 +993,8 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 							const float split = __uint_as_float(pn.y);
 							ex_node = (pn.x >> 2) + (ref & 1u);
 							ex_t = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
-#if !MG_IVL
 							const float px = ox + ex_t * dx, py = oy + ex_t * dy, pz = oz + ex_t * dz;
 							exx = (axis == 0) ? split : px; exy = (axis == 1) ? split : py; exz = (axis == 2) ? split : pz;
-#endif
 							ex_ref = ref;
 						}
 					}
