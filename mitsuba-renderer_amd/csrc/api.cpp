@@ -147,6 +147,13 @@ template <typename T> int ensureBuf(mtsgpu_ctx *c, T **p, size_t *cap, size_t ne
 	return 0;
 }
 
+// what launch_ld_tables needs besides the tables: one stream word per slot and, above 512 samples per pixel, the scratch
+// copy the tables are shuffled in
+int ensureTableWork(mtsgpu_ctx *c, size_t nSlots, uint32_t spp) {
+	int rc = ensureBuf(c, &c->ldState, &c->ldStateCap, nSlots); if (rc) return rc;
+	return ensureBuf(c, &c->ldScratch, &c->ldScratchCap, ld_table_scratch_entries((uint32_t) nSlots, spp, c->ldDepth));
+}
+
 DConfig makeConfig(const mtsgpu_ctx *c, bool slotPerPath) {
 	DConfig cfg{};
 	std::memcpy(cfg.r2c, c->cam.raster_to_camera, sizeof(cfg.r2c));
@@ -632,6 +639,7 @@ void mtsgpu_destroy(mtsgpu_ctx *c) {
 	if (c->ldScr) (void) hipFree(c->ldScr);
 	if (c->ldPerm) (void) hipFree(c->ldPerm);
 	if (c->ldState) (void) hipFree(c->ldState);
+	if (c->ldScratch) (void) hipFree(c->ldScratch);
 	if (c->arrScr) (void) hipFree(c->arrScr);
 	if (c->arrPerm) (void) hipFree(c->arrPerm);
 	if (c->arrPts) (void) hipFree(c->arrPts);
@@ -1123,6 +1131,7 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 	if (samplerHasTables(c)) {
 		rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, slotsPerPass * 3 * c->ldDepth); if (rc) return rc;
 		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, slotsPerPass * 2 * c->ldDepth * spp); if (rc) return rc;
+		rc = ensureTableWork(c, slotsPerPass, spp); if (rc) return rc;
 	}
 	rc = ensureSampleArrays(c, slotsPerPass, slotsPerPass * spp); if (rc) return rc;
 	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, kNumTraceCounts * sizeof(unsigned long long), c->stream));
@@ -1165,7 +1174,7 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 		}
 		const uint32_t nPaths = nSlots * spp;
 		if (samplerHasTables(c)) {
-			launch_ld_tables(c->stream, cfg, c->pixelList + base, nSlots, c->ldScr, c->ldPerm, cfg.arr_n ? c->ldState : nullptr);
+			launch_ld_tables(c->stream, cfg, c->pixelList + base, nSlots, c->ldScr, c->ldPerm, c->ldState, c->ldScratch);
 			launch_sample_arrays(c->stream, cfg, nSlots, c->ldState);
 		}
 		launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList + base, nSlots, nullptr, nPaths, c->queueA);
@@ -1334,12 +1343,13 @@ int mtsgpu_ld_tables(mtsgpu_ctx *c, uint32_t pixel_key, float *out1d, float *out
 	const int depth = c->ldDepth;
 	int rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, (size_t) 3 * depth); if (rc) return rc;
 	rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, (size_t) 2 * depth * spp); if (rc) return rc;
+	rc = ensureTableWork(c, 1, spp); if (rc) return rc;
 	c->renderListValid = false;
 	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, 1); if (rc) return rc;
 	HIPCHK(c, hipMemcpyAsync(c->pixelList, &pixel_key, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	DConfig cfg{};
 	cfg.spp = spp; cfg.ld_depth = depth; cfg.seed = c->seed; cfg.sampler_kind = 1;
-	launch_ld_tables(c->stream, cfg, c->pixelList, 1, c->ldScr, c->ldPerm, nullptr);
+	launch_ld_tables(c->stream, cfg, c->pixelList, 1, c->ldScr, c->ldPerm, c->ldState, c->ldScratch);
 	HIPCHK(c, hipGetLastError());
 	std::vector<uint32_t> scr((size_t) 3 * depth);
 	std::vector<uint16_t> perm((size_t) 2 * depth * spp);
@@ -1387,13 +1397,14 @@ int mtsgpu_sampler_values(mtsgpu_ctx *c, uint32_t pixel_key, uint32_t sample_ind
 	if (samplerHasTables(c)) {
 		rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, (size_t) 3 * c->ldDepth); if (rc) return rc;
 		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, (size_t) 2 * c->ldDepth * spp); if (rc) return rc;
+		rc = ensureTableWork(c, 1, spp); if (rc) return rc;
 	}
 	const int integratorSaved = c->integrator;
 	c->integrator = 0;                               // no sample arrays: the plain next1D / next2D sequence
 	const DConfig cfg = makeConfig(c, true);
 	c->integrator = integratorSaved;
 	if (samplerHasTables(c))
-		launch_ld_tables(c->stream, cfg, c->pixelList, 1, c->ldScr, c->ldPerm, nullptr);
+		launch_ld_tables(c->stream, cfg, c->pixelList, 1, c->ldScr, c->ldPerm, c->ldState, c->ldScratch);
 	float *dOut = nullptr;
 	const size_t nOut = (size_t) n * (two_d ? 2 : 1);
 	HIPCHK(c, hipMalloc((void **) &dOut, nOut * sizeof(float)));
@@ -1451,11 +1462,12 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 	if (samplerHasTables(c)) {
 		rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, (size_t) n * 3 * c->ldDepth); if (rc) return rc;
 		rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, (size_t) n * 2 * c->ldDepth * spp); if (rc) return rc;
+		rc = ensureTableWork(c, n, spp); if (rc) return rc;
 	}
 	rc = ensureSampleArrays(c, n, n); if (rc) return rc;
 	const DConfig cfg = makeConfig(c, true);
 	if (samplerHasTables(c)) {
-		launch_ld_tables(c->stream, cfg, c->pixelList, n, c->ldScr, c->ldPerm, cfg.arr_n ? c->ldState : nullptr);
+		launch_ld_tables(c->stream, cfg, c->pixelList, n, c->ldScr, c->ldPerm, c->ldState, c->ldScratch);
 		launch_sample_arrays(c->stream, cfg, n, c->ldState);
 	}
 	launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList, n, c->explicitSamples, n, c->queueA);

@@ -55,6 +55,7 @@ struct mtsgpu_ctx {
 	std::vector<uint32_t> renderPixels; std::vector<mg::TileMeta> renderTiles;
 	std::vector<long long> renderKey; bool renderListValid = false;
 	uint32_t *ldScr = nullptr; uint16_t *ldPerm = nullptr; size_t ldScrCap = 0, ldPermCap = 0;
+	uint16_t *ldScratch = nullptr; size_t ldScratchCap = 0;      // the tables of a pass while they are shuffled (kernels.h)
 	// Sampler::request2DArray arrays of the direct integrator (per pass, like the tables above)
 	unsigned long long *ldState = nullptr; size_t ldStateCap = 0;
 	uint32_t *arrScr = nullptr; uint16_t *arrPerm = nullptr; float2 *arrPts = nullptr; size_t arrScrCap = 0, arrPermCap = 0, arrPtsCap = 0;

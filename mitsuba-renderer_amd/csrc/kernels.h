@@ -261,9 +261,11 @@ __host__ __device__ inline TracePlan trace_plan(uint32_t n, int mode, const DQue
 }
 
 // --- launchers (kernels.hip) -------------------------------------------------
-// state_out (may be NULL): where the generate() stream of each slot stands after its tables
+// state (one word per slot): where the generate() stream of each slot stands after its tables; scratch: ld_table_scratch_entries()
+// entries (0 up to 512 samples per pixel) in which the tables are shuffled
+size_t ld_table_scratch_entries(uint32_t n_slots, uint32_t spp, int depth);
 void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_keys, uint32_t n_slots,
-                      uint32_t *scr, uint16_t *perm, unsigned long long *state_out);
+                      uint32_t *scr, uint16_t *perm, unsigned long long *state, uint16_t *scratch);
 // the requested sample arrays of the table-based samplers (ldsampler.cpp:152-153, stratified.cpp:136-138), continuing
 // that stream; writes cfg.arr_scr / arr_perm / arr_pts
 void launch_sample_arrays(hipStream_t s, const DConfig &cfg, uint32_t n_slots, const unsigned long long *state_in);

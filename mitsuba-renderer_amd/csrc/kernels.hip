@@ -72,46 +72,145 @@ __global__ void k_iota(uint32_t *p, uint32_t n) {
 
 // ===========================================================================
 // K0: LowDiscrepancySampler::generate() per pixel (src/samplers/ldsampler.cpp:125-158)
-// with the keyed stream in place of Random.  One lane per pixel slot; the
-// Sattolo-style shuffle of Random::shuffle (random.h:145-148) is sequential.
-// The tables hold the permutation; values are f(perm[j]) at lookup time.
+// with the keyed stream in place of Random.  The tables hold the permutation;
+// values are f(perm[j]) at lookup time.
+//
+// Random::shuffle (random.h:145-148) is `for it = n - 1 .. 1: swap(p[it], p[nextSize(it)])`, and
+// Random::nextSize (random.cpp:196-215) rejects: both the stream position of a step and the array
+// it works on depend on all steps before it.  Above 512 samples per pixel (below, the tables of 64
+// pixels fit the LDS of one wave: k_ld_tables_lds) the two chains are taken apart:
+//   k_ld_scout   one WAVE per pixel walks the pixel's stream 64 draws at a time -- the stream is
+//                counter based, lane i evaluates draw number base + i -- and finds out which draws
+//                the steps accept; it leaves the partner index other[it] of every step of every
+//                table (in the table's own row), the scrambles and the final stream position;
+//   k_ld_apply   one lane per (pixel, table) applies the swaps, 8 steps at a time with their 16
+//                loads in flight together, in a scratch copy where the 64 pixels of a wave are
+//                interleaved ([entry][lane]: p[it] is one line per access, not 64), and transposes
+//                the result through LDS into the per-pixel row.
+// C4 pass (18 k pixels x 4096 spp): scout 0.7 ms, apply 11.5 ms; a lane per pixel doing both took 15-21 ms
+// in every memory layout tried.  What bounds the apply is one random 2-byte read and one random 2-byte
+// write per step, each a whole line across the XCD's link (profiles/r05m_exp_sampler_tables_4096spp.txt).
 // ===========================================================================
-__global__ void k_ld_tables(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_slots,
-                            uint32_t *scr, uint16_t *perm, unsigned long long *state_out) {
-	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_ld_scout(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_slots,
+                                                  uint32_t *scr, uint16_t *others, unsigned long long *state) {
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 6);      // one wave per sampler slot
 	if (slot >= n_slots)
 		return;
 	const uint32_t spp = cfg.spp;
 	const int depth = cfg.ld_depth;
 	const bool ld = cfg.sampler_kind == 1;     // 4: StratifiedSampler::generate (stratified.cpp:121-141), permutations only
-	uint64_t st = keyedInit(cfg.seed, pixel_keys[slot], 0);
+	constexpr uint64_t kGamma = 0x9E3779B97F4A7C15ULL;           // keyedNext: state += gamma; return sm64mix(state)
+	const uint64_t st0 = keyedInit(cfg.seed, pixel_keys[slot], 0);
+	uint64_t drawn = 0;                        // draws consumed so far (wave-uniform): draw number d is sm64mix(st0 + (d + 1) gamma)
 	uint32_t *s = scr + (size_t) slot * 3 * depth;
-	uint16_t *pbase = perm + (size_t) slot * 2 * depth * spp;
-	for (int i = 0; i < depth; ++i) {
-		// generate1D
-		uint16_t *p = pbase + (size_t) (2 * i) * spp;
-		if (ld) s[i * 3 + 0] = (uint32_t) (keyedNext(st) & 0xFFFFFFFFull);     // the stratified sampler draws no scrambles
-		for (uint32_t k = 0; k < spp; ++k) p[k] = (uint16_t) k;
-		for (uint32_t it = spp - 1; it > 0; --it) {
-			uint32_t other = (uint32_t) keyedNextSize(st, it);
-			uint16_t a = p[it], b = p[other];
-			p[it] = b; p[other] = a;
-		}
-		// generate2D: one 64-bit draw, dword[0] = low half, dword[1] = high half
-		p = pbase + (size_t) (2 * i + 1) * spp;
+	for (int arr = 0; arr < 2 * depth; ++arr) {
 		if (ld) {
-			uint64_t q = keyedNext(st);
-			s[i * 3 + 1] = (uint32_t) (q & 0xFFFFFFFFull);
-			s[i * 3 + 2] = (uint32_t) (q >> 32);
+			// generate1D: the low half of one draw; generate2D: one 64-bit draw, dword[0] = low half, dword[1] = high half
+			const uint64_t q = sm64mix(st0 + (drawn + 1) * kGamma);
+			++drawn;
+			if (lane == 0) {
+				const int i = arr >> 1;
+				if ((arr & 1) == 0) {
+					s[i * 3 + 0] = (uint32_t) (q & 0xFFFFFFFFull);
+				} else {
+					s[i * 3 + 1] = (uint32_t) (q & 0xFFFFFFFFull);
+					s[i * 3 + 2] = (uint32_t) (q >> 32);
+				}
+			}
 		}
-		for (uint32_t k = 0; k < spp; ++k) p[k] = (uint16_t) k;
-		for (uint32_t it = spp - 1; it > 0; --it) {
-			uint32_t other = (uint32_t) keyedNextSize(st, it);
-			uint16_t a = p[it], b = p[other];
-			p[it] = b; p[other] = a;
+		uint16_t *row = others + ((size_t) slot * 2 * depth + arr) * spp;
+		uint32_t it = spp - 1;
+		while (it > 0) {
+			// the steps it, it - 1, .. down to the highest bit of `it` share nextSize's bit mask
+			const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(it), lo = (mask >> 1) + 1u;
+			const uint32_t v = (uint32_t) sm64mix(st0 + (drawn + lane + 1) * kGamma) & mask;
+			// draw i is accepted by the step it stands at, it - A_i, iff v_i < it - A_i, A_i = accepted draws before it.  A
+			// fixed point of that recurrence is its (unique) sequential solution; every sweep settles at least one more lane
+			uint64_t acc = __builtin_amdgcn_ballot_w64(v + lane < it);             // accepted whatever happened before
+			uint32_t A;
+			while (true) {
+				A = __builtin_amdgcn_mbcnt_hi((uint32_t) (acc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) acc, 0u));
+				const uint64_t acc2 = __builtin_amdgcn_ballot_w64(v + A < it);
+				if (acc2 == acc) break;
+				acc = acc2;
+			}
+			const bool a = v + A < it;
+			const uint32_t total = (uint32_t) __popcll(acc), avail = it - lo + 1u;
+			uint32_t consumed = 64u, steps = total;
+			bool mine = a;
+			if (total >= avail) {
+				// the run of steps with this mask ends inside the chunk: the draws after its last accepted one belong to the next mask
+				const uint64_t last = __builtin_amdgcn_ballot_w64(a && A == avail - 1u);
+				const uint32_t L = (uint32_t) __builtin_ctzll(last);
+				consumed = L + 1u; steps = avail;
+				mine = a && lane <= L;
+			}
+			if (mine) row[it - A] = (uint16_t) v;
+			it -= steps;
+			drawn += consumed;
 		}
 	}
-	if (state_out) state_out[slot] = st;
+	if (lane == 0) state[slot] = st0 + drawn * kGamma;
+}
+
+__global__ __launch_bounds__(64) void k_ld_apply(DConfig cfg, uint32_t n_slots, uint32_t block0, uint16_t *perm, uint16_t *scratch) {
+	__shared__ uint16_t s_tile[64][66];        // [entry][lane], padded: the transposed reads spread over the banks
+	const int nArr = 2 * cfg.ld_depth;
+	const uint32_t blk = block0 + blockIdx.x;  // (group of 64 slots, table)
+	const uint32_t group = blk / (uint32_t) nArr;
+	const int arr = (int) (blk - group * (uint32_t) nArr);
+	const uint32_t lane = threadIdx.x, slot0 = group * 64u, slot = slot0 + lane;
+	const uint32_t spp = cfg.spp;
+	uint16_t *S = scratch + (size_t) blockIdx.x * 64u * spp;
+	if (slot < n_slots) {
+		const uint16_t *row = perm + ((size_t) slot * nArr + arr) * spp;       // other[it], left by k_ld_scout
+		for (uint32_t k = 0; k < spp; ++k) S[(size_t) k * 64u + lane] = (uint16_t) k;
+		// Steps of a batch that touch the same entry -- other_j == other_k, or other_j == it_k for j < k; the it are distinct
+		// and other_k < it_k -- are resolved in registers in step order, and the stores leave in step order, so the array
+		// goes through exactly the states of the sequential loop.
+		constexpr int kBatch = 8;
+		uint32_t it = spp - 1;
+		for (; it >= (uint32_t) kBatch; it -= (uint32_t) kBatch) {          // steps it, it - 1, .., it - kBatch + 1 (all >= 1)
+			uint32_t oth[kBatch];
+			uint16_t va[kBatch], vb[kBatch];
+			#pragma unroll
+			for (int j = 0; j < kBatch; ++j) oth[j] = row[it - (uint32_t) j];
+			#pragma unroll
+			for (int j = 0; j < kBatch; ++j) { va[j] = S[(size_t) (it - (uint32_t) j) * 64u + lane]; vb[j] = S[(size_t) oth[j] * 64u + lane]; }
+			#pragma unroll
+			for (int k = 0; k < kBatch; ++k) {
+				uint16_t a = va[k], b = vb[k];
+				#pragma unroll
+				for (int j = 0; j < k; ++j) {          // vb[j] now holds what step j left at position oth[j]; the latest j wins
+					if (oth[j] == it - (uint32_t) k) a = vb[j];
+					if (oth[j] == oth[k]) b = vb[j];
+				}
+				va[k] = b;            // -> p[it - k]
+				vb[k] = a;            // -> p[oth[k]]
+			}
+			#pragma unroll
+			for (int k = 0; k < kBatch; ++k) { S[(size_t) (it - (uint32_t) k) * 64u + lane] = va[k]; S[(size_t) oth[k] * 64u + lane] = vb[k]; }
+		}
+		for (; it > 0; --it) {
+			const uint32_t other = row[it];
+			uint16_t *pa = S + (size_t) it * 64u + lane, *pb = S + (size_t) other * 64u + lane;
+			const uint16_t a = *pa, b = *pb;
+			*pa = b; *pb = a;
+		}
+	}
+	__syncthreads();           // one wave: orders the lanes' scratch writes (and their reads of `row`) before the transposed pass below
+	const uint32_t rows = (n_slots - slot0 < 64u) ? n_slots - slot0 : 64u;
+	for (uint32_t k0 = 0; k0 < spp; k0 += 64u) {
+		const uint32_t nk = (spp - k0 < 64u) ? spp - k0 : 64u;
+		if (lane < rows)
+			for (uint32_t k = 0; k < nk; ++k) s_tile[k][lane] = S[(size_t) (k0 + k) * 64u + lane];
+		__syncthreads();
+		if (lane < nk)
+			for (uint32_t r = 0; r < rows; ++r)
+				perm[((size_t) (slot0 + r) * nArr + arr) * spp + k0 + lane] = s_tile[lane][r];
+		__syncthreads();
+	}
 }
 
 // Sampler::request2DArray arrays of one pixel (one lane per sampler slot, continuing its generate() stream):
@@ -2586,18 +2685,32 @@ void launch_iota(hipStream_t s, uint32_t *p, uint32_t n) {
 	if (n) hipLaunchKernelGGL(k_iota, dim3(blocks_for(n, 256)), dim3(256), 0, s, p, n);
 }
 
+// The LDS kernel pays while all 64 lanes of a wave shuffle (up to 512 samples per pixel); above that the tables go through
+// k_ld_scout + k_ld_apply and a scratch copy of ld_table_scratch_entries() entries
+static bool ld_tables_sliced(uint32_t spp) { return (size_t) spp * 64 * sizeof(uint16_t) > 64 * 1024; }
+constexpr uint32_t kApplyChunk = 256;
+size_t ld_table_scratch_entries(uint32_t n_slots, uint32_t spp, int depth) {
+	if (!ld_tables_sliced(spp)) return 0;
+	return (size_t) std::min<uint32_t>(kApplyChunk, blocks_for(n_slots, 64) * 2 * (uint32_t) depth) * 64 * spp;
+}
+
+// all tables of n_slots pixels; `state` (one word per slot) receives the pixels' streams after generate()
 void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_keys, uint32_t n_slots,
-                      uint32_t *scr, uint16_t *perm, unsigned long long *state_out) {
+                      uint32_t *scr, uint16_t *perm, unsigned long long *state, uint16_t *scratch) {
 	if (!n_slots) return;
-	// The LDS kernel pays while all 64 lanes of a wave shuffle (up to 512 samples per pixel).  With fewer lanes per wave
-	// (8 at 4096 samples, measured on the C4 frame) the chip holds too few shuffling lanes and the global-memory kernel,
-	// which hides its latency behind 64 lanes per wave, is 6 % faster on the whole frame.
-	const uint32_t lanes = 64;
-	const size_t lds = (size_t) cfg.spp * lanes * sizeof(uint16_t);
-	if (lds <= 64 * 1024)
-		hipLaunchKernelGGL(k_ld_tables_lds, dim3(blocks_for(n_slots, lanes)), dim3(64), lds, s, cfg, pixel_keys, n_slots, lanes, scr, perm, state_out);
-	else
-		hipLaunchKernelGGL(k_ld_tables, dim3(blocks_for(n_slots, 64)), dim3(64), 0, s, cfg, pixel_keys, n_slots, scr, perm, state_out);
+	if (!ld_tables_sliced(cfg.spp)) {
+		const uint32_t lanes = 64;
+		const size_t lds = (size_t) cfg.spp * lanes * sizeof(uint16_t);
+		hipLaunchKernelGGL(k_ld_tables_lds, dim3(blocks_for(n_slots, lanes)), dim3(64), lds, s, cfg, pixel_keys, n_slots, lanes, scr, perm, state);
+	} else {
+		hipLaunchKernelGGL(k_ld_scout, dim3(blocks_for(n_slots, 4)), dim3(256), 0, s, cfg, pixel_keys, n_slots, scr, perm, state);
+		// kApplyChunk (group, table) pairs per launch: the scratch of a launch (128 MB at 4096 spp) stays in the Infinity Cache.
+		// All 1 728 pairs of a C4 pass at once miss it on every swap (15.5 ms per pass); launches of 512 / 256 / 128 / 64
+		// pairs take 13.0 / 11.5 / 14.0 / 20 ms -- below 256 the chip runs out of lanes (profiles/r05m_*)
+		const uint32_t total = blocks_for(n_slots, 64) * 2 * cfg.ld_depth;
+		for (uint32_t b0 = 0; b0 < total; b0 += kApplyChunk)
+			hipLaunchKernelGGL(k_ld_apply, dim3(std::min(kApplyChunk, total - b0)), dim3(64), 0, s, cfg, n_slots, b0, perm, scratch);
+	}
 }
 
 void launch_sample_arrays(hipStream_t s, const DConfig &cfg, uint32_t n_slots, const unsigned long long *state_in) {
