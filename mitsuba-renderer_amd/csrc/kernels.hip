@@ -83,13 +83,14 @@ __global__ void k_iota(uint32_t *p, uint32_t n) {
 //                counter based, lane i evaluates draw number base + i -- and finds out which draws
 //                the steps accept; it leaves the partner index other[it] of every step of every
 //                table (in the table's own row), the scrambles and the final stream position;
-//   k_ld_apply   one lane per (pixel, table) applies the swaps, 8 steps at a time with their 16
+//   k_ld_apply_lds  (up to 16 384 samples) one wave per (pixel, table) applies the swaps in LDS, 64 steps at a time;
+//   k_ld_apply   (above) one lane per (pixel, table) applies the swaps, 8 steps at a time with their 16
 //                loads in flight together, in a scratch copy where the 64 pixels of a wave are
 //                interleaved ([entry][lane]: p[it] is one line per access, not 64), and transposes
 //                the result through LDS into the per-pixel row.
-// C4 pass (18 k pixels x 4096 spp): scout 0.7 ms, apply 11.5 ms; a lane per pixel doing both took 15-21 ms
-// in every memory layout tried.  What bounds the apply is one random 2-byte read and one random 2-byte
-// write per step, each a whole line across the XCD's link (profiles/r05m_exp_sampler_tables_4096spp.txt).
+// C4 pass (18 k pixels x 4096 spp): scout 0.7 ms, apply 2.3 ms in LDS (11.5 ms in memory: one random 2-byte read
+// and one random 2-byte write per step, each a whole line across the XCD's link); a lane per pixel doing everything
+// took 15-21 ms in every memory layout tried (profiles/r05m_exp_sampler_tables_4096spp.txt).
 // ===========================================================================
 __global__ __launch_bounds__(256) void k_ld_scout(DConfig cfg, const uint32_t *pixel_keys, uint32_t n_slots,
                                                   uint32_t *scr, uint16_t *others, unsigned long long *state) {
@@ -211,6 +212,50 @@ __global__ __launch_bounds__(64) void k_ld_apply(DConfig cfg, uint32_t n_slots, 
 				perm[((size_t) (slot0 + r) * nArr + arr) * spp + k0 + lane] = s_tile[lane][r];
 		__syncthreads();
 	}
+}
+
+// The same for tables that fit LDS next to a claim array (up to 16 384 samples per pixel): one WAVE per (pixel, table).
+// Lane l of a batch takes step it - l: positions it - l and o_l = other[it - l].  It depends on an earlier lane j < l only
+// if o_j == o_l or o_j == it - l (the `it` positions are distinct and o_l < it - l < it - j), which a claim array finds --
+// claim[x] = lowest lane whose partner is x, by an LDS atomic minimum; 2048 slots, positions 2048 apart share one: a false
+// conflict only moves a lane to the ordered phase.  Lanes without such a j swap at once (they share no position with any
+// earlier lane, so their swaps commute with everything before them), the others follow in lane order: about 4096 / it lanes
+// of 64.  Every swap is an LDS access: no line crosses the XCD's link (2.3 ms per C4 pass against 11.5 for k_ld_apply).
+constexpr uint32_t kClaimSlots = 2048;
+__global__ __launch_bounds__(64) void k_ld_apply_lds(DConfig cfg, uint32_t n_tables, uint16_t *perm) {
+	extern __shared__ uint32_t s_apply[];
+	uint32_t *claim = s_apply;                                                    // [kClaimSlots]
+	uint16_t *p = reinterpret_cast<uint16_t *>(s_apply + kClaimSlots);            // [spp]
+	const uint32_t spp = cfg.spp, lane = threadIdx.x;
+	if (blockIdx.x >= n_tables) return;
+	uint16_t *row = perm + (size_t) blockIdx.x * spp;      // table (slot, arr) = row slot * 2 depth + arr: other[] in, permutation out
+	for (uint32_t k = lane; k < spp; k += 64u) p[k] = (uint16_t) k;
+	uint32_t it0 = spp - 1;
+	uint32_t oNext = (lane < it0) ? row[it0 - lane] : 0u;                       // steps it0 - lane >= 1
+	__syncthreads();
+	while (it0 >= 1u) {
+		const uint32_t nb = it0 < 64u ? it0 : 64u;
+		const bool active = lane < nb;
+		const uint32_t myIt = it0 - lane, o = oNext;
+		const uint32_t itN = it0 - nb;                                             // the batch after this one, requested now
+		oNext = (itN >= 1u && lane < itN) ? row[itN - lane] : 0u;
+		if (active) { claim[o & (kClaimSlots - 1u)] = 0xFFFFFFFFu; claim[myIt & (kClaimSlots - 1u)] = 0xFFFFFFFFu; }
+		__syncthreads();
+		if (active) atomicMin(&claim[o & (kClaimSlots - 1u)], lane);
+		__syncthreads();
+		const bool dep = active && (claim[o & (kClaimSlots - 1u)] < lane || claim[myIt & (kClaimSlots - 1u)] < lane);
+		if (active && !dep) { const uint16_t a = p[myIt], b = p[o]; p[myIt] = b; p[o] = a; }
+		__syncthreads();
+		uint64_t todo = __builtin_amdgcn_ballot_w64(dep);
+		while (todo) {
+			const uint32_t k = (uint32_t) __builtin_ctzll(todo);
+			todo &= todo - 1ull;
+			if (lane == k) { const uint16_t a = p[myIt], b = p[o]; p[myIt] = b; p[o] = a; }
+			__syncthreads();
+		}
+		it0 = itN;
+	}
+	for (uint32_t k = lane; k < spp; k += 64u) row[k] = p[k];
 }
 
 // Sampler::request2DArray arrays of one pixel (one lane per sampler slot, continuing its generate() stream):
@@ -2689,8 +2734,9 @@ void launch_iota(hipStream_t s, uint32_t *p, uint32_t n) {
 // k_ld_scout + k_ld_apply and a scratch copy of ld_table_scratch_entries() entries
 static bool ld_tables_sliced(uint32_t spp) { return (size_t) spp * 64 * sizeof(uint16_t) > 64 * 1024; }
 constexpr uint32_t kApplyChunk = 256;
+constexpr uint32_t kApplyLdsMaxSpp = 16384;          // k_ld_apply_lds: 8 KB of claims + 2 bytes per sample <= 40 KB per wave
 size_t ld_table_scratch_entries(uint32_t n_slots, uint32_t spp, int depth) {
-	if (!ld_tables_sliced(spp)) return 0;
+	if (!ld_tables_sliced(spp) || spp <= kApplyLdsMaxSpp) return 0;
 	return (size_t) std::min<uint32_t>(kApplyChunk, blocks_for(n_slots, 64) * 2 * (uint32_t) depth) * 64 * spp;
 }
 
@@ -2704,6 +2750,11 @@ void launch_ld_tables(hipStream_t s, const DConfig &cfg, const uint32_t *pixel_k
 		hipLaunchKernelGGL(k_ld_tables_lds, dim3(blocks_for(n_slots, lanes)), dim3(64), lds, s, cfg, pixel_keys, n_slots, lanes, scr, perm, state);
 	} else {
 		hipLaunchKernelGGL(k_ld_scout, dim3(blocks_for(n_slots, 4)), dim3(256), 0, s, cfg, pixel_keys, n_slots, scr, perm, state);
+		if (cfg.spp <= kApplyLdsMaxSpp) {
+			const uint32_t nTables = n_slots * 2 * (uint32_t) cfg.ld_depth;
+			hipLaunchKernelGGL(k_ld_apply_lds, dim3(nTables), dim3(64), kClaimSlots * sizeof(uint32_t) + cfg.spp * sizeof(uint16_t), s, cfg, nTables, perm);
+			return;
+		}
 		// kApplyChunk (group, table) pairs per launch: the scratch of a launch (128 MB at 4096 spp) stays in the Infinity Cache.
 		// All 1 728 pairs of a C4 pass at once miss it on every swap (15.5 ms per pass); launches of 512 / 256 / 128 / 64
 		// pairs take 13.0 / 11.5 / 14.0 / 20 ms -- below 256 the chip runs out of lanes (profiles/r05m_*)

@@ -7,11 +7,12 @@ from test_gpu_parity import _setup
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("spp", [1024, 2048, 4096])
+@pytest.mark.parametrize("spp", [1024, 2048, 4096, 32768])
 def test_ld_tables_above_512_samples(gpu_lib, mts, orc, spp):
     """LowDiscrepancySampler::generate() (ldsampler.cpp:125-158) above 512 samples per pixel: one wave per pixel finds the
     draws Random::nextSize accepts (random.cpp:196-215), one lane per table applies the swaps of Random::shuffle
-    (random.h:145-148) eight at a time -- scrambles and permutations equal the oracle's sequential loop"""
+    (random.h:145-148) -- in LDS, a wave per table, up to 16 384 samples; in memory, eight steps at a time, above -- scrambles
+    and permutations equal the oracle's sequential loop"""
     sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "c1", sampler="ldsampler", spp=spp)
     for key in (0, 7, 65535, 123456):
         t1, t2 = it.ld_tables(key, spp, 3)
