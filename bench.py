@@ -227,14 +227,27 @@ def run_group_child(args, world):
         cmd += ["--devices", args.devices]
     if args.dump_group_film:
         cmd += ["--dump-film", args.dump_group_film]
+    # the result line of the ranks must not depend on this child: its output goes to files, it gets 120 s, and a child
+    # that does not die within 5 s of being killed is left behind rather than waited for
+    import tempfile
     try:
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
-        lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
-        if r.returncode == 0 and lines:
-            return json.loads(lines[-1])
-        return {"error": "exit code %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
-    except subprocess.TimeoutExpired:
-        return {"error": "no result within 120 s"}
+        with tempfile.TemporaryFile() as fo, tempfile.TemporaryFile() as fe:
+            p = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe)
+            deadline = time.time() + 120
+            while p.poll() is None and time.time() < deadline:
+                time.sleep(0.1)
+            if p.poll() is None:
+                p.kill()
+                try:
+                    p.wait(timeout=5)
+                except subprocess.TimeoutExpired:
+                    pass
+                return {"error": "no result within 120 s"}
+            fo.seek(0); fe.seek(0)
+            lines = [l for l in fo.read().decode(errors="replace").splitlines() if l.startswith("{")]
+            if p.returncode == 0 and lines:
+                return json.loads(lines[-1])
+            return {"error": "exit code %d: %s" % (p.returncode, fe.read().decode(errors="replace")[-400:])}
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -257,6 +270,7 @@ def main():
     ap.add_argument("--dump-film", default="", help="rank 0 writes the reduced film of the last step to this .npy file")
     ap.add_argument("--group-child", type=int, default=0, help="(internal) time the one-process device group over N GPUs and print its JSON")
     ap.add_argument("--no-group", action="store_true", help="skip the one-process device-group timing")
+    ap.add_argument("--group", action="store_true", help="time the one-process device group with one GPU too (default: only with --gpus > 1)")
     ap.add_argument("--dump-group-film", default="", help="the group child writes its reduced film to this .npy file")
     args = ap.parse_args()
 
@@ -365,7 +379,7 @@ def main():
     counts = it.stats()
     bytes_per_step = algorithmic_bytes(counts)
     it.set_options(max_paths=args.max_paths, count_traversal=False, time_kernels=True)
-    trace_ms = 0.0
+    trace_ms = trace_first_ms = trace_shadow_ms = 0.0
     trace_launches = 0
     shade_ms = 0.0
     kt_steps = 2
@@ -373,7 +387,9 @@ def main():
         step()
         st = it.stats()                     # per-launch HIP-event durations on the library's streams
         trace_ms += st["trace_ms"]; shade_ms += st["shade_ms"]; trace_launches += st["trace_launches"]
+        trace_first_ms += st["trace_first_ms"]; trace_shadow_ms += st["trace_shadow_ms"]
     trace_ms /= kt_steps; shade_ms /= kt_steps; trace_launches /= kt_steps      # per step from here on
+    trace_first_ms /= kt_steps; trace_shadow_ms /= kt_steps
     it.set_options(max_paths=args.max_paths, count_traversal=False, time_kernels=False)
 
     # --- timed region: exactly K steps between barriers ---
@@ -400,17 +416,23 @@ def main():
     if args.dump_film and rank == 0:
         np.save(args.dump_film, film.cpu().numpy())
 
-    # --- replay roof of the closest-hit kernel on a sample of the frame's own rays (untimed; rank 0) ---
-    replay_raw = None
+    # --- the traversal kernels against replays of their own request streams: samples of the frame's own rays, one per class
+    # of launch (untimed; rank 0).  Deep rays first: the camera class generates the last pass's camera rays again. ---
+    replay_raw = {}
     replay_note = None
     r_stride = 1
     if rank == 0:
         try:
-            avail = W * H * spp_total // world
+            avail = min(W * H * spp_total // world, 72 << 20)    # paths of one pass
             r_stride = 8 if avail >= (32 << 20) else 1
             r_n = min(8 << 20, avail // r_stride)          # 8 M rays: twice the size from which the early loop exits are on
             if r_n >= 65536:
-                replay_raw = it.replay_roof(r_n, r_stride, reps=3)
+                for kind in ("deep", "shadow", "camera"):
+                    n_k = r_n // 4 if kind == "shadow" else r_n      # about a third of the paths queue a shadow ray per bounce
+                    try:
+                        replay_raw[kind] = it.replay_roof(n_k, r_stride, reps=3, kind=kind)
+                    except pkg.MtsGpuError as e:                     # e.g. device-driven passes leave no shadow-queue size behind
+                        replay_raw[kind] = {"error": str(e)}
             else:
                 replay_note = "frame too small for a replay sample"
         except Exception as e:
@@ -454,9 +476,12 @@ def main():
         triad = pkg.hbm_triad_gbs(device)
         gather = pkg.gather_roof(device, 4)
         req_per_step = issued_requests(counts)
-        replay = {"kernel": "k_trace<closest>", "bound": "vector-memory requests: the kernel's own request stream replayed as a pure throughput test "
-                  "(mtsgpu_replay_roof: the same lines in the same per-ray order, one 16-byte load each, eight independent requests in "
-                  "flight per lane, no arithmetic, same grid and LDS footprint)",
+        replay = {"kernel": "k_trace (closest-hit and any-hit launches, by class)",
+                  "what": "each class of traversal launch against a replay of its own request stream (mtsgpu_replay_roof: the same lines in "
+                          "the same per-ray order, one 16-byte load each, eight independent requests in flight per lane, no arithmetic, "
+                          "grid and LDS footprint of the closest-hit kernel).  A throughput test of the memory system on these lines, "
+                          "not a bound: other issue orders may be faster.  Not replayed: queue-id and shadow-ray loads (streamed), "
+                          "stack spills, the extra chunks of sphere primitives",
                   "issued_requests_per_ray": req_per_step / max(rays, 1),
                   "lds_served_requests_per_ray": (counts["req_pair_lds"] + counts["req_node_lds"]) / max(rays, 1),
                   "issued_breakdown_per_ray": {"pairs": counts["req_pair_global"] / max(rays, 1), "pop_nodes": counts["req_node_global"] / max(rays, 1),
@@ -465,15 +490,32 @@ def main():
                   "random_gather_4MiB_G_per_s": gather / 1e9 if gather else None,
                   "note": replay_note}
         if replay_raw:
-            rr = replay_raw
-            replay.update({
-                "sample": "%d closest-hit rays: the last ray of every %dth path of the frame just rendered" % (rr["rays"], r_stride),
-                "sample_requests_per_ray": rr["requests"] / rr["rays"], "sample_truncated_rays": rr["truncated_rays"],
-                "product_ms": rr["product_ms"], "replay_ms": rr["replay_ms"],
-                "achieved": rr["requests"] / (rr["product_ms"] * 1e-3) / 1e9, "peak": rr["requests"] / (rr["replay_ms"] * 1e-3) / 1e9,
-                "unit": "G lane-requests/s", "frac": rr["replay_ms"] / rr["product_ms"],
-                "replay_floor_trace_ms_per_step": trace_ms * rr["replay_ms"] / rr["product_ms"],
-            })
+            samples = {"camera": "camera rays of the last pass, generated again, every %dth; closest-hit kernel in plain 64-ray batches",
+                       "deep": "the last ray of every %dth path of the frame just rendered; closest-hit kernel with material binning",
+                       "shadow": "every %dth slot of the shadow queue as the frame left it; any-hit kernel"}
+            class_ms = {"camera": trace_first_ms, "shadow": trace_shadow_ms, "deep": trace_ms - trace_first_ms - trace_shadow_ms}
+            classes = {}
+            replay_ms_per_step = 0.0
+            complete = True
+            for kind, rr in replay_raw.items():
+                if "error" in rr:
+                    classes[kind] = {"error": rr["error"], "launches_ms_per_step": class_ms[kind]}
+                    complete = False
+                    continue
+                ratio = rr["replay_ms"] / rr["product_ms"]
+                classes[kind] = {"sample": ("%d rays: " % rr["rays"]) + samples[kind] % r_stride,
+                                 "sample_requests_per_ray": rr["requests"] / rr["rays"], "sample_truncated_rays": rr["truncated_rays"],
+                                 "product_ms": rr["product_ms"], "replay_ms": rr["replay_ms"], "replay_ratio": ratio,
+                                 "product_G_requests_per_s": rr["requests"] / (rr["product_ms"] * 1e-3) / 1e9,
+                                 "replay_G_requests_per_s": rr["requests"] / (rr["replay_ms"] * 1e-3) / 1e9,
+                                 "launches_ms_per_step": class_ms[kind],
+                                 "launches": {"camera": "the closest-hit launch of every pass's first bounce", "shadow": "all any-hit launches",
+                                              "deep": "all other closest-hit launches"}[kind]}
+                replay_ms_per_step += class_ms[kind] * ratio
+            replay.update({"classes": classes, "unit": "G lane-requests/s", "trace_ms_per_step": trace_ms,
+                           # sum over the frame's launches of (launch time x the replay ratio measured on its class's sample)
+                           "replay_ms_per_step": replay_ms_per_step if complete else None,
+                           "replay_ratio": replay_ms_per_step / trace_ms if complete and trace_ms > 0 else None})
         sh_bytes = shade_algorithmic_bytes(counts)
         sh_achieved = sh_bytes / (shade_ms * 1e-3) / 1e9 if shade_ms > 0 else 0.0
         out = {
@@ -524,8 +566,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if not args.no_group:
-            # every rank is done (the others exit now): the form the Mitsuba plugin uses, all GPUs behind one process
+        if (world > 1 or args.group) and not args.no_group:
+            # every rank is done (the others exit now): the form the Mitsuba plugin uses, all GPUs behind one process.
+            # With one GPU it is the same frame once more (--group asks for it anyway)
             out["group"] = run_group_child(args, world)
         print(json.dumps(out), flush=True)
 

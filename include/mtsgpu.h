@@ -222,6 +222,9 @@ typedef struct mtsgpu_stats {
 	 * inside the ray's interval), stack words spilled to HBM, 16-byte record heads (n_idx plus the heads fetched again when
 	 * an interrupted leaf is resumed).  Ray and hit: 3 per ray. */
 	uint64_t req_pair_global, req_pair_lds, req_node_global, req_node_lds, req_tail, req_spill, req_head;
+	/* parts of trace_ms: the closest-hit launch of the first bounce of every pass (camera rays), and all any-hit launches;
+	 * the remaining closest-hit launches are trace_ms - trace_first_ms - trace_shadow_ms */
+	double trace_first_ms, trace_shadow_ms;
 } mtsgpu_stats;
 
 typedef struct mtsgpu_ctx mtsgpu_ctx;
@@ -344,18 +347,26 @@ int  mtsgpu_hbm_triad(int device, size_t bytes, int iters, double *gbs);
  * element from `footprint_bytes` (a power of two; 4 MiB sits in the L2 like the upper kd-tree), with k_trace's grid
  * shape.  The traversal kernel is bound by this rate, not by DRAM bytes. */
 int  mtsgpu_gather_roof(int device, size_t footprint_bytes, double *lane_requests_per_s);
-/* Measurement: the REPLAY roof of the closest-hit traversal kernel.  Takes every stride-th of the first n * stride path
- * records in memory -- after mtsgpu_render() each holds the last ray of its path -- traces them once with the counting
- * kernel, which records every vector-memory request of every ray (which sibling pair, node, leaf-record chunk, path-record
- * slot), then times (a) the product kernel and (b) a kernel that re-issues exactly those requests as a pure throughput
- * test: per ray in the recorded order, one 16-byte load per request from the line the traversal asked for, eight
- * independent requests in flight per lane, the same grid shape and LDS footprint, NO arithmetic, no stack, no mailbox, no
- * dependence between the requests -- the time the memory system needs for this set of lines.  (b) / (a) is the fraction of
- * its request roof the kernel runs at.
+/* Measurement: a traversal kernel against a replay of its own request stream.  A sample of n rays of the frame rendered
+ * last is traced once with the counting kernel, which records every vector-memory request of every ray (which sibling
+ * pair, node, leaf-record chunk, path-record slot; not recorded: the loads of queue ids and shadow rays, which are
+ * streamed, stack words spilled to HBM, and the two extra chunks of a sphere primitive); then (a) the product kernel of
+ * that class and (b) a kernel that re-issues exactly those requests are timed: per ray in the recorded order, one 16-byte
+ * load per request from the line the traversal asked for, eight independent requests in flight per lane, the grid shape
+ * and LDS footprint of the closest-hit kernel, NO arithmetic, no stack, no mailbox, no dependence between the requests.
+ * (b) is ONE throughput test of the memory system on this set of lines, not a bound: other issue orders may be faster.
+ * kind selects the sample and the product kernel:
+ *   0  every stride-th of the first n * stride path records -- after mtsgpu_render() each holds the LAST ray of its
+ *      path -- with the closest-hit kernel as the bounces launch it (material binning on);
+ *   1  the camera rays of the pass rendered last, generated again (the path records are overwritten), every stride-th,
+ *      with the closest-hit kernel in the plain 64-ray batches of a first bounce;
+ *   2  every stride-th slot of the shadow queue as the frame left it (slot i holds the ray of the deepest bounce that
+ *      queued more than i shadow rays; host-driven passes only), moved to the front of the queue, with the any-hit
+ *      kernel (which adds the rays' pending terms to the dead path records).
  * out[12]: rays, recorded requests, rays whose list was truncated (256 requests), product ms, replay ms (best of reps),
  * then the issued-request counters of the sample: pairs global / LDS, nodes global / LDS, record heads, tails, spills.
  * Overwrites the hits of the sampled path records; call after the film has been read. */
-int  mtsgpu_replay_roof(mtsgpu_ctx *ctx, uint32_t n, uint32_t stride, int reps, double *out);
+int  mtsgpu_replay_roof(mtsgpu_ctx *ctx, int kind, uint32_t n, uint32_t stride, int reps, double *out);
 
 /* --- standalone kernels exposed for parity tests and the traversal benchmark */
 /* ShapeKDTree::rayIntersect(ray, its) / (ray) on n host rays.

@@ -536,6 +536,7 @@ private:
 struct GPURenderDriver {
 	mtsgpu_group *group;
 	volatile int cancelFlag;
+	std::string reduceNoteLogged;        /* the last fall-back reason that went to the log */
 	std::string devices;
 	uint64_t seed;
 
@@ -649,7 +650,10 @@ struct GPURenderDriver {
 		/* a collective that could not be used is not an error (the films were added up in member order instead), but
 		 * the user should learn why the xGMI reduce did not run */
 		const char *note = mtsgpu_group_reduce_note(group);
-		if (note && note[0]) SLog(EWarn, "libmtsgpu: film reduce fell back to the ordered sum: %s", note);
+		if (note && note[0] && reduceNoteLogged != note) {          /* once per reason, not once per frame */
+			SLog(EWarn, "libmtsgpu: film reduce fell back to the ordered sum: %s", note);
+			reduceNoteLogged = note;
+		}
 
 		/* --- hand the film back as ImageBlocks: every Film plugin (exrfilm, pngfilm, mfilm) and the GUI keep working.
 		 *     The sums of the crop window go out as border-less blocks: the filter has been applied already. --- */

@@ -162,7 +162,7 @@ def lib():
     L.mtsgpu_random_values.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.mtsgpu_bsdf_eval.argtypes = [vp, C.c_uint32, f32p, C.c_int, C.c_uint32, f32p, f32p]
     L.mtsgpu_hbm_triad.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
-    L.mtsgpu_replay_roof.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+    L.mtsgpu_replay_roof.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
     L.mtsgpu_create_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     L.mtsgpu_group_destroy.argtypes = [vp]; L.mtsgpu_group_destroy.restype = None
     L.mtsgpu_group_size.argtypes = [vp]
@@ -390,11 +390,15 @@ class MIPathTracer:
         self._chk(lib().mtsgpu_trace_rays(self._ctx, abi.ptr(r, abi.f32p), r.shape[0], int(shadow), abi.ptr(hits, abi.u32p)), "trace_rays")
         return hits
 
-    def replay_roof(self, n, stride=1, reps=3):
-        """mtsgpu_replay_roof: the request stream of n closest-hit rays (every stride-th path record of the frame rendered
-        last) replayed without arithmetic, next to the product kernel on the same rays"""
+    REPLAY_KINDS = {"deep": 0, "camera": 1, "shadow": 2}
+
+    def replay_roof(self, n, stride=1, reps=3, kind="deep"):
+        """mtsgpu_replay_roof: the request stream of n rays of the frame rendered last replayed without arithmetic, next to
+        the product kernel on the same rays.  kind: "deep" = the last ray of every stride-th path (closest-hit kernel),
+        "camera" = the camera rays of the last pass, generated again (closest-hit kernel, first-bounce launch shape),
+        "shadow" = every stride-th slot of the shadow queue (any-hit kernel)"""
         out = (C.c_double * 12)()
-        self._chk(lib().mtsgpu_replay_roof(self._ctx, int(n), int(stride), int(reps), out), "replay_roof")
+        self._chk(lib().mtsgpu_replay_roof(self._ctx, self.REPLAY_KINDS[kind], int(n), int(stride), int(reps), out), "replay_roof")
         keys = ["rays", "requests", "truncated_rays", "product_ms", "replay_ms", "pair_global", "pair_lds", "node_global", "node_lds",
                 "heads", "tails", "spills"]
         return dict(zip(keys, list(out)))

@@ -62,6 +62,7 @@ class Stats(C.Structure):
         ("trace_union_ms", C.c_double),
         ("req_pair_global", C.c_uint64), ("req_pair_lds", C.c_uint64), ("req_node_global", C.c_uint64), ("req_node_lds", C.c_uint64),
         ("req_tail", C.c_uint64), ("req_spill", C.c_uint64), ("req_head", C.c_uint64),
+        ("trace_first_ms", C.c_double), ("trace_shadow_ms", C.c_double),
     ]
 
     def as_dict(self):

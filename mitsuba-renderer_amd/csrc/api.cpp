@@ -222,6 +222,16 @@ hipEvent_t *nextEventPair(mtsgpu_ctx *c, std::vector<std::pair<hipEvent_t, hipEv
 	return &pool[used++].first;
 }
 
+// an event pair for a traversal launch of class cls (ctx.h: traceEvClass)
+hipEvent_t *nextTraceEvents(mtsgpu_ctx *c, int cls) {
+	hipEvent_t *ev = nextEventPair(c, c->traceEvents, c->traceEvUsed);
+	if (ev) {
+		if (c->traceEvClass.size() < c->traceEvUsed) c->traceEvClass.resize(c->traceEvUsed);
+		c->traceEvClass[c->traceEvUsed - 1] = (unsigned char) cls;
+	}
+	return ev;
+}
+
 int readCounters(mtsgpu_ctx *c) {
 	HIPCHK(c, hipMemcpyAsync(c->hostCounters, c->q.counters, kNumCounters * kCounterStride * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -238,7 +248,7 @@ int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent,
 	for (int attempt = 0; attempt < 2; ++attempt) {
 		if (attempt) HIPCHK(c, hipMemsetAsync(c->q.counters, 0, counterBytes, s));
 		c->q.force_static = attempt ? 1u : 0u;
-		hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
+		hipEvent_t *ev = c->timeKernels ? nextTraceEvents(c, coherent ? 1 : 0) : nullptr;
 		if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
 		launch_trace(s, 0, c->countTraversal && attempt == 0, true, c->dsc, c->paths, c->q, queue, n, coherent);
 		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
@@ -274,7 +284,7 @@ int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatil
 	DConfig cfg = cfg0;
 	const size_t counterBytes = kNumCounters * kCounterStride * sizeof(uint32_t);
 	auto timedTrace = [&](int mode, bool bin, const uint32_t *queue, uint32_t n, bool coherent) -> int {
-		hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
+		hipEvent_t *ev = c->timeKernels ? nextTraceEvents(c, mode == 1 ? 2 : 0) : nullptr;
 		if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
 		launch_trace(s, mode, c->countTraversal, bin, c->dsc, c->paths, c->q, queue, n, coherent);
 		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
@@ -367,9 +377,10 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 			c->q.dev_stats = nullptr; c->q.counters = c->counterSets; c->q.spill = c->spillClosest;
 		}
 	} restore{ c, s2, shadowPending };
-	auto timed = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used, hipStream_t s, int which) -> int {
+	// cls >= 0: a traversal launch of that class (ctx.h: traceEvClass)
+	auto timed = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used, hipStream_t s, int which, int cls = -1) -> int {
 		if (!c->timeKernels) return 0;
-		hipEvent_t *ev = which == 0 ? nextEventPair(c, pool, used) : &pool[used - 1].first;
+		hipEvent_t *ev = which == 0 ? (cls >= 0 ? nextTraceEvents(c, cls) : nextEventPair(c, pool, used)) : &pool[used - 1].first;
 		if (!ev) return fail(c, MTSGPU_EHIP, "hipEventCreate failed");
 		HIPCHK(c, hipEventRecord(ev[which], s));
 		return 0;
@@ -380,7 +391,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 		for (; b < end; ++b) {
 			uint32_t *set = counterSet(c, b), *prev = counterSet(c, b - 1);
 			c->q.counters = set; c->q.next = nxt; c->q.spill = c->spillClosest;
-			int rc = timed(c->traceEvents, c->traceEvUsed, s1, 0); if (rc) return rc;
+			int rc = timed(c->traceEvents, c->traceEvUsed, s1, 0, b == 0 ? 1 : 0); if (rc) return rc;
 			launch_trace(s1, 0, c->countTraversal, true, c->dsc, c->paths, c->q, cur, upper, b == 0,
 			             b == 0 ? nullptr : prev + (size_t) kNextWord);
 			rc = timed(c->traceEvents, c->traceEvUsed, s1, 1); if (rc) return rc;
@@ -402,7 +413,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 			// shadow rays of this bounce on the second stream, next to the closest-hit launch of the next bounce
 			HIPCHK(c, hipStreamWaitEvent(s2, c->evShade[b & 1], 0));
 			DQueues q2 = c->q; q2.spill = c->spillShadow;
-			rc = timed(c->traceEvents, c->traceEvUsed, s2, 0); if (rc) return rc;
+			rc = timed(c->traceEvents, c->traceEvUsed, s2, 0, 2); if (rc) return rc;
 			launch_trace(s2, 1, c->countTraversal, false, c->dsc, c->paths, q2, c->q.shadow, upper, b == 0,
 			             set + (size_t) kShadowWord);
 			rc = timed(c->traceEvents, c->traceEvUsed, s2, 1); if (rc) return rc;
@@ -483,7 +494,8 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		// stream, so that the closest-hit launch of the next bounce runs next to them -- the shading above has completed
 		if (nShadow) {
 			DQueues q2 = c->q; q2.spill = c->spillShadow;
-			hipEvent_t *ev2 = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
+			hipEvent_t *ev2 = c->timeKernels ? nextTraceEvents(c, 2) : nullptr;
+			c->lastPass.shadowMax = std::max(c->lastPass.shadowMax, nShadow);
 			if (ev2) HIPCHK(c, hipEventRecord(ev2[0], s2));
 			launch_trace(s2, 1, c->countTraversal, false, c->dsc, c->paths, q2, c->q.shadow, nShadow, first);
 			if (ev2) HIPCHK(c, hipEventRecord(ev2[1], s2));
@@ -530,6 +542,9 @@ void collectTimings(mtsgpu_ctx *c) {
 	for (size_t i = 0; i < c->traceEvUsed; ++i) {
 		if (hipEventElapsedTime(&ms, c->traceEvents[i].first, c->traceEvents[i].second) != hipSuccess) continue;
 		c->stats.trace_ms += ms;
+		const int cls = i < c->traceEvClass.size() ? c->traceEvClass[i] : 0;
+		if (cls == 1) c->stats.trace_first_ms += ms;
+		else if (cls == 2) c->stats.trace_shadow_ms += ms;
 		float t0 = 0;
 		if (i == 0 || hipEventElapsedTime(&t0, c->traceEvents[0].first, c->traceEvents[i].first) == hipSuccess)
 			iv.emplace_back(t0, t0 + ms);
@@ -1179,6 +1194,8 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 		}
 		launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList + base, nSlots, nullptr, nPaths, c->queueA);
 		HIPCHK(c, hipGetLastError());
+		c->lastPass.valid = true; c->lastPass.cfg = cfg; c->lastPass.base = base;
+		c->lastPass.nSlots = nSlots; c->lastPass.nPaths = nPaths; c->lastPass.shadowMax = 0;
 		rc = runBounces(c, cfg, nPaths, cancel);
 		if (rc) return rc;
 		if (wideFilter) {
@@ -1233,6 +1250,7 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 	std::memset(&c->stats, 0, sizeof(c->stats));
 	c->traceEvUsed = c->shadeEvUsed = 0;
 	if (n == 0) return 0;
+	c->lastPass.valid = false;
 	int rc = ensurePaths(c, n); if (rc) return rc;
 	{
 		// host rays -> ray_o / ray_d slots of the path records
@@ -1243,7 +1261,7 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 	}
 	launch_iota(c->stream, c->queueA, n);
 	if (c->countTraversal) HIPCHK(c, hipMemsetAsync(c->q.trace_counts, 0, kNumTraceCounts * sizeof(unsigned long long), c->stream));
-	hipEvent_t *ev = c->timeKernels ? nextEventPair(c, c->traceEvents, c->traceEvUsed) : nullptr;
+	hipEvent_t *ev = c->timeKernels ? nextTraceEvents(c, shadow ? 2 : 0) : nullptr;
 	if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
 	HIPCHK(c, hipMemsetAsync(c->q.counters, 0, kNumCounters * kCounterStride * sizeof(uint32_t), c->stream));     // dynamic batch head
 	launch_trace(c->stream, shadow ? 2 : 0, c->countTraversal, false, c->dsc, c->paths, c->q, c->queueA, n, false);
@@ -1259,20 +1277,30 @@ int mtsgpu_trace_rays(mtsgpu_ctx *c, const float *rays, uint32_t n, int shadow, 
 }
 
 // The replay roof of the closest-hit traversal kernel (include/mtsgpu.h).
-int mtsgpu_replay_roof(mtsgpu_ctx *c, uint32_t n, uint32_t stride, int reps, double *out) {
+int mtsgpu_replay_roof(mtsgpu_ctx *c, int kind, uint32_t n, uint32_t stride, int reps, double *out) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
 	if (!c->haveScene) return fail(c, MTSGPU_ESTATE, "no scene uploaded");
-	if (!out || n == 0 || stride == 0 || reps < 1) return fail(c, MTSGPU_EINVAL, "bad argument");
+	if (!out || n == 0 || stride == 0 || reps < 1 || kind < 0 || kind > 2) return fail(c, MTSGPU_EINVAL, "bad argument");
+	const mtsgpu_ctx::LastPass lp = c->lastPass;
+	if (kind == 1 && (!lp.valid || (uint64_t) n * stride > lp.nPaths))
+		return fail(c, MTSGPU_EINVAL, "replay roof: %u camera rays x stride %u exceed the pass rendered last (%u paths)", n, stride, lp.valid ? lp.nPaths : 0u);
+	if (kind == 2 && (!lp.valid || (uint64_t) n * stride > lp.shadowMax))
+		return fail(c, MTSGPU_EINVAL, "replay roof: %u shadow rays x stride %u exceed the shadow queue of the pass rendered last (%u rays; host-driven passes only)",
+		            n, stride, lp.valid ? lp.shadowMax : 0u);
 	if ((uint64_t) n * stride > c->pathCap || ((uint64_t) (n - 1) * stride + 1) * kPathSlots > (1ull << 29))
 		return fail(c, MTSGPU_EINVAL, "replay roof: %u rays x stride %u exceed the path records in memory (%zu) or the 2^29 slots a recorded index can name", n, stride, c->pathCap);
 	HIPCHK(c, hipSetDevice(c->device));
 	hipStream_t s = c->stream;
+	const int mode = kind == 2 ? 1 : 0;
+	const bool coherent = kind == 1, bin = kind != 2;      // as the bounces launch this class of rays
 	const uint32_t cap = 256;                  // requests kept per ray (C3: 45 on average; longer lists are truncated and counted); % 4 == 0
 	const uint32_t nBatches = (n + 63u) / 64u;
 	uint32_t *rec = nullptr, *recLen = nullptr, *order = nullptr, *tr = nullptr, *batchLen = nullptr, *sink = nullptr;
+	float4 *tmp = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	auto cleanup = [&]() {
 		for (uint32_t *p : { rec, recLen, order, tr, batchLen, sink }) if (p) (void) hipFree(p);
+		if (tmp) (void) hipFree(tmp);
 		if (e0) (void) hipEventDestroy(e0);
 		if (e1) (void) hipEventDestroy(e1);
 		c->q.rec = c->q.rec_len = nullptr; c->q.rec_cap = 0;
@@ -1283,16 +1311,35 @@ int mtsgpu_replay_roof(mtsgpu_ctx *c, uint32_t n, uint32_t stride, int reps, dou
 	RR_CHK(hipMalloc((void **) &order, (size_t) n * 4)); RR_CHK(hipMalloc((void **) &tr, (size_t) nBatches * cap * 64 * 4));
 	RR_CHK(hipMalloc((void **) &batchLen, (size_t) nBatches * 4)); RR_CHK(hipMalloc((void **) &sink, 4));
 	RR_CHK(hipEventCreate(&e0)); RR_CHK(hipEventCreate(&e1));
-	// the rays: every stride-th path record of the frame that was rendered last (each holds the last ray of its path)
-	launch_iota_strided(s, c->queueA, n, stride);
 	const size_t counterBytes = kNumCounters * kCounterStride * sizeof(uint32_t);
-	c->q.counters = c->counterSets; c->q.spill = c->spillClosest; c->q.dev_stats = nullptr;
+	c->q.counters = c->counterSets; c->q.spill = mode == 1 ? c->spillShadow : c->spillClosest; c->q.dev_stats = nullptr;
+	c->q.next = c->queueB;
+	// the rays of the sample
+	if (kind == 1) {
+		// the camera rays of the pass rendered last, once more (its sampler tables are still in place)
+		launch_generate(s, c->dsc, c->paths, lp.cfg, c->pixelList + lp.base, lp.nSlots, nullptr, lp.nPaths, c->queueA);
+		RR_CHK(hipGetLastError());
+		c->lastPass.valid = false;             // the path records no longer hold that pass
+	}
+	if (kind == 2) {
+		// any-hit rays are addressed by their queue position: the sampled slots move to the front of the shadow queue
+		RR_CHK(hipMalloc((void **) &tmp, (size_t) n * 3 * sizeof(float4)));
+		launch_gather_strided(s, tmp, c->paths.shq_o, n, stride); launch_gather_strided(s, tmp + n, c->paths.shq_d, n, stride);
+		launch_gather_strided(s, tmp + 2 * (size_t) n, c->paths.shq_nee, n, stride);
+		RR_CHK(hipMemcpyAsync(c->paths.shq_o, tmp, (size_t) n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+		RR_CHK(hipMemcpyAsync(c->paths.shq_d, tmp + n, (size_t) n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+		RR_CHK(hipMemcpyAsync(c->paths.shq_nee, tmp + 2 * (size_t) n, (size_t) n * sizeof(float4), hipMemcpyDeviceToDevice, s));
+		c->lastPass.shadowMax = 0;             // the queue is no longer the frame's
+	} else {
+		launch_iota_strided(s, c->queueA, n, stride);       // every stride-th path record
+	}
+	const uint32_t *queue = mode == 1 ? c->q.shadow : c->queueA;
 	// 1. the counting kernel records what every ray asks for
 	RR_CHK(hipMemsetAsync(recLen, 0, (size_t) n * 4, s));
 	RR_CHK(hipMemsetAsync(c->q.trace_counts, 0, kNumTraceCounts * sizeof(unsigned long long), s));
 	RR_CHK(hipMemsetAsync(c->q.counters, 0, counterBytes, s));
 	c->q.rec = rec; c->q.rec_len = recLen; c->q.rec_cap = cap;
-	launch_trace(s, 0, true, false, c->dsc, c->paths, c->q, c->queueA, n, false);
+	launch_trace(s, mode, true, false, c->dsc, c->paths, c->q, queue, n, coherent);
 	c->q.rec = c->q.rec_len = nullptr; c->q.rec_cap = 0;
 	RR_CHK(hipGetLastError());
 	std::vector<uint32_t> len(n);
@@ -1314,7 +1361,7 @@ int mtsgpu_replay_roof(mtsgpu_ctx *c, uint32_t n, uint32_t stride, int reps, dou
 	for (int i = 0; i <= reps; ++i) {            // round 0 warms up
 		RR_CHK(hipMemsetAsync(c->q.counters, 0, counterBytes, s));
 		RR_CHK(hipEventRecord(e0, s));
-		launch_trace(s, 0, false, false, c->dsc, c->paths, c->q, c->queueA, n, false);
+		launch_trace(s, mode, false, bin, c->dsc, c->paths, c->q, queue, n, coherent);
 		RR_CHK(hipEventRecord(e1, s));
 		RR_CHK(hipEventSynchronize(e1));
 		float ms = 0; RR_CHK(hipEventElapsedTime(&ms, e0, e1));
@@ -1344,7 +1391,7 @@ int mtsgpu_ld_tables(mtsgpu_ctx *c, uint32_t pixel_key, float *out1d, float *out
 	int rc = ensureBuf(c, &c->ldScr, &c->ldScrCap, (size_t) 3 * depth); if (rc) return rc;
 	rc = ensureBuf(c, &c->ldPerm, &c->ldPermCap, (size_t) 2 * depth * spp); if (rc) return rc;
 	rc = ensureTableWork(c, 1, spp); if (rc) return rc;
-	c->renderListValid = false;
+	c->renderListValid = false; c->lastPass.valid = false;
 	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, 1); if (rc) return rc;
 	HIPCHK(c, hipMemcpyAsync(c->pixelList, &pixel_key, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	DConfig cfg{};
@@ -1391,7 +1438,7 @@ int mtsgpu_sampler_values(mtsgpu_ctx *c, uint32_t pixel_key, uint32_t sample_ind
 	const uint32_t spp = effectiveSpp(c);
 	if (n > 4096u || sample_index >= spp) return fail(c, MTSGPU_EINVAL, "sample index or count out of range");
 	HIPCHK(c, hipSetDevice(c->device));
-	c->renderListValid = false;
+	c->renderListValid = false; c->lastPass.valid = false;
 	int rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, 1); if (rc) return rc;
 	HIPCHK(c, hipMemcpyAsync(c->pixelList, &pixel_key, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	if (samplerHasTables(c)) {
@@ -1455,7 +1502,7 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 	}
 	rc = ensurePaths(c, n); if (rc) return rc;
 	rc = ensureBuf(c, &c->explicitSamples, &c->explicitCap, 3 * (size_t) n); if (rc) return rc;
-	c->renderListValid = false;
+	c->renderListValid = false; c->lastPass.valid = false;
 	rc = ensureBuf(c, &c->pixelList, &c->pixelListCap, n); if (rc) return rc;
 	HIPCHK(c, hipMemcpyAsync(c->explicitSamples, pix_samples, 3 * (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipMemcpyAsync(c->pixelList, keys.data(), (size_t) n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));

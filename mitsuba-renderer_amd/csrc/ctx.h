@@ -76,6 +76,10 @@ struct mtsgpu_ctx {
 	mtsgpu_stats stats{};
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> traceEvents, shadeEvents;
 	size_t traceEvUsed = 0, shadeEvUsed = 0;
+	std::vector<unsigned char> traceEvClass;      // per traversal launch: 0 closest-hit, 1 closest-hit of a pass's first bounce, 2 any-hit
+	// what mtsgpu_replay_roof needs to know about the pass rendered last: how to generate its camera rays again, and
+	// how many slots of the shadow queue hold rays (the largest shadow launch of the pass; 0 after device-driven bounces)
+	struct LastPass { bool valid = false; mg::DConfig cfg{}; size_t base = 0; uint32_t nSlots = 0, nPaths = 0, shadowMax = 0; } lastPass;
 };
 
 

@@ -286,8 +286,11 @@ int mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, vol
 			return gfail(g, MTSGPU_ESTATE, "member %d has a different film size", i);
 	if (ordered_reduce == 2 && !ensureComms(g))
 		return gfail(g, MTSGPU_EHIP, "RCCL is not usable: %s", g->rcclNote.c_str());
-	// the staging buffer first: both sums need it, and failing to allocate it says nothing about RCCL
-	if (n > 1 || ordered_reduce == 2)
+	// the staging buffer first: failing to allocate it says nothing about RCCL.  It receives the collective's result and the
+	// films of peers on other devices; members that all share one device and add their films in order need none
+	bool distinctPeer = false;
+	for (int i = 1; i < n; ++i) distinctPeer = distinctPeer || g->devices[i] != g->devices[0];
+	if (distinctPeer || ordered_reduce == 2 || (ordered_reduce != 1 && n > 1))
 		if (int r = ensureStaging(g, count)) return r;
 	if (ordered_reduce != 1) {
 		if (ensureComms(g)) {

@@ -320,6 +320,7 @@ void launch_build_replay(hipStream_t s, const uint32_t *rec, const uint32_t *rec
 void launch_replay(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *tr, const uint32_t *batch_len,
                    uint32_t n_batches, uint32_t cap, uint32_t zero, uint32_t *sink);
 void launch_iota_strided(hipStream_t s, uint32_t *p, uint32_t n, uint32_t stride);
+void launch_gather_strided(hipStream_t s, float4 *dst, const float4 *src, uint32_t n, uint32_t stride);      // dst[i] = src[i * stride]
 // dst[i] += src[i] over n floats (the ordered film sum of a device group)
 void launch_add_film(hipStream_t s, float *dst, const float *src, size_t n);
 // ImageBlock tiles of one context: rect, first sampler slot of the tile inside its pass, block index

@@ -2630,6 +2630,10 @@ __global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(0)) void k_replay
 	}
 	if (acc == 0xDEADBEEFu) sink[0] = acc;
 }
+__global__ void k_gather_strided(float4 *dst, const float4 *src, uint32_t n, uint32_t stride) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) dst[i] = src[(size_t) i * stride];
+}
 __global__ void k_iota_strided(uint32_t *p, uint32_t n, uint32_t stride) {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) p[i] = i * stride;
@@ -2877,6 +2881,9 @@ void launch_replay(hipStream_t s, const DScene &sc, const DPaths &ps, const DQue
                    uint32_t n_batches, uint32_t cap, uint32_t zero, uint32_t *sink) {
 	const unsigned blocks = std::min<unsigned>(blocks_for(n_batches, kTraceBlock / 64), q.n_cus * trace_blocks_per_cu(0));
 	if (blocks) hipLaunchKernelGGL(k_replay, dim3(blocks), dim3(kTraceBlock), 0, s, sc.nodes, sc.leaf_ta, ps.base, tr, batch_len, n_batches, cap, zero, sink);
+}
+void launch_gather_strided(hipStream_t s, float4 *dst, const float4 *src, uint32_t n, uint32_t stride) {
+	if (n) hipLaunchKernelGGL(k_gather_strided, dim3(blocks_for(n, 256)), dim3(256), 0, s, dst, src, n, stride);
 }
 void launch_iota_strided(hipStream_t s, uint32_t *p, uint32_t n, uint32_t stride) {
 	if (n) hipLaunchKernelGGL(k_iota_strided, dim3(blocks_for(n, 256)), dim3(256), 0, s, p, n, stride);

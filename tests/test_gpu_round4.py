@@ -28,20 +28,31 @@ def test_issued_request_counters_add_up(gpu_lib, mts):
 
 
 def test_replay_roof_replays_what_the_kernel_asked_for(gpu_lib, mts):
-    """mtsgpu_replay_roof: the recorded lists hold exactly the requests the counters saw (pairs + nodes from global
-    memory, heads, tails, two loads of the ray and the store of the hit per ray), and both timings are positive"""
+    """mtsgpu_replay_roof, all three classes of launches: the recorded lists hold exactly the requests the counters saw
+    (pairs + nodes from global memory, heads, tails; for closest-hit rays two loads of the ray and the store of the hit
+    as well), and both timings are positive"""
     sd = mts.scenes.cornell_c3(grid=48, sphere_subdiv=3)
     scene = mts.Scene(sd)
     cam = mts.PerspectiveCamera.for_description(sd, 128, 128)
     it = mts.MIPathTracer(maxDepth=8)
     it.preprocess(scene, cam, sampler="ldsampler", sampleCount=8, seed=3)
+    it.set_tuning(sync_free=0)                # host-driven bounces: the shadow class needs the size of the shadow queue
     assert it.render()
     film = it.film().copy()
     n = 128 * 128 * 8 // 2
-    rr = it.replay_roof(n, stride=2, reps=1)
-    assert rr["rays"] == n and rr["truncated_rays"] == 0
-    assert rr["requests"] == rr["pair_global"] + rr["node_global"] + rr["heads"] + rr["tails"] + 3 * n
-    assert rr["product_ms"] > 0 and rr["replay_ms"] > 0
+    for kind, own in (("deep", 3 * n), ("shadow", 0), ("camera", 3 * n)):
+        nk = n // 4 if kind == "shadow" else n
+        rr = it.replay_roof(nk, stride=2, reps=1, kind=kind)
+        assert rr["rays"] == nk and rr["truncated_rays"] == 0, kind
+        assert rr["requests"] == rr["pair_global"] + rr["node_global"] + rr["heads"] + rr["tails"] + (own if kind != "shadow" else 0) * nk // n, (kind, rr)
+        assert rr["product_ms"] > 0 and rr["replay_ms"] > 0
+    # camera rays start at the root: every one of them reads the LDS copy of the top of the tree
+    assert rr["pair_lds"] >= nk
+    # once the camera rays have been generated again the pass is gone: no second sample of it
+    with pytest.raises(mts.MtsGpuError):
+        it.replay_roof(n, stride=2, reps=1, kind="camera")
+    with pytest.raises(mts.MtsGpuError):
+        it.replay_roof(n // 4, stride=2, reps=1, kind="shadow")
     # the measurement leaves the renderer usable: the next frame is the same film
     it.clear_film()
     assert it.render()
@@ -67,14 +78,21 @@ def test_bench_line_carries_the_group_form_and_the_replay_roof(gpu_lib, mts, tmp
     replay roof with frac <= 1, and a CPU baseline that says what an ungated host would extrapolate to"""
     out = str(tmp_path / "group.npy")
     rec = _bench(["--res", "256", "--grid", "48", "--spp", "16", "--steps", "1", "--warmup", "1", "--host-kd",
-                  "--no-1spp", "--no-cpu-baseline", "--dump-group-film", out])
+                  "--no-1spp", "--no-cpu-baseline", "--group", "--dump-group-film", out])
     g = rec["group"]
     assert "error" not in g, g
     assert g["group_ms_per_step"] > 0 and g["value"] > 0 and g["devices"] == [0]
     rq = rec["roofline_requests"]
-    # (on the full-size frame the replay is a roof, frac = 0.86; a 1 M-ray sample is a launch of three rounds, where
-    # both kernels are mostly ramp and tail, so only the plumbing is asserted here)
-    assert rq["note"] is None and 0 < rq["frac"] < 2.0 and rq["product_ms"] > 0 and rq["replay_ms"] > 0, rq
+    # (on the full-size frame the replay takes 0.86 of the kernel's time; a 1 M-ray sample is a launch of three rounds,
+    # where both kernels are mostly ramp and tail, so only the plumbing is asserted here)
+    assert rq["note"] is None and set(rq["classes"]) == {"camera", "deep", "shadow"}, rq
+    for kind, cl in rq["classes"].items():
+        if kind == "shadow":           # a frame this small runs device-driven bounces, which leave no shadow-queue size behind
+            assert "host-driven passes only" in cl["error"] and rq["replay_ms_per_step"] is None, rq
+            continue
+        assert 0 < cl["replay_ratio"] < 2.5 and cl["product_ms"] > 0 and cl["replay_ms"] > 0 and cl["launches_ms_per_step"] > 0, rq
+    parts = sum(cl["launches_ms_per_step"] for cl in rq["classes"].values())
+    assert abs(parts - rq["trace_ms_per_step"]) < 1e-6 * max(1.0, parts)
     assert rq["issued_requests_per_ray"] > 0 and rq["lds_served_requests_per_ray"] > 0
     assert rec["roofline"]["frac"] > 0 and rec["roofline_shade"]["frac"] > 0
     sd = mts.scenes.cornell_c3(grid=48, sphere_subdiv=5)

@@ -34,3 +34,66 @@ def test_films_at_1024_samples_in_one_and_in_many_passes(gpu_lib, mts, orc, samp
         it.set_options(max_paths=max_paths)
         it.clear_film(); assert it.render()
         assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32)), max_paths
+
+
+def _run_bench(args, timeout=900):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+
+def _unsharded_c3(mts, res, grid, spp_total):
+    sd = mts.scenes.cornell_c3(grid=grid, sphere_subdiv=5)
+    it = mts.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth)
+    it.preprocess(mts.Scene(sd), mts.PerspectiveCamera.for_description(sd, res, res), sampler="ldsampler", sampleCount=spp_total, seed=0x5EED)
+    assert it.render()
+    return it.film()
+
+
+def test_five_ranks_on_one_gpu(gpu_lib, mts, tmp_path):
+    """bench.py's process-per-GPU form at a world size above two: five ranks (the GPU boxes allow six processes on a card,
+    this test runner is one of them) share GPU 0, tiles morton(tx, ty) % 5 (imageproc.cpp:43-78), the films summed on
+    rank 0 (renderproc.cpp:123-130; gloo on host copies, because ranks on one device cannot form an RCCL communicator):
+    every rank reports its times and the reduced film equals the unsharded render bit for bit"""
+    out = str(tmp_path / "film5.npy")
+    rec = _run_bench(["--gpus", "5", "--devices", "0,0,0,0,0", "--res", "160", "--grid", "24", "--spp-total", "8", "--steps", "1",
+                      "--warmup", "0", "--no-cpu-baseline", "--no-1spp", "--host-kd", "--no-group", "--max-paths", str(1 << 18),
+                      "--dump-film", out])
+    assert rec["n_gpus"] == 5 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert len(rec["rank_ms"]) == 5 and len(rec["reduce_ms"]) == 5 and min(rec["rank_ms"]) > 0
+    assert np.array_equal(np.load(out).view(np.uint32), _unsharded_c3(mts, 160, 24, 8).view(np.uint32))
+
+
+def test_device_group_of_eight_members_on_one_gpu(gpu_lib, mts, tmp_path):
+    """the drop-in's own multi-GPU form at the node's size: mtsgpu_create_multi over eight members (all on GPU 0 here),
+    mtsgpu_group_render gives member i the tiles of part i of 8 and sums the films in member order -- one process, eight
+    contexts, eight host threads; the film equals the unsharded render bit for bit.  With eight distinct GPUs the only
+    new thing is the RCCL reduce itself"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "film8.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--group-child", "8", "--devices", "0,0,0,0,0,0,0,0", "--res", "256",
+                        "--grid", "24", "--spp-total", "8", "--steps", "1", "--host-kd", "--dump-film", out],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    g = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert g["devices"] == [0] * 8 and g["group_ms_per_step"] > 0
+    assert g["reduce_kind"] == "ordered peer-copy sum", g
+    assert np.array_equal(np.load(out).view(np.uint32), _unsharded_c3(mts, 256, 24, 8).view(np.uint32))
+
+
+def test_fused_shading_launch_equals_one_launch_per_bsdf_type(gpu_lib, mts, orc):
+    """k_shade_all (device-driven bounces: every material queue of a bounce in ONE launch) against one k_shade launch per
+    BSDF type, on the scene with the most BSDF types, both against the oracle"""
+    sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "next_rows", W=48, H=48, sampler="ldsampler", spp=8)
+    ofilm, _ = orc.render(oscene.scene, ocam, op)
+    for fused in (1, 0):
+        it.set_tuning(sync_free=1, shade_fused=fused)
+        it.clear_film(); assert it.render()
+        assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32)), fused
