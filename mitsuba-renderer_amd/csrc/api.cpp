@@ -360,14 +360,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 	c->q.dev_stats = c->devStats;        // cleared by the caller (one frame may take several passes)
 	c->devStatsUsed = true;
 	// MIPathTracer traces at most maxDepth rays per path (path.cpp:87), the one-sample direct integrator two
-	const int depthLimit = cfg.integrator == 1 ? 2 : (cfg.max_depth > 0 ? cfg.max_depth : 0x7FFFFFFF);
-	// Long rays are handed back to the next launch (kernels.hip: CAP) -- their paths run late, so the loop goes on until the
-	// queue is empty, two bounces per look at its size once depthLimit is past.  Not with the counting kernels (their
-	// counts are compared with the oracle's per-ray counts) and not for the direct integrator's two fixed rounds.
-	const long capKnob = tuningOr(c, "visit_cap", 32);
-	const bool capped = capKnob > 0 && !c->countTraversal && cfg.integrator == 0 && nPaths <= kCapIdMaxPaths;
-	c->q.visit_cap = capped ? (uint32_t) capKnob : 0u;
-	const int limit = capped && depthLimit < 0x7FFFFFFF - 1024 ? depthLimit + 1024 : depthLimit;
+	const int limit = cfg.integrator == 1 ? 2 : (cfg.max_depth > 0 ? cfg.max_depth : 0x7FFFFFFF);
 	const int chunk = (int) tuningOr(c, "chunk", 8);
 	uint32_t *cur = c->queueA, *nxt = c->queueB;
 	uint32_t upper = nPaths;                   // what the host knows about the queue sizes
@@ -381,7 +374,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 		mtsgpu_ctx *c; hipStream_t s2; const bool &pending;
 		~Restore() {
 			if (pending) (void) hipStreamSynchronize(s2);
-			c->q.dev_stats = nullptr; c->q.counters = c->counterSets; c->q.spill = c->spillClosest; c->q.visit_cap = 0;
+			c->q.dev_stats = nullptr; c->q.counters = c->counterSets; c->q.spill = c->spillClosest;
 		}
 	} restore{ c, s2, shadowPending };
 	// cls >= 0: a traversal launch of that class (ctx.h: traceEvClass)
@@ -394,7 +387,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 	};
 	while (b < limit && upper > 0) {
 		if (cancel && *cancel) return fail(c, MTSGPU_ECANCEL, "render cancelled");
-		const int end = (int) std::min<long long>((long long) b + (b >= depthLimit ? 2 : chunk), limit);
+		const int end = (int) std::min<long long>((long long) b + chunk, limit);
 		for (; b < end; ++b) {
 			uint32_t *set = counterSet(c, b), *prev = counterSet(c, b - 1);
 			c->q.counters = set; c->q.next = nxt; c->q.spill = c->spillClosest;
@@ -1055,7 +1048,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 }, { "visit_cap", 0, 1 << 20 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);

@@ -43,7 +43,6 @@ constexpr int kCounterSets = 2;
 constexpr int kCntNext = kNumBins * kBinShards, kCntShadow = kCntNext + 1, kCntDynClosest = kCntNext + 2, kCntDynShadow = kCntNext + 3;
 // word offsets of the two queue counters of k_shade inside a counter set (one 128-byte line each)
 constexpr int kNextWord = kCntNext * kCounterStride, kShadowWord = kCntShadow * kCounterStride;
-constexpr uint32_t kCapIdMaxPaths = 1u << 27;      // queue ids carry an attempt count above bit 26 in capped launches (kernels.hip: CAP)
 #ifndef MG_SHADE_BLOCK
 #define MG_SHADE_BLOCK 1024     // 512: two atomics-bound milliseconds more per 64-spp frame (one reservation per workgroup)
 #endif
@@ -214,8 +213,6 @@ struct DQueues {
 	uint32_t tune_dyn_min_rounds;      // launches of at least this many rounds claim their last rounds dynamically (0 = 8)
 	uint32_t tune_blocks_per_cu;       // experiment: fewer resident workgroups of kTraceBlock threads per CU than trace_blocks_per_cu(mode)
 	                                   // (3 closest-hit / 4 shadow at 512 threads); 0 or a value >= that = all.  Range 0..kTraceBlocksPerCuMax
-	uint32_t visit_cap;                // closest-hit launches of device-driven bounces: leaf visits a ray gets before it is handed back
-	                                   // to the next launch (kernels.hip: CAP); 0 = no limit
 };
 
 // How one traversal launch over n rays is scheduled.  A pure function of (n, mode, q): the host evaluates it to size

@@ -770,15 +770,7 @@ uint32_t trace_top_nodes() { return 2u * kTopPairs; }
 __device__ __forceinline__ const uint4 *leaf_head(const DTraceScene &sc, uint32_t e) { return &sc.leaf_ta[kLeafStride * (size_t) e]; }
 __device__ __forceinline__ const uint4 *leaf_tail(const DTraceScene &sc, uint32_t e, uint32_t half) { return &sc.leaf_ta[kLeafStride * (size_t) e + 1 + half]; }
 
-// CAP (closest-hit launches of device-driven frames, whose launches last as long as their longest ray): a ray that has
-// visited q.visit_cap << attempt leaves without result and is handed back -- appended to the ray queue the shading of
-// this bounce fills, with its attempt count in the id's upper bits -- to be traced again, from the start and with twice
-// the budget, next to the rays of the next bounce (from the fifth attempt on without limit).  Its path skips this
-// bounce's shading and runs one bounce late from there on; every path still sees its own stages in order, which is all
-// the radiance sums depend on.
-constexpr uint32_t kCapIdBits = 27, kCapIdMask = (1u << kCapIdBits) - 1u;
-
-template <int MODE, bool COUNT, bool BIN, bool CAP = false>
+template <int MODE, bool COUNT, bool BIN>
 __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &ps, const DQueues &q, const TracePlan &plan,
                                            const uint32_t *queue, uint32_t n, const uint32_t first, const uint32_t stride,
                                            uint32_t (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock], const uint4 *s_top) {
@@ -832,7 +824,6 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 	const uint32_t refill_min = plan.refill_min, desc_min = plan.desc_min, leaf_min = plan.leaf_min;
 
 	uint32_t id = 0;
-	uint32_t budget = 0, attempt = 0;       // CAP: leaf visits left before the ray is handed back; how often that has happened
 	float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1, rx = 1, ry = 1, rz = 1;
 	float mint = 0, maxt = 0, tmax0 = 0;
 	float enx = 0, eny = 0, enz = 0, exx = 0, exy = 0, exz = 0, ex_t = 0;   // stack[enPt].p, stack[exPt].p, stack[exPt].t
@@ -926,10 +917,6 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 			MG_WSLOT(w_batch);
 			if (take) {
 				id = (MODE == 1) ? my : ld_stream<1>(&queue[my]);       // shadow rays are addressed by their queue position
-				if (CAP) {
-					attempt = id >> kCapIdBits; id &= kCapIdMask;
-					budget = attempt >= 4u ? 0xFFFFFFFFu : (q.visit_cap << attempt);
-				}
 				if (COUNT && q.rec) { rec_slot = my; rec_n = 0; if (MODE != 1) { rec_add(kReqRay, id * kPathSlots); rec_add(kReqRay, id * kPathSlots + 1); } }
 				float4 a, b;
 				float rmint, rmaxt;
@@ -1159,12 +1146,6 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				if (finished) {
 					has = false; done = true; found = (MODE == 0) ? (best_prim != kNoPrim) : hitShadow;
 					if (COUNT && q.rec) { if (MODE != 1) rec_add(kReqHit, id * kPathSlots + 2); q.rec_len[rec_slot] = rec_n; }
-				} else if (CAP && !more && --budget == 0u) {
-					// out of leaf visits: back into the ray queue of the next closest-hit launch (the ray is still in its path record)
-					const uint32_t pos = atomicAdd(&q.counters[kNextWord], 1u);
-					q.next[pos] = id | ((attempt + 1u) << kCapIdBits);
-					if (q.dev_stats) atomicAdd(&q.dev_stats[kStatClosest], ~0ull);       // it is counted again when it is traced again
-					has = false;                   // nothing to retire
 				}
 				}
 			}
@@ -1185,7 +1166,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 	}
 }
 
-template <int MODE, bool COUNT, bool BIN, bool CAP = false>
+template <int MODE, bool COUNT, bool BIN>
 __global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(MODE)) void k_trace(DTraceScene sc, DPaths ps, DQueues q,
                                                           const uint32_t *queue, uint32_t n_host, const uint32_t *n_dev) {
 	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
@@ -1207,7 +1188,7 @@ __global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(MODE)) void k_tra
 		for (uint32_t t = threadIdx.x; t < kTopPairs; t += kTraceBlock) s_top[t] = reinterpret_cast<const uint4 *>(sc.nodes)[t];
 		__syncthreads();
 	}
-	trace_body<MODE, COUNT, BIN, CAP>(sc, ps, q, plan, queue, n, first, stride, s_stack, s_mbox, s_top);
+	trace_body<MODE, COUNT, BIN>(sc, ps, q, plan, queue, n, first, stride, s_stack, s_mbox, s_top);
 }
 
 // Device-driven bounces: the per-bin views k_shade needs, from the shard counters the closest-hit launch left in `cur`
@@ -2810,7 +2791,7 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 	                                pixel_list, n_slots, explicit_samples, n_paths, queue);
 }
 
-template <int MODE, bool COUNT, bool BIN, bool CAP = false>
+template <int MODE, bool COUNT, bool BIN>
 static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n,
                            const uint32_t *n_dev) {
 	// persistent grid: enough workgroups to fill every CU, never more than there are rays (trace_plan); when only the
@@ -2824,7 +2805,7 @@ static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, co
 		blocks = std::min<unsigned>(blocks_for(n, minBatch * (kTraceBlock / 64)), q.n_cus * perCu);
 	}
 	if (!blocks) return;
-	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN, CAP>), dim3(blocks), dim3(kTraceBlock), 0, s, trace_scene(sc), ps, q, queue, n, n_dev);
+	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, trace_scene(sc), ps, q, queue, n, n_dev);
 }
 
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
@@ -2835,11 +2816,7 @@ void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &s
 	if (n_dev)
 		qq.force_static = 1u;        // no dynamically claimed batches: the material-queue segments cannot overflow then
 	if (mode == 0) {
-		if (bin) {
-			if (count) launch_trace_t<0, true, true>(s, sc, ps, qq, queue, n, n_dev);
-			else if (qq.visit_cap) launch_trace_t<0, false, true, true>(s, sc, ps, qq, queue, n, n_dev);
-			else launch_trace_t<0, false, true>(s, sc, ps, qq, queue, n, n_dev);
-		}
+		if (bin) { if (count) launch_trace_t<0, true, true>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<0, false, true>(s, sc, ps, qq, queue, n, n_dev); }
 		else     { if (count) launch_trace_t<0, true, false>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<0, false, false>(s, sc, ps, qq, queue, n, n_dev); }
 	} else if (mode == 1) {
 		if (count) launch_trace_t<1, true, false>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<1, false, false>(s, sc, ps, qq, queue, n, n_dev);
