@@ -155,6 +155,8 @@ struct EventLess {
 };
 
 struct Split { float cost = kInf, pos = 0; int axis = 0; uint32_t numLeft = 0, numRight = 0; bool planarLeft = false; };
+// a candidate split plane of the exact phase: how many primitives end on it, lie in it, start on it (indexed by event type)
+struct Candidate { float pos; int axis; uint32_t count[3]; };
 
 // preliminary node: leaf {start, end} into the owning context's index list, inner {axis, children, split},
 // or a reference to a subtree built by a job
@@ -193,6 +195,7 @@ struct Context {
 	std::vector<uint32_t> indices;
 	uint32_t leafCount = 0, nonemptyLeafCount = 0, innerCount = 0, primIndexCount = 0, retracted = 0, pruned = 0;
 	uint32_t allocNodes(uint32_t n) { const uint32_t r = (uint32_t) nodes.size(); nodes.resize(nodes.size() + n); return r; }
+	std::vector<Candidate> planes;      // scratch of Builder::sweep: the candidate planes of the node being split
 };
 
 struct Job { uint32_t depth; Box nodeBox; std::vector<uint32_t> prims; uint32_t badRefines; Context ctx; uint32_t root; double ms = 0; };
@@ -217,6 +220,46 @@ struct Plan { std::vector<PlanNode> nodes; };
 class Builder {
 public:
 	Builder(const Geometry &g, const Params &p, uint32_t nPrims) : m_g(g), m_p(p), m_nPrims(nPrims) {}
+
+	// SAH cost of splitting at a plane with nBelow / nAbove primitives on its sides (gkdtree.h:1974-1980: the empty-space
+	// bonus applies when one side is empty)
+	float planeCost(float probBelow, float probAbove, uint32_t nBelow, uint32_t nAbove) const {
+		float cost = m_p.traversalCost + m_p.queryCost * (probBelow * (float) nBelow + probAbove * (float) nAbove);
+		if (nBelow == 0 || nAbove == 0)
+			cost *= m_p.emptySpaceBonus;
+		return cost;
+	}
+
+	// The cheapest of the candidate planes strictly inside the node.  Primitives lying IN a plane go to the side that is
+	// cheaper, to the right one when both cost the same (gkdtree.h:1996-2014)
+	Split cheapestPlane(const std::vector<Candidate> &planes, const Box &nodeBox, uint32_t primCount) const {
+		Split best;
+		const SAH area(nodeBox);
+		uint32_t below[3] = { 0, 0, 0 }, above[3] = { primCount, primCount, primCount };
+		for (const Candidate &pl : planes) {
+			const int k = pl.axis;
+			const uint32_t inPlane = pl.count[kPlanar];
+			above[k] -= inPlane + pl.count[kEnd];
+			if (pl.pos > nodeBox.mn[k] && pl.pos < nodeBox.mx[k]) {
+				float probBelow, probAbove;
+				area(k, pl.pos - nodeBox.mn[k], nodeBox.mx[k] - pl.pos, probBelow, probAbove);
+				Split s;
+				s.pos = pl.pos; s.axis = k; s.numLeft = below[k]; s.numRight = above[k];
+				s.cost = planeCost(probBelow, probAbove, below[k], above[k]);
+				if (inPlane != 0) {
+					const float withLeft = planeCost(probBelow, probAbove, below[k] + inPlane, above[k]);
+					const float withRight = planeCost(probBelow, probAbove, below[k], above[k] + inPlane);
+					s.planarLeft = withLeft < withRight;
+					s.cost = s.planarLeft ? withLeft : withRight;
+					(s.planarLeft ? s.numLeft : s.numRight) += inPlane;
+				}
+				if (s.cost < best.cost)
+					best = s;
+			}
+			below[k] += pl.count[kStart] + inPlane;
+		}
+		return best;
+	}
 
 	static void pushEvents(std::vector<Event> &out, const Box &b, uint32_t index) {
 		for (int axis = 0; axis < 3; ++axis) {
@@ -277,48 +320,21 @@ public:
 			leafFromEvents(c, node, eventStart, eventEnd, primCount);
 			return leafCost;
 		}
-		Split best;
-		uint32_t numLeft[3] = { 0, 0, 0 }, numRight[3] = { primCount, primCount, primCount };
-		const Event *axisStart[3] = { eventStart, eventEnd, eventEnd };
-		int axisCtr = 1;
-		const SAH tch(nodeBox);
-		for (const Event *ev = eventStart; ev < eventEnd;) {
-			const int axis = ev->axis;
-			const float pos = ev->pos;
-			uint32_t numStart = 0, numEnd = 0, numPlanar = 0;
-			while (ev < eventEnd && ev->pos == pos && ev->axis == axis && ev->type == kEnd) { ++numEnd; ++ev; }
-			while (ev < eventEnd && ev->pos == pos && ev->axis == axis && ev->type == kPlanar) { ++numPlanar; ++ev; }
-			while (ev < eventEnd && ev->pos == pos && ev->axis == axis && ev->type == kStart) { ++numStart; ++ev; }
-			if (ev < eventEnd && ev->axis != axis)
-				axisStart[axisCtr++] = ev;
-			numRight[axis] -= numPlanar + numEnd;
-			if (pos > nodeBox.mn[axis] && pos < nodeBox.mx[axis]) {
-				const uint32_t nL = numLeft[axis], nR = numRight[axis];
-				const float nLF = (float) nL, nRF = (float) nR;
-				float pl, pr;
-				tch(axis, pos - nodeBox.mn[axis], nodeBox.mx[axis] - pos, pl, pr);
-				if (numPlanar == 0) {
-					float cost = m_p.traversalCost + m_p.queryCost * (pl * nLF + pr * nRF);
-					if (nL == 0 || nR == 0)
-						cost *= m_p.emptySpaceBonus;
-					if (cost < best.cost) { best.pos = pos; best.axis = axis; best.cost = cost; best.numLeft = nL; best.numRight = nR; }
-				} else {
-					float costPlanarLeft = m_p.traversalCost + m_p.queryCost * (pl * (float) (nL + numPlanar) + pr * nRF);
-					float costPlanarRight = m_p.traversalCost + m_p.queryCost * (pl * nLF + pr * (float) (nR + numPlanar));
-					if (nL + numPlanar == 0 || nR == 0) costPlanarLeft *= m_p.emptySpaceBonus;
-					if (nL == 0 || nR + numPlanar == 0) costPlanarRight *= m_p.emptySpaceBonus;
-					if (costPlanarLeft < best.cost || costPlanarRight < best.cost) {
-						best.pos = pos; best.axis = axis;
-						if (costPlanarLeft < costPlanarRight) {
-							best.cost = costPlanarLeft; best.numLeft = nL + numPlanar; best.numRight = nR; best.planarLeft = true;
-						} else {
-							best.cost = costPlanarRight; best.numLeft = nL; best.numRight = nR + numPlanar; best.planarLeft = false;
-						}
-					}
-				}
+		// The greedy SAH step (gkdtree.h:1936-2021) in two passes over the sorted events, the way the device phase does it with
+		// prefix sums (exactOnDevice): first every distinct (axis, position) becomes one candidate plane with the numbers of
+		// primitives that end on it, lie in it and start on it; then a running count per axis turns those into the populations
+		// left and right of each plane and the cheapest plane is kept -- the first one among equals, in (axis, position) order.
+		const Event *axisStart[3] = { eventEnd, eventEnd, eventEnd };
+		std::vector<Candidate> &planes = c.planes;
+		planes.clear();
+		for (const Event *ev = eventStart; ev < eventEnd; ++ev) {
+			if (planes.empty() || planes.back().axis != ev->axis || planes.back().pos != ev->pos) {
+				if (planes.empty() || planes.back().axis != ev->axis) axisStart[ev->axis] = ev;
+				planes.push_back(Candidate{ ev->pos, (int) ev->axis, { 0, 0, 0 } });
 			}
-			numLeft[axis] += numStart + numPlanar;
+			planes.back().count[ev->type]++;
 		}
+		const Split best = cheapestPlane(planes, nodeBox, primCount);
 
 		if (best.cost >= leafCost) {
 			if ((best.cost > 4 * leafCost && primCount < 16) || badRefines >= m_p.maxBadRefines || best.cost == kInf) {
@@ -395,7 +411,8 @@ public:
 		const float rightCost = sweep(c, cls, depth + 1, children + 1, rightBox, rightEvents, best.numRight - prunedRight, badRefines);
 
 		float pl, pr;
-		tch(best.axis, best.pos - nodeBox.mn[best.axis], nodeBox.mx[best.axis] - best.pos, pl, pr);
+		const SAH area(nodeBox);
+		area(best.axis, best.pos - nodeBox.mn[best.axis], nodeBox.mx[best.axis] - best.pos, pl, pr);
 		const float finalCost = m_p.traversalCost + (pl * leftCost + pr * rightCost);
 		if (!m_p.retract || finalCost < primCount * m_p.queryCost)
 			return finalCost;
