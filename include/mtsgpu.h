@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MTSGPU_ABI_VERSION 5
+#define MTSGPU_ABI_VERSION 6
 
 enum {
 	MTSGPU_OK = 0,

@@ -5,7 +5,7 @@ against the sizes the C compiler reports (mtsgpu_abi_sizeof)."""
 import ctypes as C
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 BSDF_LAMBERTIAN, BSDF_DIELECTRIC, BSDF_ROUGHMETAL, BSDF_MICROFACET, BSDF_MIRROR, BSDF_PHONG, BSDF_ROUGHGLASS, BSDF_DIFFTRANS = 0, 1, 2, 3, 4, 5, 6, 7
 BSDF_TWOSIDED = 0x100
 BSDF_NPARAMS = 16
