@@ -97,3 +97,34 @@ def test_fused_shading_launch_equals_one_launch_per_bsdf_type(gpu_lib, mts, orc)
         it.set_tuning(sync_free=1, shade_fused=fused)
         it.clear_film(); assert it.render()
         assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32)), fused
+
+
+def test_rccl_process_group_of_one_rank(gpu_lib, mts, tmp_path):
+    """what bench.py does first with more than one GPU, as far as one GPU allows: torch.distributed over backend nccl (= RCCL)
+    forms a group, the probing all-reduce and the film reduce (filmreduce.reduce_film on a 1024 x 1024 x 5 tensor) run on the
+    device; a fresh process, because a process group is per process"""
+    import os, subprocess, sys, socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import datetime, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import _pkgload
+pkg = _pkgload.load()
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, timeout=datetime.timedelta(seconds=120), device_id=torch.device("cuda", 0))
+probe = torch.ones(1, device="cuda"); dist.all_reduce(probe); torch.cuda.synchronize()
+assert int(probe.item()) == 1
+film = torch.arange(1024 * 1024 * 5, dtype=torch.float32, device="cuda").reshape(1024, 1024, 5)
+ref = film.clone()
+dist.reduce(film, dst=0, op=dist.ReduceOp.SUM); torch.cuda.synchronize()      # what reduce_film issues with more than one rank
+assert torch.equal(film, ref)
+assert pkg.filmreduce.reduce_film(film, dst=0) is film
+dist.barrier(); dist.destroy_process_group()
+print("rccl ok", dist.Backend.NCCL)
+''' % root
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and b"rccl ok" in r.stdout, r.stderr.decode()[-2000:]
