@@ -569,6 +569,9 @@ int fetchTraceCounts(mtsgpu_ctx *c) {
 	c->stats.req_pair_global = h[kCntPairGlobal]; c->stats.req_pair_lds = h[kCntPairLds];
 	c->stats.req_node_global = h[kCntNodeGlobal]; c->stats.req_node_lds = h[kCntNodeLds];
 	c->stats.req_tail = h[kCntTail]; c->stats.req_spill = h[kCntSpill]; c->stats.req_head = h[kCntHead];
+	if (getenv("MTSGPU_DEBUG"))     // candidates whose tail was fetched with a plane distance outside the visited leaf's own interval
+		fprintf(stderr, "[mtsgpu] record tails: %llu requests, %llu candidates of which %llu (%.3f) lie outside the leaf's interval\n",
+		        h[kCntTail], h[kCntTail] / 2, h[15], h[kCntTail] ? 2.0 * h[15] / h[kCntTail] : 0.0);
 	if (getenv("MTSGPU_DEBUG"))     // SIMD utilisation of the traversal loops: lane steps / lane slots issued
 		fprintf(stderr, "[mtsgpu] lanes: inner %llu/%llu (%.3f)  leaf-prims %llu/%llu (%.3f)  outer %llu/%llu (%.3f)  batch slots %llu\n",
 		        h[0], h[4], h[4] ? (double) h[0] / h[4] : 0.0, h[2], h[5], h[5] ? (double) h[2] / h[5] : 0.0,

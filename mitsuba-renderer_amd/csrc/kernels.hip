@@ -805,6 +805,9 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 	const uint32_t shard = blockIdx.x % kBinShards;     // contention on a bin counter is spread over kBinShards words
 
 	uint32_t c_inner = 0, c_leaf = 0, c_idx = 0, c_tri = 0;
+	// COUNT: candidates whose record tail was fetched although their plane distance lies outside the interval the ray spends
+	// in the leaf being visited (the reference tests against the ray's whole interval, sahkdtree3.h:262-288); c_ten = stack[enPt].t
+	uint32_t c_tail_out = 0; float c_ten = 0;
 	uint32_t w_inner = 0, w_leaf = 0, w_outer = 0, w_batch = 0;   // COUNT: lane slots issued per loop (64 per wave iteration)
 #define MG_WSLOT(w) do { if (COUNT && lane == (uint32_t) __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) (w) += 64u; } while (0)
 
@@ -969,6 +972,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					// entry point (stack[enPt]) and current exit point (stack[exPt]) in registers
 					enx = ox + mint * dx; eny = oy + mint * dy; enz = oz + mint * dz;      // stack[enPt].p = ray(mint)
 					tmax0 = maxt;
+					if (COUNT) c_ten = mint;
 					ex_t = maxt; exx = ox + maxt * dx; exy = oy + maxt * dy; exz = oz + maxt * dz;
 					ex_node = kNullNode; ex_ref = kSentinel;
 					sp = 0; cur = 0; e_cont = kNoPrim;
@@ -1091,6 +1095,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 							const uint4 B = ld_stream<2>(leaf_tail(sc, e, 0));
 							const uint4 C = ld_stream<2>(leaf_tail(sc, e, 1));         // c_nu, c_nv, shape index, -
 							if (COUNT) { g_tail += 2u; rec_add(kReqLeaf, kLeafStride * e + 1u); rec_add(kReqLeaf, kLeafStride * e + 2u); }
+						if (COUNT && (t < c_ten - 1e-4f * fabsf(c_ten) || t > ex_t + 1e-4f * fabsf(ex_t))) c_tail_out++;
 							const float a_u = __uint_as_float(B.x), a_v = __uint_as_float(B.y);
 							const float b_nu = __uint_as_float(B.z), b_nv = __uint_as_float(B.w);
 							const float c_nu = __uint_as_float(C.x), c_nv = __uint_as_float(C.y);
@@ -1120,6 +1125,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				else {
 					// --- pop: the exit point becomes the entry point ---
 					enx = exx; eny = exy; enz = exz;
+					if (COUNT) c_ten = ex_t;
 					cur = ex_node;
 					if (cur == kNullNode) {
 						finished = true;
@@ -1154,9 +1160,9 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 
 	if (COUNT) {
 		// wave reduction, then one atomic per wave and counter
-		unsigned long long v[15] = { c_inner, c_leaf, c_idx, c_tri, w_inner, w_leaf, w_outer, w_batch, g_pair, l_pair, g_node, l_node, g_tail, g_spill, g_head };
+		unsigned long long v[16] = { c_inner, c_leaf, c_idx, c_tri, w_inner, w_leaf, w_outer, w_batch, g_pair, l_pair, g_node, l_node, g_tail, g_spill, g_head, c_tail_out };
 		#pragma unroll
-		for (int k = 0; k < 15; ++k) {
+		for (int k = 0; k < 16; ++k) {
 			unsigned long long x = v[k];
 			for (int off = 32; off > 0; off >>= 1)
 				x += __shfl_down(x, off);
