@@ -119,6 +119,7 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	if (segCap * kBinShards > 0xFFFFFFFFull) return fail(c, MTSGPU_EINVAL, "pass too large");
 	c->q.bin_seg_cap = (uint32_t) segCap;
 	rc |= devAlloc(c, &c->queueA, cap, o); rc |= devAlloc(c, &c->queueB, cap, o);
+	for (int k = 0; k < 2; ++k) { rc |= devAlloc(c, &c->rayqA[k], cap, o); rc |= devAlloc(c, &c->rayqB[k], cap, o); }
 	rc |= devAlloc(c, &c->q.shadow, cap, o);
 	rc |= devAlloc(c, &c->counterSets, (size_t) kCounterSets * kNumCounters * kCounterStride, o);
 	rc |= devAlloc(c, &c->viewsDev, kNumBins, o);
@@ -222,6 +223,18 @@ hipEvent_t *nextEventPair(mtsgpu_ctx *c, std::vector<std::pair<hipEvent_t, hipEv
 	return &pool[used++].first;
 }
 
+long tuningOr(const mtsgpu_ctx *c, const char *key, long dflt);
+// The rays of the two closest-hit queues in queue order (kernels.h: DPaths::rq_*): the traversal reads those of `cur`, the
+// kernel that fills `nxt` writes them.  NULL (or the "ray_queues" knob at 0): records only.
+void rayQueues(mtsgpu_ctx *c, const uint32_t *cur, const uint32_t *nxt) {
+	const bool on = tuningOr(c, "ray_queues", 1) != 0;
+	auto of = [&](const uint32_t *q, int k) -> float4 * { return !on || !q ? nullptr : (q == c->queueA ? c->rayqA[k] : (q == c->queueB ? c->rayqB[k] : nullptr)); };
+	c->paths.rq_o = of(cur, 0); c->paths.rq_d = of(cur, 1); c->paths.rqn_o = of(nxt, 0); c->paths.rqn_d = of(nxt, 1);
+}
+// ... and outside the bounce loops nobody reads or writes them (test hooks and the replay measurement trace rays they put
+// into the records)
+struct RayQueuesOff { mtsgpu_ctx *c; ~RayQueuesOff() { rayQueues(c, nullptr, nullptr); } };
+
 // an event pair for a traversal launch of class cls (ctx.h: traceEvClass)
 hipEvent_t *nextTraceEvents(mtsgpu_ctx *c, int cls) {
 	hipEvent_t *ev = nextEventPair(c, c->traceEvents, c->traceEvUsed);
@@ -295,7 +308,10 @@ int runDirectRounds(mtsgpu_ctx *c, const DConfig &cfg0, uint32_t nPaths, volatil
 	HIPCHK(c, hipMemsetAsync(c->q.counters, 0, counterBytes, s));
 	c->q.next = c->queueB;
 	BinView views[kNumBins];
+	RayQueuesOff rqOff{ c };
+	rayQueues(c, c->queueA, nullptr);        // the camera rays; the rays of the sampling rounds are traced from the records
 	int rc = traceAndBin(c, c->queueA, nPaths, true, views); if (rc) return rc;
+	rayQueues(c, nullptr, nullptr);
 	c->stats.rays_closest += nPaths;
 	auto shadeRound = [&](int mode, int index, bool withTerminal) -> int {
 		hipEvent_t *sev = c->timeKernels ? nextEventPair(c, c->shadeEvents, c->shadeEvUsed) : nullptr;
@@ -377,6 +393,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 			c->q.dev_stats = nullptr; c->q.counters = c->counterSets; c->q.spill = c->spillClosest;
 		}
 	} restore{ c, s2, shadowPending };
+	RayQueuesOff rqOff{ c };
 	// cls >= 0: a traversal launch of that class (ctx.h: traceEvClass)
 	auto timed = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used, hipStream_t s, int which, int cls = -1) -> int {
 		if (!c->timeKernels) return 0;
@@ -391,6 +408,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 		for (; b < end; ++b) {
 			uint32_t *set = counterSet(c, b), *prev = counterSet(c, b - 1);
 			c->q.counters = set; c->q.next = nxt; c->q.spill = c->spillClosest;
+			rayQueues(c, cur, nxt);
 			int rc = timed(c->traceEvents, c->traceEvUsed, s1, 0, b == 0 ? 1 : 0); if (rc) return rc;
 			launch_trace(s1, 0, c->countTraversal, true, c->dsc, c->paths, c->q, cur, upper, b == 0,
 			             b == 0 ? nullptr : prev + (size_t) kNextWord);
@@ -468,6 +486,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 	const size_t setBytes = (size_t) kNumCounters * kCounterStride * sizeof(uint32_t);
 	bool shadowPending = false;
 	int b = 0;
+	RayQueuesOff rqOff{ c };
 	for (; nQ > 0; ++b) {
 		if (cancel && *cancel)
 			return fail(c, MTSGPU_ECANCEL, "render cancelled");
@@ -475,6 +494,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		c->q.counters = counterSet(c, b); c->q.spill = c->spillClosest;
 		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, setBytes, s));
 		c->q.next = nxt;
+		rayQueues(c, cur, nxt);
 		// closest hit + material sort
 		BinView views[kNumBins];
 		int rc = traceAndBin(c, cur, nQ, first, views); if (rc) return rc;
@@ -1051,7 +1071,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 }, { "ray_queues", 0, 1 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);
@@ -1195,7 +1215,9 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 			launch_ld_tables(c->stream, cfg, c->pixelList + base, nSlots, c->ldScr, c->ldPerm, c->ldState, c->ldScratch);
 			launch_sample_arrays(c->stream, cfg, nSlots, c->ldState);
 		}
+		rayQueues(c, nullptr, c->queueA);
 		launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList + base, nSlots, nullptr, nPaths, c->queueA);
+		rayQueues(c, nullptr, nullptr);
 		HIPCHK(c, hipGetLastError());
 		c->lastPass.valid = true; c->lastPass.cfg = cfg; c->lastPass.base = base;
 		c->lastPass.nSlots = nSlots; c->lastPass.nPaths = nPaths; c->lastPass.shadowMax = 0;
@@ -1520,7 +1542,9 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 		launch_ld_tables(c->stream, cfg, c->pixelList, n, c->ldScr, c->ldPerm, c->ldState, c->ldScratch);
 		launch_sample_arrays(c->stream, cfg, n, c->ldState);
 	}
+	rayQueues(c, nullptr, c->queueA);
 	launch_generate(c->stream, c->dsc, c->paths, cfg, c->pixelList, n, c->explicitSamples, n, c->queueA);
+	rayQueues(c, nullptr, nullptr);
 	HIPCHK(c, hipGetLastError());
 	HIPCHK(c, hipMemsetAsync(c->devStats, 0, kNumDevStats * sizeof(unsigned long long), c->stream));
 	c->devStatsUsed = false;

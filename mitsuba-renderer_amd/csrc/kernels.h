@@ -129,6 +129,11 @@ struct DPaths {
 	// MIDirectIntegrator with several BSDF samples: the camera ray and its hit, [id][3] (ray_o, ray_d, hit), kept
 	// while the record carries the ray of the current BSDF sample
 	float4 *prim;
+	// The rays of a closest-hit queue once more, in QUEUE order (entry i = ray_o / ray_d of the path queue[i]): the kernel that
+	// fills a queue (k_generate, k_shade) streams them out next to the ids -- rqn_*, the queue being filled -- and
+	// k_trace<closest> streams them in -- rq_*, the queue being traced -- instead of gathering one random 128-byte line
+	// per ray behind the id (a dependent trip, 64 lines per load instruction).  NULL = not kept / read the records.
+	float4 *rq_o, *rq_d, *rqn_o, *rqn_d;
 };
 
 // flags in Li.w

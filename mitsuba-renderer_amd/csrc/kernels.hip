@@ -649,6 +649,7 @@ __global__ __launch_bounds__(kGenBlock) void k_generate(DScene sc, DPaths ps, DC
 	reinterpret_cast<uint4 &>(row[6]) = make_uint4((uint32_t) (smp.stream & 0xFFFFFFFFull), (uint32_t) (smp.stream >> 32), j, pixel);   // misc
 	row[7] = make_float4(sx, sy, 0.0f, 0.0f);                          // spos
 	queue[id] = id;
+	if (ps.rqn_o) { st_stream<4>(&ps.rqn_o[id], row[0]); st_stream<4>(&ps.rqn_d[id], row[1]); }      // the camera rays in queue order
 	}
 	// program order suffices inside a wave (every row is written and read by the same wave)
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -927,7 +928,8 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					a = ld_stream<1>(&ps.shq_o[my]); b = ld_stream<1>(&ps.shq_d[my]);
 					rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
 				} else {
-					a = ld_stream<1>(&ps.ray_o(id)); b = ld_stream<1>(&ps.ray_d(id));
+					if (MODE == 0 && BIN && ps.rq_o) { a = ld_stream<1>(&ps.rq_o[my]); b = ld_stream<1>(&ps.rq_d[my]); }    // in queue order: no trip behind the id
+					else { a = ld_stream<1>(&ps.ray_o(id)); b = ld_stream<1>(&ps.ray_d(id)); }
 					rmint = a.w; rmaxt = b.w;
 				}
 				ox = a.x; oy = a.y; oz = a.z; dx = b.x; dy = b.y; dz = b.z;
@@ -2429,7 +2431,14 @@ __device__ __forceinline__ void shade_block(const DScene &sc, const DPaths &ps, 
 	uint32_t offN = s_base[0], offS = s_base[1];
 	for (uint32_t w = 0; w < wave; ++w) { offN += s_cnt[0][w]; offS += s_cnt[1][w]; }
 	const unsigned long long below = (1ull << lane) - 1ull;
-	if (continues) q.next[offN + (uint32_t) __popcll(mN & below)] = id;
+	if (continues) {
+		const uint32_t pos = offN + (uint32_t) __popcll(mN & below);
+		q.next[pos] = id;
+		if (ps.rqn_o) {       // the new ray once more, in the order of the queue it was appended to
+			st_stream<4>(&ps.rqn_o[pos], rows[shade_row_index(lane, 0)]);
+			st_stream<4>(&ps.rqn_d[pos], rows[shade_row_index(lane, 1)]);
+		}
+	}
 	if (wantShadow) {
 		// the shadow ray lives in queue order (coalesced for both kernels); the path id rides in nee.w
 		const uint32_t pos = offS + (uint32_t) __popcll(mS & below);
