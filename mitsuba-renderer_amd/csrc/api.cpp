@@ -76,6 +76,7 @@ void applyTuning(mtsgpu_ctx *c) {
 	c->q.tune_blocks_per_cu = (uint32_t) get("blocks_per_cu", 0);
 	c->q.tune_plain_below = (uint32_t) get("plain_below", 0);
 	c->q.tune_dyn_min_rounds = (uint32_t) get("dyn_min_rounds", 0);
+	c->q.bin_hits = c->binHits;
 }
 
 // size of the full film the crop window lies in (film.cpp:33-41); without a crop window the film itself
@@ -115,6 +116,8 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	const unsigned gridBlocksMax = c->nCUs * kTraceBlocksPerCuMax;
 	const size_t segCap = cap / kBinShards + cap / (4 * kBinShards) + (size_t) kTraceBlock * (gridBlocksMax / kBinShards + 2);
 	rc |= devAlloc(c, &c->q.bins_base, segCap * kBinShards * kNumBins, o);
+	rc |= devAlloc(c, &c->binHits, segCap * kBinShards * kNumBins, o);
+	applyTuning(c);                  // DQueues::bin_hits follows the allocation
 	c->q.bin_stride = (uint32_t) (segCap * kBinShards);
 	if (segCap * kBinShards > 0xFFFFFFFFull) return fail(c, MTSGPU_EINVAL, "pass too large");
 	c->q.bin_seg_cap = (uint32_t) segCap;

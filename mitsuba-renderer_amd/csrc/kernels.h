@@ -189,6 +189,10 @@ struct DQueues {
 	uint32_t *bins_base;
 	uint32_t bin_stride;
 	uint32_t bin_seg_cap;
+	// the hit (t, u, v, primitive) of every binned path next to its id, same index: the closest-hit kernel appends both in one
+	// stream and the shading reads both in one -- otherwise the hit is a 16-byte store into a random path record (a partial
+	// line: read, merged, written back).  Launches without the material sort leave their hits in the path records.
+	uint4 *bin_hits;
 	__host__ __device__ uint32_t *bin(int b) const { return bins_base + (size_t) b * bin_stride; }
 	uint32_t *next;               // paths that continue (input of the next closest-hit launch)
 	uint32_t *shadow;             // paths with a pending shadow ray

@@ -865,8 +865,9 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 			// ---- retire the finished rays (all lanes take part in the ballots) ----
 			if (MODE == 0) {
 				int bin = -1;
+				constexpr bool hitsToBins = BIN;      // a binned path's hit travels with its id (DQueues::bin_hits)
 				if (done) {
-					st_stream<1>(&ps.hit(id), make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim));
+					if (!hitsToBins) st_stream<1>(&ps.hit(id), make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim));
 					if (BIN) {
 						bin = kNumBins - 1;
 						if (found) {
@@ -892,8 +893,11 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					// can in principle exceed it: the entry is dropped then, the counter still counts it, and the host
 					// repeats the launch with static dealing when it sees a count above the capacity
 					const uint32_t pos = base + rank;
-					if (bin >= 0 && pos < q.bin_seg_cap)
-						st_stream<1>(&q.bins_base[(size_t) bin * q.bin_stride + (size_t) shard * q.bin_seg_cap + pos], id);
+					if (bin >= 0 && pos < q.bin_seg_cap) {
+						const size_t at = (size_t) bin * q.bin_stride + (size_t) shard * q.bin_seg_cap + pos;
+						st_stream<1>(&q.bins_base[at], id);
+						if (hitsToBins) st_stream<1>(&q.bin_hits[at], make_uint4(__float_as_uint(best_t), __float_as_uint(best_u), __float_as_uint(best_v), best_prim));
+					}
 				}
 			} else if (MODE == 1) {
 				// Scene::sampleLuminaire's visibility test passed: add the pending contribution (path.cpp:124)
@@ -2342,12 +2346,18 @@ __device__ __forceinline__ void shade_block(const DScene &sc, const DPaths &ps, 
 		return;                            // (uniform) a grid sized for the worst case
 	const bool active = gtid < total;
 	uint32_t id = 0u;
+	uint4 binHit = make_uint4(0u, 0u, 0u, kNoPrim); bool haveBinHit = false;
 	if (active) {
 		int seg = 0;
 		#pragma unroll
 		for (int k = 1; k < kBinShards; ++k)
 			if (gtid >= prefix[k]) seg = k;
-		id = bin_ids[(size_t) seg * q.bin_seg_cap + (gtid - prefix[seg])];
+		const size_t at = (size_t) seg * q.bin_seg_cap + (gtid - prefix[seg]);
+		id = bin_ids[at];
+		// the hit came with the id when the closest-hit kernel filled this bin (DQueues::bin_hits)
+		if (q.bin_hits && bin_ids >= q.bins_base && bin_ids < q.bins_base + (size_t) kNumBins * q.bin_stride) {
+			binHit = q.bin_hits[(size_t) (bin_ids - q.bins_base) + at]; haveBinHit = true;
+		}
 	}
 	// ---- the path records of the wave, staged through LDS ----
 	// The ids come from a material-sorted queue, so every lane owns a different 128-byte line.  Read field by field
@@ -2373,6 +2383,7 @@ __device__ __forceinline__ void shade_block(const DScene &sc, const DPaths &ps, 
 	float4 ro = make_float4(0, 0, 0, 0), rd = ro, T4 = ro, L4 = ro;
 	uint4 h = make_uint4(0u, 0u, 0u, kNoPrim);
 	if (active) {
+		if (haveBinHit) reinterpret_cast<uint4 &>(row[2]) = binHit;      // ... and goes into the record with the write-back below
 		ro = row[0]; rd = row[1]; h = reinterpret_cast<const uint4 &>(row[2]); T4 = row[3]; L4 = row[4];
 		if (ROUNDS && cfg.dr_mode == 2) {
 			// rounds of MIDirectIntegrator: later BSDF samples start again from the camera hit (kept in ps.prim)
