@@ -236,7 +236,7 @@ void rayQueues(mtsgpu_ctx *c, const uint32_t *cur, const uint32_t *nxt) {
 }
 // ... and outside the bounce loops nobody reads or writes them (test hooks and the replay measurement trace rays they put
 // into the records)
-struct RayQueuesOff { mtsgpu_ctx *c; ~RayQueuesOff() { rayQueues(c, nullptr, nullptr); } };
+struct RayQueuesOff { mtsgpu_ctx *c; ~RayQueuesOff() { rayQueues(c, nullptr, nullptr); c->q.nee_parked = 0; } };
 
 // an event pair for a traversal launch of class cls (ctx.h: traceEvClass)
 hipEvent_t *nextTraceEvents(mtsgpu_ctx *c, int cls) {
@@ -397,6 +397,7 @@ int runBouncesDevice(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatil
 		}
 	} restore{ c, s2, shadowPending };
 	RayQueuesOff rqOff{ c };
+	c->q.nee_parked = tuningOr(c, "nee_parked", 1) != 0 ? 1u : 0u;
 	// cls >= 0: a traversal launch of that class (ctx.h: traceEvClass)
 	auto timed = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &pool, size_t &used, hipStream_t s, int which, int cls = -1) -> int {
 		if (!c->timeKernels) return 0;
@@ -490,6 +491,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 	bool shadowPending = false;
 	int b = 0;
 	RayQueuesOff rqOff{ c };
+	c->q.nee_parked = tuningOr(c, "nee_parked", 1) != 0 ? 1u : 0u;
 	for (; nQ > 0; ++b) {
 		if (cancel && *cancel)
 			return fail(c, MTSGPU_ECANCEL, "render cancelled");
@@ -1074,7 +1076,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 }, { "ray_queues", 0, 1 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 }, { "ray_queues", 0, 1 }, { "nee_parked", 0, 1 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);
@@ -1552,9 +1554,10 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 	HIPCHK(c, hipMemsetAsync(c->devStats, 0, kNumDevStats * sizeof(unsigned long long), c->stream));
 	c->devStatsUsed = false;
 	rc = runBounces(c, cfg, n, nullptr); if (rc) return rc;
-	std::vector<float> Li(4 * (size_t) n), thr(4 * (size_t) n), spos(4 * (size_t) n);
+	std::vector<float> Li(4 * (size_t) n), thr(4 * (size_t) n), spos(4 * (size_t) n), parked(4 * (size_t) n);
 	const size_t pitch = kPathSlots * sizeof(float4);
 	HIPCHK(c, hipMemcpy2DAsync(Li.data(), 16, c->paths.base + 4, pitch, 16, n, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpy2DAsync(parked.data(), 16, c->paths.base + 2, pitch, 16, n, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipMemcpy2DAsync(thr.data(), 16, c->paths.base + 3, pitch, 16, n, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipMemcpy2DAsync(spos.data(), 16, c->paths.base + 7, pitch, 16, n, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1562,7 +1565,10 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 		uint32_t flags; int depth;
 		std::memcpy(&flags, &Li[4 * i + 3], 4); std::memcpy(&depth, &thr[4 * i + 3], 4);
 		float *o = out + 8 * i;
-		o[0] = Li[4 * i]; o[1] = Li[4 * i + 1]; o[2] = Li[4 * i + 2]; o[3] = (flags & F_ALPHA) ? 1.0f : 0.0f;
+		// a direct-light term still parked in the record of a path that has ended (DQueues::nee_parked)
+		const float4 L = settled_Li(make_float4(Li[4 * i], Li[4 * i + 1], Li[4 * i + 2], 0.0f),
+		                            make_float4(parked[4 * i], parked[4 * i + 1], parked[4 * i + 2], parked[4 * i + 3]));
+		o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = (flags & F_ALPHA) ? 1.0f : 0.0f;
 		o[4] = spos[4 * i]; o[5] = spos[4 * i + 1]; o[6] = (float) depth; o[7] = 0.0f;
 	}
 	collectTimings(c);

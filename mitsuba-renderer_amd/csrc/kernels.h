@@ -222,7 +222,20 @@ struct DQueues {
 	uint32_t tune_dyn_min_rounds;      // launches of at least this many rounds claim their last rounds dynamically (0 = 8)
 	uint32_t tune_blocks_per_cu;       // experiment: fewer resident workgroups of kTraceBlock threads per CU than trace_blocks_per_cu(mode)
 	                                   // (3 closest-hit / 4 shadow at 512 threads); 0 or a value >= that = all.  Range 0..kTraceBlocksPerCuMax
+	// The direct-light term of a shadow ray that came through (path.cpp:124: Li += ...): 0 = the any-hit kernel adds it to the
+	// path's radiance itself (a random line read and a partial-line write per ray, with the wave waiting for the read);
+	// 1 = it PARKS the term in slot 2 of the path record, tagged kNeeTag (one 16-byte store, nobody waits), and whoever reads
+	// the record next adds it first -- the path's next shading, or the film kernels if the path has ended.  Same addition,
+	// same place in the path's order of sums.  Slot 2 is free for it: the hits of binned paths travel with the bins.
+	uint32_t nee_parked;
 };
+constexpr uint32_t kNeeTag = 0x4E454521u;      // not a primitive index (< 2^29) and not kNoPrim
+// the radiance of a path record with a parked direct-light term added (what every reader of a finished path sees)
+__host__ __device__ inline float4 settled_Li(float4 L, float4 parked) {
+	union { float f; uint32_t u; } w; w.f = parked.w;
+	if (w.u == kNeeTag) { L.x += parked.x; L.y += parked.y; L.z += parked.z; }
+	return L;
+}
 
 // How one traversal launch over n rays is scheduled.  A pure function of (n, mode, q): the host evaluates it to size
 // the grid when it knows n, the kernel evaluates it again -- with n read from device memory when the host does not

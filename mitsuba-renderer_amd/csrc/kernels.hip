@@ -904,9 +904,14 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				if (done && !found) {
 					const float4 c = ps.shq_nee[id];            // id = position in the shadow queue; c.w = path id
 					const uint32_t pid = __float_as_uint(c.w);
-					float4 L = ps.Li(pid);
-					L.x += c.x; L.y += c.y; L.z += c.z;
-					ps.Li(pid) = L;
+					if (q.nee_parked) {
+						// parked in the record (DQueues::nee_parked): its next reader adds it
+						ps.slot(pid, 2) = make_float4(c.x, c.y, c.z, __uint_as_float(kNeeTag));
+					} else {
+						float4 L = ps.Li(pid);
+						L.x += c.x; L.y += c.y; L.z += c.z;
+						ps.Li(pid) = L;
+					}
 				}
 			} else {
 				if (done)
@@ -2383,8 +2388,15 @@ __device__ __forceinline__ void shade_block(const DScene &sc, const DPaths &ps, 
 	float4 ro = make_float4(0, 0, 0, 0), rd = ro, T4 = ro, L4 = ro;
 	uint4 h = make_uint4(0u, 0u, 0u, kNoPrim);
 	if (active) {
-		if (haveBinHit) reinterpret_cast<uint4 &>(row[2]) = binHit;      // ... and goes into the record with the write-back below
-		ro = row[0]; rd = row[1]; h = reinterpret_cast<const uint4 &>(row[2]); T4 = row[3]; L4 = row[4];
+		// a direct-light term the any-hit kernel parked in slot 2 (DQueues::nee_parked) is added before anything else of this
+		// Li iteration, where the sequential loop adds it (path.cpp:124)
+		const float4 slot2 = row[2];
+		L4 = settled_Li(row[4], slot2);
+		h = haveBinHit ? binHit : reinterpret_cast<const uint4 &>(slot2);
+		// what the write-back below leaves in slot 2: nothing while terms are parked there, otherwise the hit
+		if (q.nee_parked) row[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		else reinterpret_cast<uint4 &>(row[2]) = h;
+		ro = row[0]; rd = row[1]; T4 = row[3];
 		if (ROUNDS && cfg.dr_mode == 2) {
 			// rounds of MIDirectIntegrator: later BSDF samples start again from the camera hit (kept in ps.prim)
 			if (cfg.dr_index > 0) {
@@ -2516,7 +2528,7 @@ __global__ void k_accumulate(DPaths ps, DConfig cfg, uint32_t n_slots, uint32_t 
 	float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
 	for (uint32_t j = 0; j < spp; ++j) {
 		const size_t id = (size_t) slot * spp + j;
-		const float4 L = ps.Li(id);
+		const float4 L = settled_Li(ps.Li(id), ps.slot(id, 2));
 		const float4 sp = ps.spos(id);
 		if (path_len) depthSum += (unsigned long long) __float_as_int(ps.thr(id).w);      // same 128-byte line as Li / spos
 		// Spectrum::isValid (spectrum.h:285-290)
@@ -2579,7 +2591,7 @@ __global__ __launch_bounds__(256) void k_accumulate_wave(DPaths ps, DConfig cfg,
 		const uint32_t j = j0 + lane;
 		const bool have = j < spp;
 		const size_t id = (size_t) slot * spp + (have ? j : spp - 1u);
-		const float4 L = ps.Li(id);
+		const float4 L = settled_Li(ps.Li(id), ps.slot(id, 2));
 		const float4 sp = ps.spos(id);
 		if (path_len && have) depthSum += (unsigned long long) __float_as_int(ps.thr(id).w);
 		// this lane's sample: valid (Spectrum::isValid, spectrum.h:285-290)?  which film pixels does it reach with weight one?
@@ -2632,7 +2644,7 @@ __global__ __launch_bounds__(256) void k_accumulate_wave(DPaths ps, DConfig cfg,
 				const uint32_t jEnd = min(j0 + 64u, spp);
 				for (uint32_t jj = j0; jj < jEnd; ++jj) {
 					const size_t i2 = (size_t) slot * spp + jj;
-					const float4 L2 = ps.Li(i2);
+					const float4 L2 = settled_Li(ps.Li(i2), ps.slot(i2, 2));
 					const float4 s2 = ps.spos(i2);
 					if (L2.x != L2.x || L2.x < 0.0f || L2.y != L2.y || L2.y < 0.0f || L2.z != L2.z || L2.z < 0.0f) continue;
 					const float al2 = (__float_as_uint(L2.w) & F_ALPHA) ? 1.0f : 0.0f;
@@ -2802,7 +2814,7 @@ __global__ __launch_bounds__(256) void k_splat_blocks(DPaths ps, DConfig cfg, co
 				for (int px = pxLo; px <= pxHi; ++px) {
 					const size_t first = ((size_t) tm.slot_base + (size_t) (py - tm.y0) * tm.w + (px - tm.x0)) * spp;
 					for (uint32_t j = 0; j < spp; ++j) {
-						const float4 L = ps.Li(first + j);
+						const float4 L = settled_Li(ps.Li(first + j), ps.slot(first + j, 2));
 						const float4 sp = ps.spos(first + j);
 						if (L.x != L.x || L.x < 0.0f || L.y != L.y || L.y < 0.0f || L.z != L.z || L.z < 0.0f)
 							continue;                                   // Spectrum::isValid
