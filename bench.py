@@ -50,12 +50,11 @@ def algorithmic_bytes(st):
 
 
 def issued_requests(st):
-    """Lane-level vector-memory requests the traversal kernels ISSUED in the counting step (mtsgpu_stats.req_*): sibling
+    """Lane-level vector-memory GATHERS the traversal kernels issued in the counting step (mtsgpu_stats.req_*): sibling
     pairs and single nodes that were not served by the LDS copy of the top of the tree, one record head per index entry,
-    the record tails, stack spills, and per ray the ray (2 x 16 B) and the hit (16 B; for a shadow ray: origin,
-    direction, and the pending term when it is unoccluded)."""
-    rays = st["rays_closest"] + st["rays_shadow"]
-    return st["req_pair_global"] + st["req_node_global"] + st["req_head"] + st["req_tail"] + st["req_spill"] + 3 * rays
+    the record tails, stack spills.  Rays, queue ids, binned ids + hits and shadow rays move in queue order (streams: about
+    five 4- to 16-byte accesses per closest-hit ray, three per any-hit ray) and are not counted here."""
+    return st["req_pair_global"] + st["req_node_global"] + st["req_head"] + st["req_tail"] + st["req_spill"]
 
 
 def shade_algorithmic_bytes(st):
@@ -480,13 +479,13 @@ def main():
                   "what": "each class of traversal launch against a replay of its own request stream (mtsgpu_replay_roof: the same lines in "
                           "the same per-ray order, one 16-byte load each, eight independent requests in flight per lane, no arithmetic, "
                           "grid and LDS footprint of the closest-hit kernel).  A throughput test of the memory system on these lines, "
-                          "not a bound: other issue orders may be faster.  Not replayed: queue-id and shadow-ray loads (streamed), "
-                          "stack spills, the extra chunks of sphere primitives",
+                          "not a bound: other issue orders may be faster.  Not replayed: what moves in queue order (queue ids, rays, "
+                          "binned ids and hits, shadow rays), stack spills, the extra chunks of sphere primitives",
                   "issued_requests_per_ray": req_per_step / max(rays, 1),
                   "lds_served_requests_per_ray": (counts["req_pair_lds"] + counts["req_node_lds"]) / max(rays, 1),
                   "issued_breakdown_per_ray": {"pairs": counts["req_pair_global"] / max(rays, 1), "pop_nodes": counts["req_node_global"] / max(rays, 1),
                                                "record_heads": counts["req_head"] / max(rays, 1), "record_tails": counts["req_tail"] / max(rays, 1),
-                                               "stack_spills": counts["req_spill"] / max(rays, 1), "ray_and_hit": 3.0},
+                                               "stack_spills": counts["req_spill"] / max(rays, 1)},
                   "random_gather_4MiB_G_per_s": gather / 1e9 if gather else None,
                   "note": replay_note}
         if replay_raw:

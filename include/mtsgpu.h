@@ -349,15 +349,17 @@ int  mtsgpu_hbm_triad(int device, size_t bytes, int iters, double *gbs);
 int  mtsgpu_gather_roof(int device, size_t footprint_bytes, double *lane_requests_per_s);
 /* Measurement: a traversal kernel against a replay of its own request stream.  A sample of n rays of the frame rendered
  * last is traced once with the counting kernel, which records every vector-memory request of every ray (which sibling
- * pair, node, leaf-record chunk, path-record slot; not recorded: the loads of queue ids and shadow rays, which are
- * streamed, stack words spilled to HBM, and the two extra chunks of a sphere primitive); then (a) the product kernel of
+ * pair, node, leaf-record chunk; not recorded: what the kernel streams in and out in queue order -- queue ids, rays,
+ * the ids and hits appended to the material bins -- stack words spilled to HBM, and the two extra chunks of a sphere
+ * primitive); then (a) the product kernel of
  * that class and (b) a kernel that re-issues exactly those requests are timed: per ray in the recorded order, one 16-byte
  * load per request from the line the traversal asked for, eight independent requests in flight per lane, the grid shape
  * and LDS footprint of the closest-hit kernel, NO arithmetic, no stack, no mailbox, no dependence between the requests.
  * (b) is ONE throughput test of the memory system on this set of lines, not a bound: other issue orders may be faster.
  * kind selects the sample and the product kernel:
  *   0  every stride-th of the first n * stride path records -- after mtsgpu_render() each holds the LAST ray of its
- *      path -- with the closest-hit kernel as the bounces launch it (material binning on);
+ *      path; the rays are copied into queue order first -- with the closest-hit kernel as the bounces launch it
+ *      (material binning on);
  *   1  the camera rays of the pass rendered last, generated again (the path records are overwritten), every stride-th,
  *      with the closest-hit kernel in the plain 64-ray batches of a first bounce;
  *   2  every stride-th slot of the shadow queue as the frame left it (slot i holds the ray of the deepest bounce that

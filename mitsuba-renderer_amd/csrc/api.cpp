@@ -1361,15 +1361,20 @@ int mtsgpu_replay_roof(mtsgpu_ctx *c, int kind, uint32_t n, uint32_t stride, int
 		RR_CHK(hipMemcpyAsync(c->paths.shq_nee, tmp + 2 * (size_t) n, (size_t) n * sizeof(float4), hipMemcpyDeviceToDevice, s));
 		c->lastPass.shadowMax = 0;             // the queue is no longer the frame's
 	} else {
-		launch_iota_strided(s, c->queueA, n, stride);       // every stride-th path record
+		// every stride-th path record, its ray copied into queue order the way the bounces hand rays to this kernel
+		launch_iota_strided(s, c->queueA, n, stride);
+		launch_gather_strided(s, c->rayqA[0], c->paths.base + 0, n, stride * kPathSlots);
+		launch_gather_strided(s, c->rayqA[1], c->paths.base + 1, n, stride * kPathSlots);
+		rayQueues(c, c->queueA, nullptr);
 	}
+	RayQueuesOff rqOff{ c };
 	const uint32_t *queue = mode == 1 ? c->q.shadow : c->queueA;
 	// 1. the counting kernel records what every ray asks for
 	RR_CHK(hipMemsetAsync(recLen, 0, (size_t) n * 4, s));
 	RR_CHK(hipMemsetAsync(c->q.trace_counts, 0, kNumTraceCounts * sizeof(unsigned long long), s));
 	RR_CHK(hipMemsetAsync(c->q.counters, 0, counterBytes, s));
 	c->q.rec = rec; c->q.rec_len = recLen; c->q.rec_cap = cap;
-	launch_trace(s, mode, true, false, c->dsc, c->paths, c->q, queue, n, coherent);
+	launch_trace(s, mode, true, bin, c->dsc, c->paths, c->q, queue, n, coherent);
 	c->q.rec = c->q.rec_len = nullptr; c->q.rec_cap = 0;
 	RR_CHK(hipGetLastError());
 	std::vector<uint32_t> len(n);

@@ -930,14 +930,15 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 			MG_WSLOT(w_batch);
 			if (take) {
 				id = (MODE == 1) ? my : ld_stream<1>(&queue[my]);       // shadow rays are addressed by their queue position
-				if (COUNT && q.rec) { rec_slot = my; rec_n = 0; if (MODE != 1) { rec_add(kReqRay, id * kPathSlots); rec_add(kReqRay, id * kPathSlots + 1); } }
+				// (rays that arrive in queue order are streamed, like shadow rays: not part of the recorded request list)
+				if (COUNT && q.rec) { rec_slot = my; rec_n = 0; if (MODE != 1 && !(MODE == 0 && ps.rq_o)) { rec_add(kReqRay, id * kPathSlots); rec_add(kReqRay, id * kPathSlots + 1); } }
 				float4 a, b;
 				float rmint, rmaxt;
 				if (MODE == 1) {
 					a = ld_stream<1>(&ps.shq_o[my]); b = ld_stream<1>(&ps.shq_d[my]);
 					rmint = kShadowEpsilon; rmaxt = 1 - kShadowEpsilon;      // Scene::isOccluded, scene.h:241-246
 				} else {
-					if (MODE == 0 && BIN && ps.rq_o) { a = ld_stream<1>(&ps.rq_o[my]); b = ld_stream<1>(&ps.rq_d[my]); }    // in queue order: no trip behind the id
+					if (MODE == 0 && ps.rq_o) { a = ld_stream<1>(&ps.rq_o[my]); b = ld_stream<1>(&ps.rq_d[my]); }    // in queue order: no trip behind the id
 					else { a = ld_stream<1>(&ps.ray_o(id)); b = ld_stream<1>(&ps.ray_d(id)); }
 					rmint = a.w; rmaxt = b.w;
 				}
@@ -974,7 +975,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				found = false;
 				done = !go;       // a ray that misses the scene's box is finished at once
 				has = go;
-				if (COUNT && q.rec && !go) { if (MODE != 1) rec_add(kReqHit, id * kPathSlots + 2); q.rec_len[rec_slot] = rec_n; }
+				if (COUNT && q.rec && !go) { if (MODE != 1 && !(MODE == 0 && BIN)) rec_add(kReqHit, id * kPathSlots + 2); q.rec_len[rec_slot] = rec_n; }
 				if (go) {
 					if (kMbox) {
 						#pragma unroll
@@ -1162,7 +1163,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				}
 				if (finished) {
 					has = false; done = true; found = (MODE == 0) ? (best_prim != kNoPrim) : hitShadow;
-					if (COUNT && q.rec) { if (MODE != 1) rec_add(kReqHit, id * kPathSlots + 2); q.rec_len[rec_slot] = rec_n; }
+					if (COUNT && q.rec) { if (MODE != 1 && !(MODE == 0 && BIN)) rec_add(kReqHit, id * kPathSlots + 2); q.rec_len[rec_slot] = rec_n; }      // binned hits are streamed
 				}
 				}
 			}

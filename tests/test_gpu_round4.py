@@ -28,9 +28,9 @@ def test_issued_request_counters_add_up(gpu_lib, mts):
 
 
 def test_replay_roof_replays_what_the_kernel_asked_for(gpu_lib, mts):
-    """mtsgpu_replay_roof, all three classes of launches: the recorded lists hold exactly the requests the counters saw
-    (pairs + nodes from global memory, heads, tails; for closest-hit rays two loads of the ray and the store of the hit
-    as well), and both timings are positive"""
+    """mtsgpu_replay_roof, all three classes of launches: the recorded lists hold exactly the gathers the counters saw
+    (pairs + nodes from global memory, heads, tails -- rays, ids and hits move in queue order and are not part of the
+    lists), and both timings are positive"""
     sd = mts.scenes.cornell_c3(grid=48, sphere_subdiv=3)
     scene = mts.Scene(sd)
     cam = mts.PerspectiveCamera.for_description(sd, 128, 128)
@@ -40,11 +40,11 @@ def test_replay_roof_replays_what_the_kernel_asked_for(gpu_lib, mts):
     assert it.render()
     film = it.film().copy()
     n = 128 * 128 * 8 // 2
-    for kind, own in (("deep", 3 * n), ("shadow", 0), ("camera", 3 * n)):
+    for kind in ("deep", "shadow", "camera"):
         nk = n // 4 if kind == "shadow" else n
         rr = it.replay_roof(nk, stride=2, reps=1, kind=kind)
         assert rr["rays"] == nk and rr["truncated_rays"] == 0, kind
-        assert rr["requests"] == rr["pair_global"] + rr["node_global"] + rr["heads"] + rr["tails"] + (own if kind != "shadow" else 0) * nk // n, (kind, rr)
+        assert rr["requests"] == rr["pair_global"] + rr["node_global"] + rr["heads"] + rr["tails"], (kind, rr)
         assert rr["product_ms"] > 0 and rr["replay_ms"] > 0
     # camera rays start at the root: every one of them reads the LDS copy of the top of the tree
     assert rr["pair_lds"] >= nk
