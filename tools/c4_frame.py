@@ -1,5 +1,5 @@
 """One C4 frame (C3 scene, 1024^2, ldsampler 4096 spp, 58 passes) per setting of the knobs given:
-python3 tools/c4_frame.py [spp] [knob=v0,v1 ...]   e.g.  tools/c4_frame.py 4096 tables_ahead=0,1"""
+python3 tools/c4_frame.py [spp] [knob=v0,v1 ...]   e.g.  tools/c4_frame.py 4096 nee_parked=0,1"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import _pkgload
