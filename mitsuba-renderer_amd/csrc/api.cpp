@@ -480,8 +480,9 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		if (sf == 1 || (sf < 0 && nPaths <= (8u << 20)))
 			return runBouncesDevice(c, cfg, nPaths, cancel);
 	}
-	// measured on the 64-spp frame: two chip-filling persistent grids at once run 15 % slower than one after the other
-	// (they evict each other's working set), so the overlap is reserved for the short launches of device-driven frames
+	// measured on the 64-spp frame (profiles/r05k_*): two chip-filling persistent grids at once run a third slower than one after the other
+	// (the second one's workgroups do not pack into the holes the first one's leave), so the overlap is reserved for the short
+	// launches of device-driven frames
 	const bool overlap = tuningOr(c, "overlap", 0) != 0;
 	uint32_t nQ = nPaths;
 	uint32_t *cur = c->queueA, *nxt = c->queueB;
