@@ -35,11 +35,18 @@ for seed in range(first, first + count):
     it.preprocess(scene, cam, sampler=sampler, sampleCount=spp, seed=seed)
     op = orc.render_params(sd.max_depth, rr_depth=sd.rr_depth, strict_normals=int(seed & 1), sampler=kind, spp=spp, seed=seed,
                            integrator="direct" if direct else "path", luminaire_samples=nl, bsdf_samples=nb)
+    # who drives the bounces: 0 the default for a frame this small (device-driven, all material queues in one launch), 1 the host
+    # (one read-back per bounce, exact grids, dynamically claimed batches, one shading launch per BSDF type), 2 the host over
+    # several ragged passes, 3 device-driven with one shading launch per BSDF type
+    drive = (seed // 5) % 4
+    if drive == 1: it.set_tuning(sync_free=0)
+    elif drive == 2: it.set_tuning(sync_free=0); it.set_options(max_paths=spp * (W * H // 3 + 1))
+    elif drive == 3: it.set_tuning(sync_free=1, shade_fused=0)
     assert it.render()
     film = it.film()
     ofilm, _ = orc.render(oscene.scene, ocam, op)
     nbad = int((film.view(np.uint32) != ofilm.view(np.uint32)).any(axis=2).sum())
     bad_total += nbad + (0 if same else 1)
-    print("seed %d: %d tris, %s%s%s, tree %s, %d of %d pixels differ" % (seed, sd.n_tris, sampler, " %d spp" % spp if many else "", " direct(%d,%d)" % (nl, nb) if direct else "",
+    print("seed %d: %d tris, %s%s%s drive %d, tree %s, %d of %d pixels differ" % (seed, sd.n_tris, sampler, " %d spp" % spp if many else "", " direct(%d,%d)" % (nl, nb) if direct else "", drive,
                                                                        "same" if same else "DIFFERENT", nbad, W * H), flush=True)
 print("TOTAL mismatches:", bad_total)
