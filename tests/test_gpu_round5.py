@@ -128,3 +128,26 @@ print("rccl ok", dist.Backend.NCCL)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0 and b"rccl ok" in r.stdout, r.stderr.decode()[-2000:]
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_random_scenes_whoever_drives_the_bounces(gpu_lib, mts, orc, seed):
+    """random scenes (every BSDF type, mixed luminaires, spheres) rendered with each way of driving the bounces of a pass --
+    the device (one shading launch for all material queues, or one per BSDF type), the host (read-back per bounce, dynamically
+    claimed batches), the host over three ragged passes: the film equals the oracle's bit for bit every time
+    (tools/fuzz_parity.py sweeps the same over thousands of seeds: profiles/r05w_*)"""
+    sd = mts.scenes.fuzz(seed, n_meshes=6 + seed % 25)
+    scene = mts.Scene(sd); oscene = orc.FlatScene(sd)
+    W, H, spp = 40, 30, 8
+    sampler = ["independent", "ldsampler", "halton"][seed % 3]
+    kind = {"independent": 0, "ldsampler": 1, "halton": 2}[sampler]
+    cam = mts.PerspectiveCamera.for_description(sd, W, H); ocam = orc.make_camera(sd, W, H)
+    op = orc.render_params(sd.max_depth, rr_depth=sd.rr_depth, strict_normals=0, sampler=kind, spp=spp, seed=seed)
+    ofilm, _ = orc.render(oscene.scene, ocam, op)
+    it = mts.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth)
+    it.preprocess(scene, cam, sampler=sampler, sampleCount=spp, seed=seed)
+    for name, tuning, max_paths in (("device", dict(sync_free=1, shade_fused=1), 0), ("device, per type", dict(sync_free=1, shade_fused=0), 0),
+                                    ("host", dict(sync_free=0), 0), ("host, three passes", dict(sync_free=0), spp * (W * H // 3 + 1))):
+        it.set_tuning(**tuning); it.set_options(max_paths=max_paths)
+        it.clear_film(); assert it.render()
+        assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32)), name
