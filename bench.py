@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_M
 def kernel_source_hash():
     """identifies the kernels a committed PMC traffic record belongs to"""
     h = hashlib.sha256()
-    for f in ("kernels.hip", "kernels.h", "devmath.h"):
+    for f in ("trace.hip", "kernels.h", "kdevice.h", "devmath.h"):      # what k_trace is compiled from
         h.update(open(os.path.join(ROOT, "mitsuba-renderer_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -56,8 +56,9 @@ def load_serialized(path, shape_index=0, bsdf=-1, lum=-1, name=None):
         lib().mtsgpu_loaded_mesh_free(h)
 
 
-_SOURCES = ["api.cpp", "group.cpp", "kernels.hip", "kdbuild.cpp", "flatten.cpp", "serialized.cpp",       # SRCS, then HDRS of csrc/Makefile
-            "host.h", "ctx.h", "kernels.h", "devmath.h", os.path.join("..", "..", "include", "mtsgpu.h")]
+_SOURCES = ["api.cpp", "group.cpp", "sampler.hip", "film.hip", "trace.hip", "shade.hip", "measure.hip",   # SRCS, then HDRS of csrc/Makefile
+            "kdbuild.cpp", "flatten.cpp", "serialized.cpp",
+            "host.h", "ctx.h", "kernels.h", "kdevice.h", "sampler.h", "devmath.h", os.path.join("..", "..", "include", "mtsgpu.h")]
 
 
 def source_hash():

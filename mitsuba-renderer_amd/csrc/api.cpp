@@ -98,6 +98,23 @@ bool samplerHasTables(const mtsgpu_ctx *c) {
 	return c->samplerKind == MTSGPU_SAMPLER_LD_KEYED || c->samplerKind == MTSGPU_SAMPLER_STRATIFIED_KEYED;
 }
 
+// Device bytes ensurePaths() allocates per path of a pass: the 128-byte record, the shadow ray (3 x 16), the nine material
+// bins sized for the all-in-one-bin case with a quarter of headroom (id 4 + hit 16 bytes per entry), the two next queues
+// (id 4 + ray 32 bytes each) and the shadow queue's ids -- about 480 bytes, 34 GB for the default pass of 72 M paths.
+constexpr size_t kBytesPerPath = kPathSlots * 16 + 3 * 16 + (size_t) (kNumBins * (4 + 16) * 5 / 4) + 2 * (4 + 32) + 4;
+// Paths per pass when the caller set none (mtsgpu_set_options max_paths == 0): 72 M, or what 60 % of the free device memory
+// holds if that is less (the sampler tables, the film and the scene of a later upload need room too)
+uint64_t defaultMaxPaths(mtsgpu_ctx *c) {
+	uint64_t paths = 72ull << 20;
+	size_t freeB = 0, totalB = 0;
+	if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+		// what this context already holds for its passes is free for the next one
+		const uint64_t avail = (uint64_t) freeB + (uint64_t) c->pathCap * kBytesPerPath;
+		paths = std::min<uint64_t>(paths, std::max<uint64_t>(1ull << 16, avail * 6 / 10 / kBytesPerPath));
+	}
+	return paths;
+}
+
 int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	if (cap <= c->pathCap)
 		return 0;
@@ -713,6 +730,7 @@ int mtsgpu_set_stream(mtsgpu_ctx *c, void *hip_stream) {
 
 int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	if (!c || !sc) return fail(c, MTSGPU_EINVAL, "null argument");
+	c->lastPass.valid = false;
 	if (sc->abi_version != MTSGPU_ABI_VERSION) return fail(c, MTSGPU_EINVAL, "scene ABI version %u != %d", sc->abi_version, MTSGPU_ABI_VERSION);
 	if (sc->n_nodes == 0 || !sc->kd_nodes) return fail(c, MTSGPU_EINVAL, "scene has no kd-tree");
 	if (sc->n_lums == 0) return fail(c, MTSGPU_EINVAL, "scene has no luminaire (Scene::initialize would add a constant one, scene.cpp:310-318)");
@@ -965,6 +983,7 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 
 int mtsgpu_set_camera(mtsgpu_ctx *c, const mtsgpu_camera *cam) {
 	if (!c || !cam) return fail(c, MTSGPU_EINVAL, "null argument");
+	c->lastPass.valid = false;
 	if (cam->width <= 0 || cam->height <= 0 || (uint64_t) cam->width * (uint64_t) cam->height > 0x7FFFFFFFull)
 		return fail(c, MTSGPU_EINVAL, "bad film size %dx%d", cam->width, cam->height);
 	if (cam->kind != 0 && cam->kind != 1) return fail(c, MTSGPU_EINVAL, "unknown camera kind %d", cam->kind);
@@ -982,6 +1001,7 @@ int mtsgpu_set_camera(mtsgpu_ctx *c, const mtsgpu_camera *cam) {
 
 int mtsgpu_set_integrator(mtsgpu_ctx *c, int max_depth, int rr_depth, int strict_normals) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	c->lastPass.valid = false;      // mtsgpu_replay_roof regenerates a pass from its saved configuration: not across a setter
 	if (rr_depth <= 0) return fail(c, MTSGPU_EINVAL, "rrDepth == 0 breaks the computation of alpha values! (integrator.cpp:291)");
 	c->maxDepth = max_depth; c->rrDepth = rr_depth; c->strictNormals = strict_normals ? 1 : 0;
 	c->integrator = 0;
@@ -990,6 +1010,7 @@ int mtsgpu_set_integrator(mtsgpu_ctx *c, int max_depth, int rr_depth, int strict
 
 int mtsgpu_set_direct_integrator(mtsgpu_ctx *c, int luminaire_samples, int bsdf_samples) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	c->lastPass.valid = false;      // mtsgpu_replay_roof regenerates a pass from its saved configuration: not across a setter
 	if (luminaire_samples < 0 || bsdf_samples < 0 || luminaire_samples + bsdf_samples <= 0)
 		return fail(c, MTSGPU_EINVAL, "luminaireSamples + bsdfSamples must be > 0 (direct.cpp:41)");
 	if (luminaire_samples > 65536 || bsdf_samples > 65536)
@@ -1000,6 +1021,7 @@ int mtsgpu_set_direct_integrator(mtsgpu_ctx *c, int luminaire_samples, int bsdf_
 
 int mtsgpu_set_sampler(mtsgpu_ctx *c, int kind, uint32_t spp, int ld_depth, uint64_t seed) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	c->lastPass.valid = false;      // mtsgpu_replay_roof regenerates a pass from its saved configuration: not across a setter
 	if (kind < MTSGPU_SAMPLER_INDEPENDENT_KEYED || kind > MTSGPU_SAMPLER_STRATIFIED_KEYED) return fail(c, MTSGPU_EINVAL, "unknown sampler kind %d", kind);
 	if (spp == 0) return fail(c, MTSGPU_EINVAL, "sampleCount must be > 0");
 	if (kind == MTSGPU_SAMPLER_LD_KEYED && (roundToPow2(spp) > 65536u || ld_depth < 1 || ld_depth > 64))
@@ -1012,6 +1034,7 @@ int mtsgpu_set_sampler(mtsgpu_ctx *c, int kind, uint32_t spp, int ld_depth, uint
 
 int mtsgpu_set_tiles(mtsgpu_ctx *c, int block_size, int part, int n_parts) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	c->lastPass.valid = false;      // mtsgpu_replay_roof regenerates a pass from its saved configuration: not across a setter
 	if (block_size <= 0 || n_parts <= 0 || part < 0 || part >= n_parts) return fail(c, MTSGPU_EINVAL, "bad tile sharding %d/%d/%d", block_size, part, n_parts);
 	c->blockSize = block_size; c->part = part; c->nParts = n_parts;
 	return 0;
@@ -1019,6 +1042,7 @@ int mtsgpu_set_tiles(mtsgpu_ctx *c, int block_size, int part, int n_parts) {
 
 int mtsgpu_set_rfilter(mtsgpu_ctx *c, float size_x, float size_y, const float *values) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	c->lastPass.valid = false;      // mtsgpu_replay_roof regenerates a pass from its saved configuration: not across a setter
 	if (!values) { c->filtSizeX = c->filtSizeY = 0.5f; c->filtBorder = 0; return 0; }
 	if (!(size_x > 0) || !(size_y > 0) || size_x > 8 || size_y > 8) return fail(c, MTSGPU_EINVAL, "bad filter size");
 	HIPCHK(c, hipSetDevice(c->device));
@@ -1031,6 +1055,7 @@ int mtsgpu_set_rfilter(mtsgpu_ctx *c, float size_x, float size_y, const float *v
 
 int mtsgpu_set_film_edges(mtsgpu_ctx *c, int high_quality_edges) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
+	c->lastPass.valid = false;      // mtsgpu_replay_roof regenerates a pass from its saved configuration: not across a setter
 	c->hqEdges = high_quality_edges != 0;
 	return 0;
 }
@@ -1167,7 +1192,7 @@ int mtsgpu_render(mtsgpu_ctx *c, volatile const int *cancel) {
 
 	const bool wideFilter = c->filtBorder > 0;
 	if (wideFilter && 2 * c->filtBorder > bs) return fail(c, MTSGPU_EINVAL, "filter border %d too wide for block size %d", c->filtBorder, bs);
-	const uint64_t maxPaths = c->maxPaths ? c->maxPaths : (72ull << 20);
+	const uint64_t maxPaths = c->maxPaths ? c->maxPaths : defaultMaxPaths(c);
 	size_t slotsPerPass = (size_t) std::max<uint64_t>(1, std::min<uint64_t>(pixels.size(), maxPaths / spp));
 	if (wideFilter) slotsPerPass = std::max<size_t>(slotsPerPass, (size_t) bs * bs);     // passes hold whole tiles
 	if ((uint64_t) slotsPerPass * spp > 0x7FFFFFFFull) return fail(c, MTSGPU_EINVAL, "pass too large");

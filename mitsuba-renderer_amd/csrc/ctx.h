@@ -49,7 +49,7 @@ struct mtsgpu_ctx {
 	mg::DQueues q{};
 	uint32_t *queueA = nullptr, *queueB = nullptr;
 	float4 *rayqA[2] = { nullptr, nullptr }, *rayqB[2] = { nullptr, nullptr };      // the rays of queueA / queueB in queue order (o, d)
-	uint4 *binHits = nullptr;               // DQueues::bin_hits (the "bin_hits" knob at 0 leaves the hits in the records)
+	uint4 *binHits = nullptr;               // DQueues::bin_hits: the hits of binned paths, next to their ids
 	uint32_t *pixelList = nullptr; size_t pixelListCap = 0;
 	// The work units of a frame (pixel keys in tile order + tile rectangles) depend on the film geometry and the tile
 	// sharding only: they are kept from frame to frame (a 1-spp frame spent 0.55 of its 10.6 ms rebuilding and uploading

@@ -26,6 +26,23 @@ constexpr unsigned trace_blocks_per_cu(int mode) { return (mode == 0 ? 24u : 32u
 #endif
 constexpr unsigned trace_waves_per_simd(int mode) { return trace_blocks_per_cu(mode) * (kTraceBlock / 64) / 4; }
 constexpr unsigned kTraceBlocksPerCuMax = 2048 / kTraceBlock;      // largest persistent traversal grid: 32 waves per CU
+// LDS layout of the traversal kernels (trace.hip; k_replay of measure.hip keeps the same footprint)
+#ifndef MG_STACK_LDS
+#define MG_STACK_LDS 10
+#endif
+#ifndef MG_TOP_PAIRS
+#define MG_TOP_PAIRS (MG_TRACE_BLOCK >= 512 ? 1024 : 128)
+#endif
+constexpr int kStackLDS = MG_STACK_LDS;       // stack levels kept in LDS (deeper ones spill: 1 push in 10^4 at 12 levels on C3)
+// The first 2 * kTopPairs device nodes -- the root and the sibling pairs below it in breadth-first order, see
+// mtsgpu_upload_scene -- are copied into LDS by every workgroup: each ray's descent from the root starts with 8-9
+// levels that every other ray visits too, and a vector-memory request costs the CU ~0.5-1 ns per lane where an LDS
+// read costs ~0.05 (profiles/r02_ta_gather_microbench.txt).  0 switches the cache off.
+constexpr uint32_t kTopPairs = MG_TOP_PAIRS;
+constexpr int kSpillLevels = 50 - kStackLDS;      // LDS + spill levels = MTS_KD_MAXDEPTH (48, gkdtree.h:35) + 2
+static_assert(kStackLDS >= 1 && kStackLDS + kSpillLevels >= 48 + 2, "the traversal stack must hold every tree the reference can build");
+constexpr uint32_t kSentinel = 0xFFFFFFFFu;
+constexpr uint32_t kNullNode = 0xFFFFFFFFu;
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
 // uint4 per leaf record: the 48-byte TriAccel records lie back to back (2.67 per 128-byte line; three of eight straddle two
 // lines).  Measured and rejected (round 4, profiles/r04d_exp_trace_leaf_record_fetch.txt): one record per 64 bytes, so that
@@ -282,7 +299,7 @@ __host__ __device__ inline TracePlan trace_plan(uint32_t n, int mode, const DQue
 	return p;
 }
 
-// --- launchers (kernels.hip) -------------------------------------------------
+// --- launchers (sampler.hip, film.hip, trace.hip, shade.hip, measure.hip) -------------------------------------------------
 // state (one word per slot): where the generate() stream of each slot stands after its tables; scratch: ld_table_scratch_entries()
 // entries (0 up to 512 samples per pixel) in which the tables are shuffled
 size_t ld_table_scratch_entries(uint32_t n_slots, uint32_t spp, int depth);

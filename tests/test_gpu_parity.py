@@ -499,6 +499,41 @@ def test_full_size_frame_properties(c3_full, mts, orc):
     assert crop[640:680, 600:664, :3].max() > 0
 
 
+def test_c4_at_full_size_against_oracle_crops(c3_full, mts, orc):
+    """BASELINE.json configs[3] exactly as bench.py times it at N = 1: the 1 044 482-triangle scene, 1024 x 1024, ldsampler at
+    4096 samples per pixel, maxDepth 16, the default pass size (57 passes of 18 432 pixels: k_ld_scout + k_ld_apply_lds,
+    k_accumulate_wave at full size).  Three 2 x 2 crops of the oracle at matched seeds -- one under the glass sphere, one on
+    the back wall, one in the last (ragged) pass -- are equal bit for bit, and every camera sample was drawn"""
+    sd, scene, oscene = c3_full
+    W = H = 1024
+    spp = 4096
+    cam = mts.PerspectiveCamera.for_description(sd, W, H)
+    it = mts.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth)
+    it.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp, seed=0x5EED)
+    assert it.render()
+    film = it.film()
+    st = it.stats()
+    assert st["camera_samples"] == W * H * spp
+    w = film[..., 4].astype(np.float64)
+    assert abs(w.sum() - float(W * H) * spp) <= 1e-6 * W * H * spp and np.isfinite(film).all()
+    # the pixel the centre of the glass sphere projects to
+    c2w = np.array(list(cam.c.camera_to_world), dtype=np.float64).reshape(4, 4)
+    r2c = np.array(list(cam.c.raster_to_camera), dtype=np.float64).reshape(4, 4)
+    p = np.linalg.inv(r2c) @ np.linalg.inv(c2w) @ np.array([0.3, 0.4, 0.2, 1.0])
+    gx, gy = int(p[0] / p[3]) & ~1, int(p[1] / p[3]) & ~1
+    assert 0 < gx < W - 2 and 0 < gy < H - 2
+    ocam = orc.make_camera(sd, W, H)
+    op = orc.render_params(sd.max_depth, rr_depth=sd.rr_depth, sampler=mts.abi.SAMPLER_LD_KEYED, spp=spp, seed=0x5EED)
+    for x0, y0 in ((gx, gy), (512, 300), (W - 2, H - 2)):
+        o, ost = orc.render(oscene.scene, ocam, op, rect=(x0, y0, x0 + 2, y0 + 2))
+        assert np.array_equal(film[y0:y0 + 2, x0:x0 + 2].view(np.uint32), o[y0:y0 + 2, x0:x0 + 2].view(np.uint32)), (x0, y0)
+        assert o[y0:y0 + 2, x0:x0 + 2, :3].max() > 0
+    # the sphere crop really is glass: paths through it run deeper than the diffuse walls' (dielectric: no russian roulette)
+    og, ostg = orc.render(oscene.scene, ocam, op, rect=(gx, gy, gx + 2, gy + 2))
+    ob, ostb = orc.render(oscene.scene, ocam, op, rect=(512, 300, 514, 302))
+    assert ostg.path_length_sum > ostb.path_length_sum
+
+
 def test_gaussian_rfilter_matches_oracle(gpu_lib, mts, orc):
     """the default film filter (film.cpp:89-95): bordered ImageBlocks + Film::putImageBlock"""
     sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "c5_small", W=80, H=72, sampler="ldsampler", spp=8)

@@ -1,5 +1,5 @@
 """CPU restatements (pure Python, small sizes) of the two parallel algorithms the sampler-table kernels use above 512 samples per
-pixel (mitsuba-renderer_amd/csrc/kernels.hip: k_ld_scout, k_ld_apply_lds), against the sequential loop they replace:
+pixel (mitsuba-renderer_amd/csrc/sampler.hip: k_ld_scout, k_ld_apply_lds), against the sequential loop they replace:
 Random::shuffle (include/mitsuba/core/random.h:145-148) driven by Random::nextSize (src/libcore/random.cpp:196-215) over the
 keyed SplitMix64 stream.  The GPU tests compare the kernels themselves with the oracle; these tests pin the ARGUMENT -- that
 the fixed point of the acceptance recurrence and the lane-ordered conflict phase reproduce the sequential states exactly."""
