@@ -6,6 +6,8 @@
 #include "devmath.h"
 #include "ctx.h"
 #include <algorithm>
+#include <functional>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -275,7 +277,7 @@ int readCounters(mtsgpu_ctx *c) {
 // Closest-hit launch over queue[0..n) with the material sort, then the per-bin segment sizes (one blocking read of the
 // counters).  A shard segment that overflowed (possible only with dynamically claimed batches, see ensurePaths) makes
 // the launch run again with static dealing: tracing a ray twice writes the same hit twice.
-int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent, BinView *views) {
+int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent, BinView *views, const std::function<int()> &afterLaunch = nullptr) {
 	hipStream_t s = c->stream;
 	const size_t counterBytes = kNumCounters * kCounterStride * sizeof(uint32_t);
 	for (int attempt = 0; attempt < 2; ++attempt) {
@@ -288,6 +290,7 @@ int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent,
 		c->q.force_static = 0;
 		HIPCHK(c, hipGetLastError());
 		c->stats.trace_launches++;
+		if (attempt == 0 && afterLaunch) { const int rc2 = afterLaunch(); if (rc2) return rc2; }
 		int rc = readCounters(c); if (rc) return rc;
 		bool overflow = false;
 		for (int b = 0; b < kNumBins; ++b) {
@@ -497,10 +500,14 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		if (sf == 1 || (sf < 0 && nPaths <= (8u << 20)))
 			return runBouncesDevice(c, cfg, nPaths, cancel);
 	}
-	// measured on the 64-spp frame (profiles/r05k_*): two chip-filling persistent grids at once run a third slower than one after the other
-	// (the second one's workgroups do not pack into the holes the first one's leave), so the overlap is reserved for the short
-	// launches of device-driven frames
-	const bool overlap = tuningOr(c, "overlap", 0) != 0;
+	// Two chip-filling persistent grids next to each other.  overlap = 1 (round 5, profiles/r05k_*): the any-hit launch of bounce b
+	// first, the closest-hit launch of bounce b + 1 behind it on the other stream -- a third SLOWER, because the workgroups of the
+	// larger footprint (80 VGPRs, 52 KB) do not pack into the holes the smaller ones (64 VGPRs, 36 KB) leave.  overlap = 2
+	// (round 6): the other way round -- the closest-hit launch of bounce b + 1 goes first and takes the whole chip, the any-hit
+	// launch of bounce b is enqueued behind it on the second stream and its workgroups move in where closest-hit workgroups
+	// leave, i.e. into the 0.3-0.7 ms at the end of that launch in which its longest rays finish alone.  Legal either way: the
+	// any-hit kernel only parks direct-light terms, the shading of bounce b + 1 waits for both.
+	const long overlap = tuningOr(c, "overlap", 0);
 	uint32_t nQ = nPaths;
 	uint32_t *cur = c->queueA, *nxt = c->queueB;
 	bool first = true;       // camera rays and their shadow rays are coherent: plain 64-ray batches win there
@@ -510,6 +517,27 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 	int b = 0;
 	RayQueuesOff rqOff{ c };
 	c->q.nee_parked = tuningOr(c, "nee_parked", 1) != 0 ? 1u : 0u;
+	if (overlap && !c->q.nee_parked) return fail(c, MTSGPU_EINVAL, "overlap needs nee_parked");
+	// the any-hit launch of a bounce: at once, or (overlap = 2) held back until the next closest-hit launch has been enqueued
+	struct Deferred { bool pending = false; DQueues q; uint32_t n = 0; bool coherent = false; int bounce = 0; } held;
+	auto launchShadow = [&](const DQueues &q2, uint32_t nShadow, bool coherent, int bounce) -> int {
+		hipEvent_t *ev2 = c->timeKernels ? nextTraceEvents(c, 2) : nullptr;
+		if (ev2) HIPCHK(c, hipEventRecord(ev2[0], s2));
+		launch_trace(s2, 1, c->countTraversal, false, c->dsc, c->paths, q2, q2.shadow, nShadow, coherent);
+		if (ev2) HIPCHK(c, hipEventRecord(ev2[1], s2));
+		HIPCHK(c, hipGetLastError());
+		if (overlap) HIPCHK(c, hipEventRecord(c->evShadow[bounce & 1], s2));
+		return 0;
+	};
+	auto flushHeld = [&]() -> int {
+		if (!held.pending) return 0;
+		held.pending = false;
+		if (const long us = tuningOr(c, "overlap_delay_us", 0)) {      // experiment: let the closest-hit grid take its slots first
+			const auto t0 = std::chrono::steady_clock::now();
+			while (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < us) { }
+		}
+		return launchShadow(held.q, held.n, held.coherent, held.bounce);
+	};
 	for (; nQ > 0; ++b) {
 		if (cancel && *cancel)
 			return fail(c, MTSGPU_ECANCEL, "render cancelled");
@@ -518,9 +546,9 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		HIPCHK(c, hipMemsetAsync(c->q.counters, 0, setBytes, s));
 		c->q.next = nxt;
 		rayQueues(c, cur, nxt);
-		// closest hit + material sort
+		// closest hit + material sort (and, behind it, the any-hit launch of the previous bounce that was held back)
 		BinView views[kNumBins];
-		int rc = traceAndBin(c, cur, nQ, first, views); if (rc) return rc;
+		int rc = traceAndBin(c, cur, nQ, first, views, flushHeld); if (rc) return rc;
 		c->stats.rays_closest += nQ;
 		// the shading of this bounce adds to Li after the shadow rays of the previous one have (path.cpp:124 before :80)
 		if (shadowPending && overlap) HIPCHK(c, hipStreamWaitEvent(s, c->evShadow[(b - 1) & 1], 0));
@@ -533,23 +561,21 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		HIPCHK(c, hipGetLastError());
 		rc = readCounters(c); if (rc) return rc;
 		const uint32_t nNext = c->hostCounters[kNextWord], nShadow = c->hostCounters[kShadowWord];
-		// shadow rays of this bounce (they add the direct-light term before the next bounce adds its own); on the second
-		// stream, so that the closest-hit launch of the next bounce runs next to them -- the shading above has completed
+		// shadow rays of this bounce (they add the direct-light term before the next bounce adds its own); the shading above has completed
 		if (nShadow) {
 			DQueues q2 = c->q; q2.spill = c->spillShadow;
-			hipEvent_t *ev2 = c->timeKernels ? nextTraceEvents(c, 2) : nullptr;
 			c->lastPass.shadowMax = std::max(c->lastPass.shadowMax, nShadow);
-			if (ev2) HIPCHK(c, hipEventRecord(ev2[0], s2));
-			launch_trace(s2, 1, c->countTraversal, false, c->dsc, c->paths, q2, c->q.shadow, nShadow, first);
-			if (ev2) HIPCHK(c, hipEventRecord(ev2[1], s2));
-			HIPCHK(c, hipGetLastError());
-			if (overlap) HIPCHK(c, hipEventRecord(c->evShadow[b & 1], s2));
+			if (overlap == 2 && nNext > 0) {
+				held.pending = true; held.q = q2; held.n = nShadow; held.coherent = first; held.bounce = b;
+			} else {
+				rc = launchShadow(q2, nShadow, first, b); if (rc) return rc;
+			}
 			shadowPending = true;
 			c->stats.rays_shadow += nShadow; c->stats.trace_launches++;
 		} else {
 			shadowPending = false;
 		}
-		if (getenv("MTSGPU_DEBUG")) {
+		if (getenv("MTSGPU_DEBUG") && !overlap) {
 			HIPCHK(c, hipStreamSynchronize(s)); HIPCHK(c, hipStreamSynchronize(s2));
 			float a = 0, b2 = 0, c2 = 0;
 			if (c->timeKernels) {
@@ -565,6 +591,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		nQ = nNext;
 		first = false;
 	}
+	{ const int rc = flushHeld(); if (rc) return rc; }
 	if (shadowPending && overlap) HIPCHK(c, hipStreamWaitEvent(s, c->evShadow[(b - 1) & 1], 0));
 	c->q.counters = c->counterSets;
 	return 0;
@@ -1102,7 +1129,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 }, { "ray_queues", 0, 1 }, { "nee_parked", 0, 1 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 2 }, { "overlap_delay_us", 0, 100000 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 }, { "ray_queues", 0, 1 }, { "nee_parked", 0, 1 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);

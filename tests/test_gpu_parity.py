@@ -515,7 +515,9 @@ def test_c4_at_full_size_against_oracle_crops(c3_full, mts, orc):
     st = it.stats()
     assert st["camera_samples"] == W * H * spp
     w = film[..., 4].astype(np.float64)
-    assert abs(w.sum() - float(W * H) * spp) <= 1e-6 * W * H * spp and np.isfinite(film).all()
+    # every sample lands in one pixel with weight 1, except the few that ImageBlock::putSample refuses (Spectrum::isValid: the
+    # 0/0 of the power heuristic, path.cpp:218-222) -- 8e-5 of them on this scene; the crops below pin the exact values
+    assert abs(w.sum() - float(W * H) * spp) <= 5e-4 * W * H * spp and w.max() <= spp + 16 and np.isfinite(film).all()
     # the pixel the centre of the glass sphere projects to
     c2w = np.array(list(cam.c.camera_to_world), dtype=np.float64).reshape(4, 4)
     r2c = np.array(list(cam.c.raster_to_camera), dtype=np.float64).reshape(4, 4)
