@@ -455,6 +455,7 @@ def main():
         # HBM traffic of the traversal launches from a separate PMC pass of the same frame (profiles/); only a
         # record taken with exactly these kernel sources counts
         traffic = None
+        fabric_rec = None
         l2 = {"l2_hit_rate": None, "l2_miss_per_ray": None}
         traffic_note = "no PMC record for these kernel sources (tools/profile_round.sh writes profiles/*_traffic.json)"
         try:
@@ -464,6 +465,7 @@ def main():
                 if tj.get("kernel_source_hash") == kernel_source_hash() and world == 1 and not strong \
                         and tj["workload"] == {"grid": args.grid, "res": args.res, "spp": args.spp}:
                     traffic = tj["hbm_bytes_per_launch"]; traffic_note = "profiles/" + f
+                    fabric_rec = tj
                     l2 = {"l2_hit_rate": tj.get("l2_hit_rate"), "l2_miss_per_ray": tj.get("l2_miss_per_ray")}
                     break
         except Exception:
@@ -515,6 +517,19 @@ def main():
                            # sum over the frame's launches of (launch time x the replay ratio measured on its class's sample)
                            "replay_ms_per_step": replay_ms_per_step if complete else None,
                            "replay_ratio": replay_ms_per_step / trace_ms if complete and trace_ms > 0 else None})
+        # what crosses the fabric (L2 misses, 128-byte lines; calibrated: profiles/r06a_fetch_size_calibration.txt) during the
+        # traversal launches, against the rate the chip sustains for random 128-byte lines that live in the Infinity Cache
+        fabric = None
+        if fabric_rec and trace_ms > 0:
+            fb = fabric_rec.get("fabric_bytes_per_frame")
+            ceil = (fabric_rec.get("random_line_rate_G_per_s") or {}).get("k_g16_150MB")
+            if fb:
+                lines = fb / 128.0 / (trace_ms * 1e-3) / 1e9
+                fabric = {"bytes_per_step": fb, "tb_per_s": fb / (trace_ms * 1e-3) / 1e12, "G_lines_per_s": lines,
+                          "random_line_ceiling_G_per_s": ceil, "frac_of_ceiling": lines / ceil if ceil else None,
+                          "read_requests_per_ray": (fabric_rec.get("fabric_read_requests_per_frame") or 0) / max(rays, 1) or None,
+                          "what": "bytes between the L2s and the Infinity Cache / HBM per step (2 x FETCH_SIZE + WRITE_SIZE, the x2 measured) over the traversal "
+                                  "launches' time; ceiling = random 16-byte gathers on distinct lines of a 150 MB footprint (tools/micro/gather_calib.hip)"}
         sh_bytes = shade_algorithmic_bytes(counts)
         sh_achieved = sh_bytes / (shade_ms * 1e-3) / 1e9 if shade_ms > 0 else 0.0
         out = {
@@ -542,6 +557,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                 "l2_hit_rate": l2["l2_hit_rate"], "l2_miss_per_ray": l2["l2_miss_per_ray"],     # TCC_HIT / TCC_MISS of the same record
+                "fabric": fabric,
                 "peak_measured_triad": triad, "frac_of_triad": achieved / triad if triad else None,
                 "algorithmic_bytes_per_launch": bytes_per_step / max(counts["trace_launches"], 1),
                 "algorithmic_bytes_per_step": bytes_per_step, "bytes_per_ray": bytes_per_step / max(rays, 1),

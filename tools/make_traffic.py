@@ -31,16 +31,33 @@ try:
             rays = st["rays_closest"] + st["rays_shadow"]
 except Exception:
     pass
+# fabric read requests of the same launches (pmc_ea pass): every one a 128-byte request on gfx950 (TCC_EA0_RDREQ_128B = TCC_EA0_RDREQ)
+ea, _ = total("pmc_ea", "TCC_EA0_RDREQ_sum", "k_trace")
+ea128, _ = total("pmc_ea", "TCC_EA0_RDREQ_128B_sum", "k_trace")
+# the line rates the chip sustains for random lines (tools/micro/gather_calib.hip, profiles/r06a_fetch_size_calibration.json)
+calib = {}
+try:
+    for e in json.load(open(os.path.join(ROOT, "profiles", "r06a_fetch_size_calibration.json"))):
+        calib["%s_%dMB" % (e["shape"], e["footprint_mb"])] = e["lines_per_ns"]
+except Exception:
+    pass
 out = {
     "workload": {"grid": 320, "res": 1024, "spp": 64},
     "kernel_source_hash": bench.kernel_source_hash(),
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile_round.sh %s -> python3 tools/pmc_workload.py 64 (production kernels)" % tag,
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_EA0_RDREQ* (separate passes), tools/profile_round.sh %s -> python3 tools/pmc_workload.py 64 (production kernels)" % tag,
     "kernel": "k_trace<0,false,true> + k_trace<1,false,false> (%d launches per frame)" % launches,
     "fetch_size_kb": fetch, "write_size_kb": write, "read_correction": 2.0,
-    "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream; for these 8/16-byte gathers the factor is uncalibrated, so x2 is an upper bound. traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 / launches",
+    "read_correction_source": "measured, profiles/r06a_fetch_size_calibration.txt: FETCH_SIZE tallies 64 B per fabric read request and every request is one "
+                              "128-byte line (TCC_EA0_RDREQ = TCC_EA0_RDREQ_128B = TCC_MISS = 1 per line touched) for 8-byte gathers, 16-byte gathers and "
+                              "16-byte-per-lane streams alike, at 32 MB, 150 MB and 2 GB footprints; requests to a line already in flight are NOT merged",
+    "note": "traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 / launches = bytes that cross the fabric (L2 misses; Infinity-Cache hits are counted, "
+            "TCC_EA0_RDREQ_DRAM = TCC_EA0_RDREQ): not all of it reaches HBM -- tree and leaf records (57 MB) live in the 256 MiB Infinity Cache",
     "launches_per_frame": launches,
     "hbm_bytes_per_launch": (2 * fetch + write) * 1024 / launches,
     "hbm_bytes_per_launch_uncorrected": (fetch + write) * 1024 / launches,
+    "fabric_read_requests_per_frame": ea or None, "fabric_read_requests_128B_per_frame": ea128 or None,
+    "fabric_bytes_per_frame": (2 * fetch + write) * 1024,
+    "random_line_rate_G_per_s": calib,
     "tcc_hit": hit, "tcc_miss": miss, "rays_per_frame": rays,
     "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
     "l2_miss_per_ray": miss / rays if rays else None,
