@@ -39,6 +39,7 @@
 #include <mitsuba/core/plugin.h>
 #include <mitsuba/core/sched.h>
 #include <mtsgpu.h>
+#include "streamparse.h"
 #include <sstream>
 #include <cstdlib>
 
@@ -63,116 +64,40 @@ inline void copyMatrix(float *dst, const Matrix4x4 &m) {
 	for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) dst[4 * i + j] = (float) m.m[i][j];     /* matrix layout: transform.h */
 }
 
-/* Reads back what <BSDF class>::serialize wrote -- the only access to the BSDF plugins' private parameters.  The
- * object goes through InstanceManager::serialize into memory (wire format, src/libcore/serialization.cpp:72-85: a new
- * object is [id][class name][its serialize()], a known one just [id], NULL is [0]) and the fields are read back in the
- * order the plugin's serialize() documents.  Nothing is re-instantiated.  This works for BSDFs as they stand because
- * they have no parent (BSDF::setParent is empty, bsdf.cpp:55-57) and their only children are textures; shapes and
- * luminaires point back at the scene: see DetachedReader below. */
-class BSDFParamReader {
-public:
-	BSDFParamReader(const BSDF *bsdf) {
-		m_stream = new MemoryStream();                                 /* include/mitsuba/core/mstream.h:40 */
-		ref<InstanceManager> writer = new InstanceManager();
-		writer->serialize(m_stream, bsdf);
-		m_stream->setPos(0);
-		if (!openObject(m_className))
-			SLog(EError, "gpupath: cannot read back the parameters of a BSDF");
-		/* BSDF::serialize (bsdf.cpp:50-53): ConfigurableObject::serialize = the parent (none), then m_name */
-		skipReference(); m_stream->readString();
-	}
-	const std::string &className() const { return m_className; }
-	Float readFloat() { return m_stream->readFloat(); }
-	Spectrum readSpectrum() { return Spectrum(m_stream); }
-	/* a texture child: [id][class name][Texture::serialize = parent reference][ConstantSpectrumTexture: the value]
-	 * (src/librender/texture.cpp:39-41,89-93).  Anything but a constant needs computePartials + MIPMap: out of scope. */
-	Spectrum readConstantTexture(const char *what) {
-		std::string cls;
-		const unsigned int id = m_stream->readUInt();
-		if (id != 0 && m_values.count(id)) return m_values[id];         /* one texture shared by two slots */
-		if (id == 0) SLog(EError, "gpupath: %s of %s is missing", what, m_className.c_str());
-		m_seen.insert(id);
-		cls = m_stream->readString();
-		if (cls != "ConstantSpectrumTexture")                               /* consttexture.h:28-60 */
-			SLog(EError, "gpupath: %s of %s is a %s; only constant reflectances are supported", what, m_className.c_str(), cls.c_str());
-		skipReference();
-		return m_values[id] = Spectrum(m_stream);
-	}
-	/* a ConstantFloatTexture child (roughglass' alpha): [id][class name][Texture::serialize][the value]
-	 * (src/librender/texture.cpp:95-103) */
-	Float readConstantFloatTexture(const char *what) {
-		const unsigned int id = m_stream->readUInt();
-		if (id == 0 || m_seen.count(id)) SLog(EError, "gpupath: %s of %s is missing or shared", what, m_className.c_str());
-		m_seen.insert(id);
-		const std::string cls = m_stream->readString();
-		if (cls != "ConstantFloatTexture")
-			SLog(EError, "gpupath: %s of %s is a %s; only constant values are supported", what, m_className.c_str(), cls.c_str());
-		skipReference();
-		return m_stream->readFloat();
-	}
-	int readInt() { return m_stream->readInt(); }
-	/* the nested BRDF of a `twosided` adapter: positions the reader on its fields */
-	void enterNestedBSDF() {
-		if (!openObject(m_className)) SLog(EError, "gpupath: twosided BRDF without a nested BRDF");
-		skipReference(); m_stream->readString();
-	}
-private:
-	bool openObject(std::string &cls) {
-		const unsigned int id = m_stream->readUInt();
-		if (id == 0 || m_seen.count(id)) return false;
-		m_seen.insert(id);
-		cls = m_stream->readString();
-		return true;
-	}
-	void skipReference() {
-		const unsigned int id = m_stream->readUInt();
-		if (id != 0 && !m_seen.count(id))
-			SLog(EError, "gpupath: unexpected nested object in the serialized form of %s", m_className.c_str());
-	}
-	ref<MemoryStream> m_stream;
-	std::set<unsigned int> m_seen;
-	std::map<unsigned int, Spectrum> m_values;
-	std::string m_className;
-};
+/* The private parameters of BSDFs, delta / environment luminaires and spheres are read back from what the object's own
+ * serialize() writes: the object goes through InstanceManager::serialize into memory (wire format,
+ * src/libcore/serialization.cpp:72-85: a new object is [id][class name][its serialize()], a known one just [id], NULL is [0])
+ * and the bytes are taken apart by integration/streamparse.h, which follows the field order of each class's serialize() and is
+ * tested on bytes without Mitsuba (tests/test_stream_parsers.py).  Nothing is re-instantiated.
+ *
+ * BSDFs are serialized as they stand: they have no parent (BSDF::setParent is empty, bsdf.cpp:55-57) and their only children
+ * are textures. */
+inline ref<MemoryStream> serializedBSDF(const BSDF *bsdf) {
+	ref<MemoryStream> stream = new MemoryStream();                            /* include/mitsuba/core/mstream.h:40 */
+	ref<InstanceManager> writer = new InstanceManager();
+	writer->serialize(stream, bsdf);
+	return stream;
+}
 
-/* Reads back what a scene-level object (a delta luminaire, the environment map, a sphere) wrote in serialize() -- these
- * plugins live in their .cpp files and keep every parameter private.  ConfigurableObject::serialize (properties.cpp:358-363)
- * starts with the PARENT, which for such an object is the Scene: serializing it as it stands would drag the whole scene
- * along.  The parent pointer is public API (getParent / setParent, cobject.h:40-46, properties.cpp:351-353: a plain
- * store), so it is taken off for the duration of the call and put back; render() runs on the RenderJob thread before any
- * worker touches the scene.  The fields are then read in the order of the class's unserialization constructor. */
-class DetachedReader {
-public:
-	DetachedReader(ConfigurableObject *obj, const char *expectedClass) {
-		ConfigurableObject *parent = obj->getParent();
-		obj->setParent(NULL);
-		m_stream = new MemoryStream();
-		ref<InstanceManager> writer = new InstanceManager();
-		try {
-			writer->serialize(m_stream, obj);                                  /* serialization.cpp:72-85: [id][class name][serialize()] */
-		} catch (...) {
-			obj->setParent(parent);
-			throw;
-		}
+/* A scene-level object (a delta luminaire, the environment map, a sphere): these plugins live in their .cpp files and keep
+ * every parameter private.  ConfigurableObject::serialize (properties.cpp:358-363) starts with the PARENT, which for such an
+ * object is the Scene: serializing it as it stands would drag the whole scene along.  The parent pointer is public API
+ * (getParent / setParent, cobject.h:40-46, properties.cpp:351-353: a plain store), so it is taken off for the duration of the
+ * call and put back; render() runs on the RenderJob thread before any worker touches the scene. */
+inline ref<MemoryStream> serializedDetached(ConfigurableObject *obj) {
+	ConfigurableObject *parent = obj->getParent();
+	obj->setParent(NULL);
+	ref<MemoryStream> stream = new MemoryStream();
+	ref<InstanceManager> writer = new InstanceManager();
+	try {
+		writer->serialize(stream, obj);                                        /* serialization.cpp:72-85: [id][class name][serialize()] */
+	} catch (...) {
 		obj->setParent(parent);
-		m_stream->setPos(0);
-		m_stream->readUInt();
-		const std::string cls = m_stream->readString();
-		if (cls != expectedClass) SLog(EError, "gpupath: expected a %s, found a %s", expectedClass, cls.c_str());
-		if (m_stream->readUInt() != 0) SLog(EError, "gpupath: %s still has a parent", expectedClass);      /* ConfigurableObject(Stream *) */
+		throw;
 	}
-	/* Luminaire(Stream *, InstanceManager *) (src/librender/luminaire.cpp:42-51) */
-	Transform readLuminaireBase() {
-		if (m_stream->readUInt() != 0) SLog(EError, "gpupath: luminaires inside participating media are not on this path");
-		m_stream->readFloat(); m_stream->readInt(); m_stream->readBool();      /* sampling weight, type, intersectable */
-		const Transform worldToLuminaire(m_stream.get());
-		m_stream->readString();
-		return worldToLuminaire;
-	}
-	MemoryStream *stream() { return m_stream.get(); }
-private:
-	ref<MemoryStream> m_stream;
-};
+	obj->setParent(parent);
+	return stream;
+}
 
 inline void copy3x3(float *dst, const Matrix4x4 &m) {
 	for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dst[3 * i + j] = (float) m.m[i][j];
@@ -205,12 +130,13 @@ struct FlatScene {
 		lumShape.assign(lums.size(), -1); lumInvArea.assign(lums.size(), 0.0f);
 		sc.background_lum = -1;
 		for (size_t l = 0; l < lums.size(); ++l) {
-			Luminaire *lum = lums[l];                                                 /* non-const: DetachedReader takes the parent off and puts it back */
+			Luminaire *lum = lums[l];                                                 /* non-const: serializedDetached takes the parent off and puts it back */
 			lumIndex[lum] = (int) l;
 			float *P = &lumParams[(size_t) MTSGPU_LUM_NPARAMS * l];
 			const std::string cls = lum->getClass()->getName();
+			std::string err;
 			/* area, constant and point luminaires hand their stored values out through the public evaluation interface
-			 * unchanged; the others keep them private and are read back from serialize() (DetachedReader) */
+			 * unchanged; the others keep them private and are read back from serialize() (serializedDetached + streamparse.h) */
 			if (cls == "AreaLuminaire") {
 				lumType.push_back(MTSGPU_LUM_AREA);
 				ShapeSamplingRecord sRec; sRec.n = Normal(0, 0, 1);
@@ -237,44 +163,16 @@ struct FlatScene {
 				P[3] = (float) eRec.sRec.p.x; P[4] = (float) eRec.sRec.p.y; P[5] = (float) eRec.sRec.p.z;
 			} else if (cls == "DirectionalLuminaire") {
 				lumType.push_back(MTSGPU_LUM_DIRECTIONAL);
-				DetachedReader rd(lum, "DirectionalLuminaire");                     /* directional.cpp:44-52 */
-				rd.readLuminaireBase();
-				const Vector dir(rd.stream());
-				const Spectrum intensity(rd.stream());
-				const Point diskOrigin(rd.stream()); (void) diskOrigin;
-				P[6] = (float) rd.stream()->readFloat();                            /* m_diskRadius after preprocess (:65-72) */
-				rgbOf(intensity, P);
-				P[3] = (float) dir.x; P[4] = (float) dir.y; P[5] = (float) dir.z;
+				ref<MemoryStream> st = serializedDetached(lum);                     /* directional.cpp:57-63; m_diskRadius after preprocess (:65-72) */
+				if (!mtsgpu_stream::parseDirectional<Float>(st->getData(), st->getSize(), P, &err)) SLog(EError, "gpupath: %s", err.c_str());
 			} else if (cls == "SpotLuminaire") {
 				lumType.push_back(MTSGPU_LUM_SPOT);
-				DetachedReader rd(lum, "SpotLuminaire");                            /* spot.cpp:46-53 */
-				const Transform w2l = rd.readLuminaireBase();
-				{	/* m_texture: only the default constant 1 is on this path (spot.cpp:42-43, :96-102) */
-					MemoryStream *s = rd.stream();
-					s->readUInt();
-					if (s->readString() != "ConstantSpectrumTexture") SLog(EError, "gpupath: projection textures of spot luminaires are not on this path");
-					s->readUInt();                                                   /* Texture::serialize: its parent (the luminaire: a known id) */
-					const Spectrum tex(s);
-					if (tex != Spectrum(1.0f)) SLog(EError, "gpupath: projection textures of spot luminaires are not on this path");
-				}
-				const Spectrum intensity(rd.stream());
-				const Float beamWidth = rd.stream()->readFloat(), cutoffAngle = rd.stream()->readFloat();
-				const Point pos = w2l.inverse()(Point(0, 0, 0));                    /* SpotLuminaire::configure (:56-62) */
-				rgbOf(intensity, P);
-				P[3] = (float) pos.x; P[4] = (float) pos.y; P[5] = (float) pos.z;
-				P[6] = (float) std::cos(beamWidth); P[7] = (float) std::cos(cutoffAngle);
-				P[8] = (float) cutoffAngle; P[9] = (float) (1.0f / (cutoffAngle - beamWidth));
-				copy3x3(P + 10, w2l.getMatrix());
-				P[19] = (float) beamWidth;
+				ref<MemoryStream> st = serializedDetached(lum);                     /* spot.cpp:63-70, configure() :56-62 */
+				if (!mtsgpu_stream::parseSpot<Float>(st->getData(), st->getSize(), P, &err)) SLog(EError, "gpupath: %s", err.c_str());
 			} else if (cls == "CollimatedBeamLuminaire") {
 				lumType.push_back(MTSGPU_LUM_COLLIMATED);
-				DetachedReader rd(lum, "CollimatedBeamLuminaire");                  /* collimated.cpp:40-51 */
-				const Transform w2l = rd.readLuminaireBase();
-				const Spectrum intensity(rd.stream());
-				rgbOf(intensity, P);
-				P[3] = (float) rd.stream()->readFloat();                            /* m_radius */
-				copy3x4(P + 4, w2l.getMatrix());
-				copy3x4(P + 16, w2l.getInverseMatrix());
+				ref<MemoryStream> st = serializedDetached(lum);                     /* collimated.cpp:47-51 */
+				if (!mtsgpu_stream::parseCollimated<Float>(st->getData(), st->getSize(), P, &err)) SLog(EError, "gpupath: %s", err.c_str());
 			} else if (cls == "EnvMapLuminaire") {
 				lumType.push_back(MTSGPU_LUM_ENVMAP);
 				if (sc.background_lum >= 0) SLog(EError, "gpupath: more than one background luminaire");
@@ -326,20 +224,10 @@ struct FlatScene {
 				 * radius and transform private: read back from serialize() (:72-78) with the parent taken off.  The shape's
 				 * BSDF and luminaire are nested in that stream (Shape::serialize, shape.cpp:130-138); they are skipped by
 				 * seeking from the END, where the sphere's own fields have a fixed size. */
-				Shape *s_ = const_cast<Shape *>(shape);
-				DetachedReader rd(s_, "Sphere");
-				MemoryStream *st = rd.stream();
-				const size_t tail = 2 * 16 * sizeof(Float) + sizeof(Float) + 3 * sizeof(Float) + 1;   /* Transform, radius, centre, inverted (:74-77) */
-				st->setPos(st->getSize() - tail);
-				const Transform o2w(st);
-				const Float radius = st->readFloat();
-				const Point centre(st);
-				const bool inverted = st->readBool();
+				ref<MemoryStream> st = serializedDetached(const_cast<Shape *>(shape));
 				float *SP = &shapeParams[(size_t) MTSGPU_SHAPE_NPARAMS * s];
-				SP[0] = (float) centre.x; SP[1] = (float) centre.y; SP[2] = (float) centre.z; SP[3] = (float) radius;
-				SP[4] = inverted ? 1.0f : 0.0f;
-				copy3x3(SP + 5, o2w.getMatrix()); copy3x3(SP + 14, o2w.getInverseMatrix());
-				SP[23] = (float) (1 / (4 * M_PI * radius * radius));                 /* m_invSurfaceArea (:69) */
+				std::string err;
+				if (!mtsgpu_stream::parseSphere<Float>(st->getData(), st->getSize(), SP, &err)) SLog(EError, "gpupath: %s", err.c_str());
 				/* its primitive: a TriAccel row with k = KNoTriangleFlag (skdtree.cpp:92-96), no vertices */
 				TriAccel ta; memset(&ta, 0, sizeof(ta));
 				ta.k = KNoTriangleFlag; ta.shapeIndex = (uint32_t) s; ta.primIndex = 0;       /* triaccel.h:34-48,28 */
@@ -434,17 +322,11 @@ private:
 	 * bytes serialize() carries with Mitsuba's own Bitmap, build the MIPMap with Mitsuba's own MIPMap::fromBitmap -- and
 	 * what configure() does (:95-110): the luminance x sin(theta) density over level min(3, levels - 1) */
 	void readEnvMap(Luminaire *lum, float *P) {
-		DetachedReader rd(lum, "EnvMapLuminaire");
-		const Transform w2l = rd.readLuminaireBase();
-		MemoryStream *s = rd.stream();
-		P[0] = (float) s->readFloat();                                               /* m_intensityScale */
-		s->readString();                                                             /* m_path */
-		const BSphere bs(s);                                                         /* after preprocess (:112-126) */
-		P[3] = (float) bs.center.x; P[4] = (float) bs.center.y; P[5] = (float) bs.center.z; P[6] = (float) bs.radius;
-		copy3x3(P + 7, w2l.getMatrix()); copy3x3(P + 16, w2l.getInverseMatrix());
-		const uint32_t size = s->readUInt();
+		ref<MemoryStream> st = serializedDetached(lum);
+		size_t exrOffset = 0; uint32_t size = 0; std::string err;
+		if (!mtsgpu_stream::parseEnvMapHeader<Float>(st->getData(), st->getSize(), P, &exrOffset, &size, &err)) SLog(EError, "gpupath: %s", err.c_str());
 		ref<MemoryStream> exr = new MemoryStream(size);
-		s->copyTo(exr, size);
+		exr->write(st->getData() + exrOffset, size);                                  /* the EXR file's bytes (envmap.cpp:85-92) */
 		exr->setPos(0);
 		ref<Bitmap> bitmap = new Bitmap(Bitmap::EEXR, exr);                           /* bitmap.h */
 		ref<MIPMap> mip = MIPMap::fromBitmap(bitmap);                                 /* mipmap.h:57 */
@@ -479,54 +361,12 @@ private:
 		bsdfIndex[bsdf] = index;
 		bsdfParams.insert(bsdfParams.end(), MTSGPU_BSDF_NPARAMS, 0.0f);
 		bsdfType.push_back(0);
-		uint32_t flags = 0;
-		BSDFParamReader rd(bsdf);
-		float *P = &bsdfParams[(size_t) MTSGPU_BSDF_NPARAMS * index];
-		if (rd.className() == "TwoSidedBRDF") {                                  /* twosided.cpp: the nested BRDF follows */
-			flags |= MTSGPU_BSDF_TWOSIDED;
-			rd.enterNestedBSDF();
-		}
-		const std::string cls = rd.className();
-		if (cls == "Lambertian") {                                               /* lambertian.cpp: reflectance texture */
-			bsdfType[index] = MTSGPU_BSDF_LAMBERTIAN | flags;
-			rgbOf(rd.readConstantTexture("reflectance"), P);
-		} else if (cls == "Dielectric") {                                        /* dielectric.cpp:88-95 */
-			bsdfType[index] = MTSGPU_BSDF_DIELECTRIC | flags;
-			P[0] = (float) rd.readFloat(); P[1] = (float) rd.readFloat();
-			rgbOf(rd.readConstantTexture("specularReflectance"), P + 2);
-			rgbOf(rd.readConstantTexture("specularTransmittance"), P + 5);
-		} else if (cls == "RoughMetal") {                                        /* roughmetal.cpp:169-176 */
-			bsdfType[index] = MTSGPU_BSDF_ROUGHMETAL | flags;
-			rgbOf(rd.readConstantTexture("specularReflectance"), P + 7);
-			P[0] = (float) rd.readFloat();
-			rgbOf(rd.readSpectrum(), P + 1); rgbOf(rd.readSpectrum(), P + 4);
-		} else if (cls == "Microfacet") {                                        /* microfacet.cpp:283-293 */
-			bsdfType[index] = MTSGPU_BSDF_MICROFACET | flags;
-			rgbOf(rd.readConstantTexture("diffuseReflectance"), P + 5);
-			rgbOf(rd.readConstantTexture("specularReflectance"), P + 8);
-			for (int k = 0; k < 5; ++k) P[k] = (float) rd.readFloat();         /* alphaB, kd, ks, intIOR, extIOR */
-		} else if (cls == "Mirror") {                                            /* mirror.cpp:51-55 */
-			bsdfType[index] = MTSGPU_BSDF_MIRROR | flags;
-			rgbOf(rd.readSpectrum(), P);
-		} else if (cls == "Phong") {                                             /* phong.cpp:55-63 (values after configure()) */
-			bsdfType[index] = MTSGPU_BSDF_PHONG | flags;
-			rgbOf(rd.readConstantTexture("diffuseReflectance"), P + 5);
-			rgbOf(rd.readConstantTexture("specularReflectance"), P + 8);
-			for (int k = 0; k < 5; ++k) P[k] = (float) rd.readFloat();         /* exponent, kd, ks, specular / diffuse sampling weight */
-		} else if (cls == "RoughGlass") {                                        /* roughglass.cpp:148-156 */
-			bsdfType[index] = MTSGPU_BSDF_ROUGHGLASS | flags;
-			P[0] = (float) rd.readInt();                                       /* EBeckmann 0, EPhong 1, EGGX 2 (:84-91) = the ABI's codes */
-			P[1] = (float) rd.readConstantFloatTexture("alpha");               /* phong: already the exponent (:130-136) */
-			rgbOf(rd.readConstantTexture("specularReflectance"), P + 4);
-			rgbOf(rd.readConstantTexture("specularTransmittance"), P + 7);
-			P[2] = (float) rd.readFloat(); P[3] = (float) rd.readFloat();      /* intIOR, extIOR */
-		} else if (cls == "DiffuseTransmitter") {                                /* difftrans.cpp:142-146 */
-			bsdfType[index] = MTSGPU_BSDF_DIFFTRANS | flags;
-			rgbOf(rd.readConstantTexture("transmittance"), P);
-		} else {
-			SLog(EError, "gpupath: BSDF class %s is not on this path (lambertian, dielectric, roughmetal, microfacet, mirror, phong, "
-				"roughglass, difftrans and the twosided adapter are)", cls.c_str());
-		}
+		ref<MemoryStream> st = serializedBSDF(bsdf);
+		std::string err;
+		uint32_t type = 0;
+		if (!mtsgpu_stream::parseBSDF<Float>(st->getData(), st->getSize(), &type, &bsdfParams[(size_t) MTSGPU_BSDF_NPARAMS * index], &err))
+			SLog(EError, "gpupath: %s", err.c_str());
+		bsdfType[index] = type;
 		return index;
 	}
 };
