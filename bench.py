@@ -205,7 +205,8 @@ def group_child(args):
     out = {"form": "one process, %d GPUs: mtsgpu_create_multi + mtsgpu_group_render" % n, "devices": devices,
            "group_ms_per_step": ms, "group_ms_best": min(times), "steps": len(times),
            "value": args.res * args.res * spp_total / (ms * 1e-3) / 1e6, "unit": "Msamples/s",
-           "reduce_kind": g.reduce_kind(), "reduce_note": g.reduce_note()}
+           "reduce_kind": g.reduce_kind(), "reduce_note": g.reduce_note(),
+           "rccl_ranks": g.rccl_ranks()}            # ranks of the communicator that passed the library's self-check (0: ordered sum)
     if args.dump_film:
         import numpy as np
         np.save(args.dump_film, g.film())
@@ -263,6 +264,9 @@ def main():
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1spp", action="store_true", help="skip the time-to-1spp frames")
+    ap.add_argument("--no-c4", action="store_true", help="with --gpus > 1 in weak mode: skip the C4 strong-scaling frames (4096 spp over all GPUs) that are timed after the weak steps")
+    ap.add_argument("--c4-spp", type=int, default=4096, help="samples per pixel of the C4 strong-scaling frame (BASELINE.json configs[3]: 4096)")
+    ap.add_argument("--c4-steps", type=int, default=2)
     ap.add_argument("--host-kd", action="store_true", help="kd-tree build (binning and exact phase) on the host instead of the GPU (same tree)")
     ap.add_argument("--devices", default="", help="comma list: HIP device of each local rank (default: LOCAL_RANK). "
                     "Ranks sharing a device reduce their films through gloo on host copies (test mode)")
@@ -299,6 +303,8 @@ def main():
     if device >= torch.cuda.device_count():
         sys.exit("rank %d: device %d requested, %d visible" % (rank, device, torch.cuda.device_count()))
     torch.cuda.set_device(device)
+    collective_ranks = 0
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = "gloo" if shared_device else "nccl"
@@ -312,6 +318,7 @@ def main():
                 torch.cuda.synchronize()
             if int(probe.item()) != world:
                 raise RuntimeError("all_reduce of ones over %d ranks returned %s" % (world, probe.item()))
+            collective_ranks = int(probe.item())         # what the backend's first collective summed up: one per rank
         except Exception as e:
             sys.stderr.write("bench.py rank %d/%d (device %d): torch.distributed backend %s failed: %s: %s\n"
                              % (rank, world, device, backend, type(e).__name__, e))
@@ -451,6 +458,27 @@ def main():
             best = min(best, (time.perf_counter() - t1) * 1e3)
         one_spp_ms = best
 
+    # --- BASELINE.json configs[3] next to the weak line: with N > 1 GPUs the same scene at 4096 spp per FRAME (strong
+    # scaling: every GPU renders its tiles at 4096 spp, one film reduce per frame), timed like the steps above ---
+    c4 = None
+    if world > 1 and not strong and not args.no_c4:
+        it.preprocess(scene, cam, sampler="ldsampler", sampleCount=args.c4_spp, seed=0x5EED)
+        it.set_tiles(32, rank, world)
+        it.set_options(max_paths=args.max_paths, count_traversal=False, time_kernels=False)
+        step(); fence()                              # warm-up: the 4096-spp tables and passes
+        t1 = time.perf_counter()
+        for _ in range(max(1, args.c4_steps)):
+            step()
+        fence()
+        c4_elapsed = time.perf_counter() - t1
+        t = torch.tensor([c4_elapsed], dtype=torch.float64, device="cpu" if shared_device else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        c4_elapsed = float(t.item())
+        n_c4 = max(1, args.c4_steps)
+        c4 = {"config": "BASELINE.json configs[3]: the 1M-triangle scene at %d spp per frame, tiles sharded over %d GPUs, one film reduce per frame (strong scaling)" % (args.c4_spp, world),
+              "metric": "Msamples/s", "value": W * H * args.c4_spp * n_c4 / c4_elapsed / 1e6, "n_gpus": world, "scaling": "strong",
+              "steps": n_c4, "warmup": 1, "ms_per_step": c4_elapsed / n_c4 * 1e3, "spp_total": args.c4_spp}
+
     if rank == 0:
         # HBM traffic of the traversal launches from a separate PMC pass of the same frame (profiles/); only a
         # record taken with exactly these kernel sources counts
@@ -537,12 +565,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the film reduce: which collective summed the per-GPU films, and how many ranks its first collective (a sum of ones) saw
+            "reduce_kind": "none (one GPU)" if world == 1 else ("rccl all-ranks reduce (torch.distributed nccl backend)" if backend == "nccl" else "gloo on host copies (ranks share a device: test mode)"),
+            "rccl_ranks": collective_ranks if backend == "nccl" else 0,
             "config": {
                 "workload": "%s 1M-tri Cornell: %d-tri displaced walls TriMesh + 20480-tri dielectric icosphere + area light, "
                             "path maxDepth=%d rrDepth=%d, %dx%d, ldsampler %s, box filter"
                             % ("C4" if strong else "C3", 5 * 2 * args.grid * args.grid, sd.max_depth, sd.rr_depth, W, H,
                                ("%d spp per frame (strong scaling)" % spp_total) if strong
-                               else ("%d spp per GPU (%d per frame, weak scaling)" % (args.spp, spp_total))),
+                               else ("%d spp per GPU (%d per frame, weak scaling)" % (args.spp, spp_total)))
+                            + ("; the C4 frame (configs[3]: %d spp per frame over the same %d GPUs, strong scaling) is timed after it: c4_strong" % (args.c4_spp, world) if c4 else ""),
                 "triangles": int(scene.sc.n_tris), "kd_nodes": int(scene.sc.n_nodes), "kd_indices": int(scene.sc.n_indices),
                 "parallelism": "ImageBlock tiles, morton(tx, ty) %% %d + one RCCL film reduce per frame" % world,
                 "host_flatten_s": flatten_s,
@@ -550,6 +582,7 @@ def main():
             # per rank: ms per step of its own frame (film clear + all kernels), and of the film reduce that follows
             # (it includes the wait for the slowest rank; on rank 0 also the receive)
             "rank_ms": rank_ms, "reduce_ms": reduce_ms,
+            "c4_strong": c4,
             "time_to_1spp_frame_ms": one_spp_ms,
             "avg_path_length": counts.get("avg_path_length"),
             "roofline": {

@@ -329,6 +329,11 @@ int  mtsgpu_group_set_rfilter(mtsgpu_group *g, float size_x, float size_y, const
 int  mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, volatile const int *cancel);
 /* 0 = ordered peer-copy sum, 1 = RCCL ncclReduce: what the last mtsgpu_group_render used */
 int  mtsgpu_group_last_reduce_kind(const mtsgpu_group *g);
+/* The number of ranks of the group's RCCL communicator, once it exists and has passed its self-check (created by the first
+ * mtsgpu_group_render that wants the collective: ncclCommInitAll gave every member a communicator, each reports the group's
+ * size, and a one-float sum of ones arrived at the root as that size); 0 before that, when RCCL is not usable, or after a
+ * collective failed and the group went back to the ordered sum. */
+int  mtsgpu_group_rccl_ranks(const mtsgpu_group *g);
 /* Why the last mtsgpu_group_render summed the films in member order although RCCL was asked for ("" when it did not have
  * to): librccl could not be loaded (the environment variable MTSGPU_RCCL_LIB names the library to load), the
  * communicator could not be created, or ncclReduce / ncclGroupEnd failed.  A failed collective does not lose the frame:
@@ -338,6 +343,13 @@ const char *mtsgpu_group_reduce_note(const mtsgpu_group *g);
 /* mtsgpu_set_tuning on every member.  One key belongs to the group itself and exists for tests: "rccl_fail" != 0 makes
  * the next collectives report a failure, which exercises the fall-back to the ordered sum. */
 int  mtsgpu_group_set_tuning(mtsgpu_group *g, const char *key, long value);
+
+/* Test hook of the traversal kernels' record-tail filter: 1 when mtsgpu_upload_scene would flag a leaf entry with this TriAccel
+ * (12 dwords, include/mitsuba/render/triaccel.h:34-48) in a leaf with this box, i.e. when TriAccel::rayIntersect
+ * (triaccel.h:141-158), evaluated in binary32, provably rejects EVERY projected point (o_u + t d_u, o_v + t d_v) that lies beyond
+ * the box by more than `margin` on the triangle's u or v axis -- k_trace then does not fetch the record's tail for such a
+ * candidate (its margin is 2^-16 of the scene's largest coordinate).  No GPU needed. */
+int  mtsgpu_tail_filter_flag(const uint32_t *triaccel12, const float *box_min, const float *box_max, float margin);
 
 /* HBM triad a[i] = b[i] + s * c[i] over three arrays of `bytes` each on `device` (float4 lanes, best of `iters`
  * launches): the practical bandwidth roof next to the 8 TB/s specification.  GB/s in *gbs. */

@@ -32,7 +32,7 @@ EXPORTS = [
     "mtsgpu_make_camera_crop", "mtsgpu_hbm_triad", "mtsgpu_sampler_values", "mtsgpu_random_values", "mtsgpu_set_tuning", "mtsgpu_gather_roof",
     "mtsgpu_create_multi", "mtsgpu_group_destroy", "mtsgpu_group_size", "mtsgpu_group_ctx", "mtsgpu_group_last_error",
     "mtsgpu_group_upload_scene", "mtsgpu_group_set_camera", "mtsgpu_group_set_integrator", "mtsgpu_group_set_sampler",
-    "mtsgpu_group_set_rfilter", "mtsgpu_group_render", "mtsgpu_group_last_reduce_kind", "mtsgpu_group_reduce_note", "mtsgpu_bsdf_eval", "mtsgpu_replay_roof", "mtsgpu_group_set_tuning",
+    "mtsgpu_group_set_rfilter", "mtsgpu_group_render", "mtsgpu_group_last_reduce_kind", "mtsgpu_group_rccl_ranks", "mtsgpu_group_reduce_note", "mtsgpu_bsdf_eval", "mtsgpu_replay_roof", "mtsgpu_group_set_tuning", "mtsgpu_tail_filter_flag",
 ]
 
 
@@ -164,6 +164,7 @@ def lib():
     L.mtsgpu_bsdf_eval.argtypes = [vp, C.c_uint32, f32p, C.c_int, C.c_uint32, f32p, f32p]
     L.mtsgpu_hbm_triad.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     L.mtsgpu_replay_roof.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+    L.mtsgpu_tail_filter_flag.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float]
     L.mtsgpu_create_multi.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
     L.mtsgpu_group_destroy.argtypes = [vp]; L.mtsgpu_group_destroy.restype = None
     L.mtsgpu_group_size.argtypes = [vp]
@@ -176,6 +177,7 @@ def lib():
     L.mtsgpu_group_set_rfilter.argtypes = [vp, C.c_float, C.c_float, f32p]
     L.mtsgpu_group_render.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.mtsgpu_group_last_reduce_kind.argtypes = [vp]
+    L.mtsgpu_group_rccl_ranks.argtypes = [vp]
     L.mtsgpu_group_reduce_note.argtypes = [vp]; L.mtsgpu_group_reduce_note.restype = C.c_char_p
     L.mtsgpu_group_set_tuning.argtypes = [vp, C.c_char_p, C.c_long]
     _lib = L
@@ -516,6 +518,10 @@ class DeviceGroup:
 
     def reduce_kind(self):
         return {0: "ordered peer-copy sum", 1: "rccl ncclReduce"}.get(lib().mtsgpu_group_last_reduce_kind(self._g))
+
+    def rccl_ranks(self):
+        """ranks of the group's RCCL communicator once it has passed its self-check, else 0"""
+        return int(lib().mtsgpu_group_rccl_ranks(self._g))
 
     def set_tuning(self, **knobs):
         """mtsgpu_set_tuning on every member (and the group's own test knob rccl_fail)"""

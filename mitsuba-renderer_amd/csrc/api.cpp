@@ -597,6 +597,123 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 	return 0;
 }
 
+// ---- exact record-tail filter of k_trace: per leaf entry, one flag ----------------------------------------------------------
+// TriAccel::rayIntersect (triaccel.h:141-158) first computes the plane distance t from the record's head, then
+//     hu = o_u + t d_u - a_u,  hv = o_v + t d_v - a_v,  u = hv b_nu + hu b_nv,  v = hu c_nu + hv c_nv,  accept iff u >= 0 && v >= 0 && u + v <= 1
+// from its tail.  k_trace may skip the tail -- two 16-byte requests -- of a candidate exactly when that test is CERTAIN to fail.  It
+// knows the face through which the ray leaves the leaf it is visiting (axis, plane, side: the current exit point of the traversal,
+// sahkdtree3.h:233,248-249) and the point p = o + t d in the arithmetic of the reference; what it cannot know without the tail is
+// whether the triangle reaches beyond that face.  The flag says: for EVERY pair of binary32 values (p_u, p_v) with p_u beyond the
+// leaf's box on the u axis (either side), or p_v beyond it on the v axis, the expressions above -- evaluated in binary32 in the
+// reference's order, each operation rounded -- fail the test.  Proof per half-plane, here for p_u > hi_u:
+//   * hu = fl(p_u - a_u) >= fl(hi_u - a_u) =: h (rounding is monotone); the flag needs h > 0.
+//   * with U = hv b_nu + hu b_nv and V = hu c_nu + hv c_nv in exact arithmetic, the computed u, v differ from U, V by at most
+//     E_u = g (|hv b_nu| + |hu b_nv|) + e and E_v likewise (two roundings per term: g = 2^-22 covers 2 ulp, e the subnormal range),
+//     and fl(u + v) <= 1 needs u + v <= 1 + 2^-24.  So the test fails whenever U < -E_u, or V < -E_v, or U + V - E_u - E_v > 1 + 2^-22.
+//   * all three conditions are stable under (hu, hv) -> lambda (hu, hv), lambda >= 1 (U, V and the g-part of E scale with lambda),
+//     and every point of the half-plane hu >= h is lambda (h, w) for some real w: it suffices that for every real w one of the three
+//     holds at (h, w).  On w >= 0 and on w <= 0 each condition is "an affine function of w is positive": the maximum of three
+//     affine functions is convex, its minimum over a half-line lies at the end point or where two of them cross.
+// The bounds are evaluated in binary64 (products of two binary32 values are exact there) with g doubled for its own rounding.
+// Nothing here depends on where the triangle's vertices are: a flag that is set is a statement about the record's numbers alone.
+bool rejectsOnHalfLine(const double m[3], const double c[3]) {
+	// max_i (m_i z + c_i) > 0 for all z >= 0 ?
+	auto value = [&](double z) { double v = -INFINITY; for (int i = 0; i < 3; ++i) v = std::max(v, m[i] * z + c[i]); return v; };
+	if (!(value(0.0) > 0.0)) return false;
+	// far out: some function must grow, or a constant one must stay positive
+	double mmax = std::max(m[0], std::max(m[1], m[2]));
+	if (!(mmax >= 0.0)) return false;
+	if (mmax == 0.0) {
+		double cbest = -INFINITY;
+		for (int i = 0; i < 3; ++i) if (m[i] == 0.0) cbest = std::max(cbest, c[i]);
+		if (!(cbest > 0.0)) return false;
+	}
+	for (int i = 0; i < 3; ++i)
+		for (int j = i + 1; j < 3; ++j) {
+			if (m[i] == m[j]) continue;
+			const double z = (c[j] - c[i]) / (m[i] - m[j]);
+			if (!(z > 0.0) || !std::isfinite(z)) continue;
+			// the crossing point itself is rounded: look at it and at its neighbours
+			for (double zz : { z, z * (1.0 - 1e-12), z * (1.0 + 1e-12) })
+				if (!(value(zz) > 0.0)) return false;
+		}
+	return true;
+}
+// the half-plane {fixed coordinate beyond h (same sign as h), other coordinate w free}: U = af h' + aw w, V = bf h' + bw w
+bool rejectsBeyond(double af, double aw, double bf, double bw, double h) {
+	if (!(h != 0.0) || !std::isfinite(h) || !std::isfinite(af) || !std::isfinite(aw) || !std::isfinite(bf) || !std::isfinite(bw)) return false;
+	const double g = 0x1p-21, e = 0x1p-140;
+	for (int side = 0; side < 2; ++side) {              // w >= 0, then w = -z <= 0
+		const double aW = side ? -aw : aw, bW = side ? -bw : bw;
+		const double m[3] = { -aW - g * std::fabs(aW), -bW - g * std::fabs(bW), aW + bW - g * (std::fabs(aW) + std::fabs(bW)) };
+		const double c[3] = { -af * h - g * std::fabs(af * h) - e, -bf * h - g * std::fabs(bf * h) - e,
+		                      (af + bf) * h - g * (std::fabs(af * h) + std::fabs(bf * h)) - 1.0 - 0x1p-21 - 2 * e };
+		if (!rejectsOnHalfLine(m, c)) return false;
+	}
+	return true;
+}
+// The SAH builder puts its planes on the bounds of the (clipped) triangles, so most triangles TOUCH faces of their leaf, and for
+// a point one ulp beyond a touched face nothing can be proven (u + v may round to exactly 1).  The kernel therefore only skips a
+// tail when the point lies beyond the face by more than a margin mu (one scene-wide binary32 constant, DTraceScene::tail_margin):
+// it tests fl(p - plane) > mu, which implies p - plane > mu in exact arithmetic (rounding is monotone), and the plane is the
+// leaf's own bound or lies beyond it.  The proof is made for the half-planes beyond lo - mu / hi + mu.
+// rec: the 12 dwords of a TriAccel (triaccel.h:34-48); lo / hi: the leaf's box
+float roundedTowardZero(double x) {
+	float f = (float) x;
+	if (std::fabs((double) f) > std::fabs(x)) f = std::nextafterf(f, 0.0f);
+	return f;
+}
+bool tailFilterFlag(const uint32_t *rec, const float lo[3], const float hi[3], float margin) {
+	const uint32_t k = rec[0];
+	if (k > 2u || !(margin >= 0.0f) || !std::isfinite(margin)) return false;
+	float f[12]; std::memcpy(f, rec, 48);
+	const float a_u = f[4], a_v = f[5];
+	const double b_nu = f[6], b_nv = f[7], c_nu = f[8], c_nv = f[9];
+	const int ku = (int) ((k + 1u) % 3u), kv = (int) ((k + 2u) % 3u);          // triaccel.h:104-137
+	// hu = fl(p_u - a_u) with p_u > hi_u + mu: hu >= fl(hi_u + mu - a_u) >= that value rounded toward zero (binary64 holds the sum of
+	// three binary32 values to 2^-53, far inside the step to the next binary32 value toward zero); likewise below lo - mu
+	const float hUhi = roundedTowardZero(((double) hi[ku] + margin - a_u) * (1.0 - 0x1p-50)), hUlo = roundedTowardZero(((double) lo[ku] - margin - a_u) * (1.0 - 0x1p-50));
+	const float hVhi = roundedTowardZero(((double) hi[kv] + margin - a_v) * (1.0 - 0x1p-50)), hVlo = roundedTowardZero(((double) lo[kv] - margin - a_v) * (1.0 - 0x1p-50));
+	if (!(hUhi > 0.0f) || !(hUlo < 0.0f) || !(hVhi > 0.0f) || !(hVlo < 0.0f)) return false;
+	// fixed hu: U = hv b_nu + hu b_nv -> af = b_nv, aw = b_nu; V = hu c_nu + hv c_nv -> bf = c_nu, bw = c_nv
+	if (!rejectsBeyond(b_nv, b_nu, c_nu, c_nv, hUhi) || !rejectsBeyond(b_nv, b_nu, c_nu, c_nv, hUlo)) return false;
+	// fixed hv: af = b_nu, aw = b_nv; bf = c_nv, bw = c_nu
+	return rejectsBeyond(b_nu, b_nv, c_nv, c_nu, hVhi) && rejectsBeyond(b_nu, b_nv, c_nv, c_nu, hVlo);
+}
+// one flag per entry of the index list: the leaves' boxes come from walking the tree with the scene's box (gkdtree.h:1170-1176)
+// the margin of a scene: 2^-16 of its largest coordinate (some tens of ulps there; rays whose plane point lies closer to a face
+// than this are not filtered, everything else about the filter is independent of the choice)
+float tailFilterMargin(const mtsgpu_scene *sc) {
+	float m = 0.0f;
+	for (int a = 0; a < 3; ++a) m = std::max(m, std::max(std::fabs(sc->aabb_min[a]), std::fabs(sc->aabb_max[a])));
+	m *= 0x1p-16f;
+	return (std::isfinite(m) && m > 0.0f) ? m : 0x1p-100f;
+}
+void tailFilterFlags(const mtsgpu_scene *sc, float margin, std::vector<uint8_t> &flags) {
+	flags.assign(sc->n_indices, 0);
+	struct Item { uint32_t node; float lo[3], hi[3]; };
+	std::vector<Item> stack;
+	Item root; root.node = 0;
+	for (int a = 0; a < 3; ++a) { root.lo[a] = sc->aabb_min[a]; root.hi[a] = sc->aabb_max[a]; }
+	stack.push_back(root);
+	while (!stack.empty()) {
+		const Item it = stack.back(); stack.pop_back();
+		const uint32_t a = sc->kd_nodes[2 * (size_t) it.node], b = sc->kd_nodes[2 * (size_t) it.node + 1];
+		if (a & 0x80000000u) {
+			for (uint32_t e = a & 0x7FFFFFFFu; e < b; ++e)
+				flags[e] = tailFilterFlag(sc->triaccel + 12 * (size_t) sc->kd_indices[e], it.lo, it.hi, margin) ? 1 : 0;
+			continue;
+		}
+		const int axis = (int) (a & 3u);
+		float split; std::memcpy(&split, &b, 4);
+		const uint32_t left = it.node + ((a & 0x3FFFFFFCu) >> 2);
+		Item l = it, r = it;
+		l.node = left; l.hi[axis] = split;
+		r.node = left + 1; r.lo[axis] = split;
+		stack.push_back(r); stack.push_back(l);
+	}
+}
+
 int checkReady(mtsgpu_ctx *c) {
 	if (!c) return fail(nullptr, MTSGPU_EINVAL, "null context");
 	if (!c->haveScene) return fail(c, MTSGPU_ESTATE, "no scene uploaded");
@@ -892,7 +1009,7 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 			}
 		}
 		const uint32_t total = std::max<uint32_t>(pos, std::max(2u, topSlots));      // the LDS prefix is always there to copy
-		if (total >= (1u << 29)) return fail(c, MTSGPU_EINVAL, "kd-tree too large");
+		if (total >= (1u << 29)) return fail(c, MTSGPU_EINVAL, "kd-tree too large");      // absolute child indices; k_trace's stack words keep node index * 2 below bit 30
 		std::vector<uint32_t> dev(2 * (size_t) total, 0u);
 		dev[2] = 0x80000000u; dev[3] = 0u;           // padding slot: empty leaf, never referenced
 		for (uint32_t i = 0; i < N; ++i) {
@@ -909,15 +1026,20 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 		// (Shape::isOccluder, shape.h:324)
 		const size_t LS = 4 * (size_t) kLeafStride;                 // dwords per record slot
 		std::vector<uint32_t> ta(LS * ((size_t) sc->n_indices + 1), 0u);
+		std::vector<uint8_t> tailFlags;
+		d.tail_margin = tailFilterMargin(sc);
+		if (trace_tail_filter()) tailFilterFlags(sc, d.tail_margin, tailFlags);      // experiment builds only (trace.hip: MG_TAIL_FILTER)
+		else tailFlags.assign(sc->n_indices, 0);
 		for (uint32_t e = 0; e < sc->n_indices; ++e) {
 			const uint32_t prim = sc->kd_indices[e];
 			uint32_t *dst = &ta[LS * (size_t) e];
 			std::memcpy(dst, sc->triaccel + 12 * (size_t) prim, 48);
 			// dword 0 = k<<30 | non-occluder<<29 | primitive id (the head of the record decides everything
 			// up to the plane distance); dword 10 stays the shape index
-			if (prim >= (1u << 29)) return fail(c, MTSGPU_EINVAL, "more than 2^29 primitives");
+			if (prim >= (1u << 28)) return fail(c, MTSGPU_EINVAL, "more than 2^28 primitives");
 			const bool isShape = dst[0] == MTSGPU_KNOTRIANGLE;
-			dst[0] = (std::min(dst[0], 3u) << 30) | (sc->shape_bsdf[dst[10]] < 0 ? 0x20000000u : 0u) | prim;
+			// bit 28: the record's tail may be skipped for candidates beyond the leaf's box on a projection axis (tailFilterFlag)
+			dst[0] = (std::min(dst[0], 3u) << 30) | (sc->shape_bsdf[dst[10]] < 0 ? 0x20000000u : 0u) | (tailFlags[e] ? 0x10000000u : 0u) | prim;
 			dst[11] = 0;
 			if ((dst[0] >> 30) == 3u) {
 				// k == 3: a degenerate triangle (dword 1 = 0) or a non-triangle shape (dword 1 = shape type,
@@ -931,6 +1053,10 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 			}
 		}
 		rc |= upload(c, (const uint32_t **) &d.leaf_ta, ta.data(), ta.size());
+		if (getenv("MTSGPU_DEBUG")) {
+			size_t nf = 0; for (uint8_t f : tailFlags) nf += f;
+			fprintf(stderr, "[mtsgpu] record-tail filter: %zu of %u leaf entries flagged (%.3f)\n", nf, sc->n_indices, sc->n_indices ? (double) nf / sc->n_indices : 0.0);
+		}
 		// per-primitive position / normal records for the shading kernels
 		const size_t TS = 4 * (size_t) kTriStride;                    // floats per record (one 128-byte line)
 		std::vector<float> triRec(TS * ((size_t) sc->n_tris + 1), 0.0f);
@@ -1635,6 +1761,11 @@ int mtsgpu_li_samples(mtsgpu_ctx *c, const uint32_t *pix_samples, uint32_t n, fl
 
 // --- host-side flattening ------------------------------------------------------
 struct mtsgpu_flat_scene { FlatScene fs; };
+
+int mtsgpu_tail_filter_flag(const uint32_t *triaccel12, const float *box_min, const float *box_max, float margin) {
+	if (!triaccel12 || !box_min || !box_max) return 0;
+	return tailFilterFlag(triaccel12, box_min, box_max, margin) ? 1 : 0;
+}
 
 int mtsgpu_flatten(const mtsgpu_scene_desc *desc, const mtsgpu_kd_params *kd, mtsgpu_flat_scene **out) {
 	if (!desc || !out) return fail(nullptr, MTSGPU_EINVAL, "null argument");

@@ -29,6 +29,7 @@ struct Rccl {
 	decltype(&ncclGroupEnd) groupEnd = nullptr;
 	decltype(&ncclReduce) reduce = nullptr;
 	decltype(&ncclGetErrorString) errorString = nullptr;
+	decltype(&ncclCommCount) commCount = nullptr;            // optional: the self-check asks every communicator for its size
 
 	bool load(std::string &why) {
 		// MTSGPU_RCCL_LIB names the library to load (a site's own build; tests point it at a file that does not exist to
@@ -49,6 +50,7 @@ struct Rccl {
 		groupEnd = (decltype(groupEnd)) dlsym(handle, "ncclGroupEnd");
 		reduce = (decltype(reduce)) dlsym(handle, "ncclReduce");
 		errorString = (decltype(errorString)) dlsym(handle, "ncclGetErrorString");
+		commCount = (decltype(commCount)) dlsym(handle, "ncclCommCount");
 		if (!commInitAll || !commDestroy || !groupStart || !groupEnd || !reduce || !errorString) {
 			why = "librccl lacks one of ncclCommInitAll / ncclCommDestroy / ncclGroupStart / ncclGroupEnd / ncclReduce";
 			dlclose(handle); handle = nullptr;
@@ -69,6 +71,7 @@ struct mtsgpu_group {
 	std::string rcclNote;                  // why RCCL is not used, if it is not
 	float *staging = nullptr; size_t stagingFloats = 0;   // on members[0]'s device: a peer's film (ordered sum) / the RCCL result
 	int lastReduceKind = 0;
+	int rcclRanks = 0;                     // ranks of the communicator that passed the self-check (0: none did)
 	std::string reduceNote;                // why the last frame fell back to the ordered sum ("" when it did not)
 	bool testFailReduce = false;           // tests: the next collective reports a failure (mtsgpu_group_set_tuning "rccl_fail")
 	std::string error;
@@ -97,6 +100,51 @@ template <typename F> int forAll(mtsgpu_group *g, const char *what, F &&f) {
 	return 0;
 }
 
+bool selfCheckComms(mtsgpu_group *g, std::string &why) {
+	const int n = (int) g->members.size();
+	for (int i = 0; i < n; ++i) {
+		if (!g->comms[i]) { why = "ncclCommInitAll left member " + std::to_string(i) + " without a communicator"; return false; }
+		if (g->rccl.commCount) {
+			int cnt = -1;
+			const ncclResult_t r = g->rccl.commCount(g->comms[i], &cnt);
+			if (r != ncclSuccess || cnt != n) {
+				why = "communicator of member " + std::to_string(i) + " reports " + std::to_string(cnt) + " ranks, the group has " + std::to_string(n);
+				return false;
+			}
+		}
+	}
+	std::vector<float *> buf(n, nullptr);
+	auto release = [&]() { for (int i = 0; i < n; ++i) if (buf[i]) { (void) hipSetDevice(g->devices[i]); (void) hipFree(buf[i]); } };
+	hipError_t he = hipSuccess;
+	const float one = 1.0f, zero = 0.0f;
+	for (int i = 0; i < n && he == hipSuccess; ++i) {
+		if ((he = hipSetDevice(g->devices[i])) != hipSuccess) break;
+		if ((he = hipMalloc((void **) &buf[i], 2 * sizeof(float))) != hipSuccess) break;
+		if ((he = hipMemcpy(buf[i], &one, sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) break;
+		he = hipMemcpy(buf[i] + 1, &zero, sizeof(float), hipMemcpyHostToDevice);
+	}
+	if (he != hipSuccess) { why = std::string("buffers of the probe: ") + hipGetErrorString(he); release(); return false; }
+	ncclResult_t r = g->testFailReduce ? ncclInternalError : g->rccl.groupStart();
+	if (r == ncclSuccess) {
+		for (int i = 0; i < n && r == ncclSuccess && he == hipSuccess; ++i) {
+			if ((he = hipSetDevice(g->devices[i])) != hipSuccess) break;
+			r = g->rccl.reduce(buf[i], buf[i] + 1, 1, ncclFloat, ncclSum, 0, g->comms[i], g->members[i]->stream);
+		}
+		const ncclResult_t r2 = g->rccl.groupEnd();
+		if (r == ncclSuccess) r = r2;
+	}
+	for (int i = 0; i < n && he == hipSuccess && r == ncclSuccess; ++i)
+		if ((he = hipSetDevice(g->devices[i])) == hipSuccess) he = hipStreamSynchronize(g->members[i]->stream);
+	float sum = -1.0f;
+	if (he == hipSuccess && r == ncclSuccess && (he = hipSetDevice(g->devices[0])) == hipSuccess)
+		he = hipMemcpy(&sum, buf[0] + 1, sizeof(float), hipMemcpyDeviceToHost);
+	release();
+	if (r != ncclSuccess) { why = std::string("ncclReduce of the probe: ") + (g->testFailReduce ? "failure injected by the rccl_fail test knob" : g->rccl.errorString(r)); return false; }
+	if (he != hipSuccess) { why = std::string("probe: ") + hipGetErrorString(he); return false; }
+	if (sum != (float) n) { why = "a sum of ones over " + std::to_string(n) + " members arrived as " + std::to_string(sum); return false; }
+	return true;
+}
+
 // librccl and the communicator over the group's devices, created the first time a collective is wanted
 bool ensureComms(mtsgpu_group *g) {
 	if (!g->comms.empty()) return true;
@@ -109,6 +157,18 @@ bool ensureComms(mtsgpu_group *g) {
 		g->comms.clear();
 		return false;
 	}
+	// Self-check before the first frame depends on it: every member got a communicator, every communicator reports the
+	// group's size, and a one-float sum of ones arrives at the root as the number of members.  A group that fails it adds its
+	// films up in member order and says why (mtsgpu_group_reduce_note).
+	std::string why;
+	if (!selfCheckComms(g, why)) {
+		for (ncclComm_t cm : g->comms) if (cm) (void) g->rccl.commDestroy(cm);
+		g->comms.clear();
+		g->rcclNote = "RCCL self-check: " + why;
+		(void) hipGetLastError();
+		return false;
+	}
+	g->rcclRanks = (int) g->members.size();
 	return true;
 }
 
@@ -170,6 +230,8 @@ mtsgpu_ctx *mtsgpu_group_ctx(mtsgpu_group *g, int i) {
 const char *mtsgpu_group_last_error(const mtsgpu_group *g) { return g ? g->error.c_str() : g_lastError.c_str(); }
 
 int mtsgpu_group_last_reduce_kind(const mtsgpu_group *g) { return g ? g->lastReduceKind : -1; }
+
+int mtsgpu_group_rccl_ranks(const mtsgpu_group *g) { return g ? g->rcclRanks : 0; }
 
 int mtsgpu_group_upload_scene(mtsgpu_group *g, const mtsgpu_scene *scene) {
 	if (!g) return gfail(nullptr, MTSGPU_EINVAL, "null group");
@@ -300,6 +362,7 @@ int mtsgpu_group_render(mtsgpu_group *g, int block_size, int ordered_reduce, vol
 			// communicator that has failed once is not trusted again -- and add the films up in member order instead.
 			for (ncclComm_t cm : g->comms) if (cm) (void) g->rccl.commDestroy(cm);
 			g->comms.clear();
+			g->rcclRanks = 0;
 			g->rcclNote = why;
 			(void) hipGetLastError();
 		}

@@ -105,6 +105,7 @@ struct DScene {
 	int32_t background_lum;
 	uint32_t n_lums, n_nodes, n_tris, n_shapes;
 	float aabb_min[3], aabb_max[3];
+	float tail_margin;            // record-tail filter of k_trace (api.cpp: tailFilterFlag): how far beyond a leaf's face a plane point must lie
 };
 
 // What k_trace needs of the scene (a kernel argument: the fewer scalar registers it pins, the fewer get spilled)
@@ -114,10 +115,11 @@ struct DTraceScene {
 	const uint32_t *shape_bin;
 	uint32_t has_shapes;
 	float aabb_min[3], aabb_max[3];
+	float tail_margin;
 };
 inline DTraceScene trace_scene(const DScene &sc) {
 	DTraceScene t;
-	t.nodes = sc.nodes; t.leaf_ta = sc.leaf_ta; t.shape_bin = sc.shape_bin; t.has_shapes = sc.has_shapes;
+	t.nodes = sc.nodes; t.leaf_ta = sc.leaf_ta; t.shape_bin = sc.shape_bin; t.has_shapes = sc.has_shapes; t.tail_margin = sc.tail_margin;
 	for (int i = 0; i < 3; ++i) { t.aabb_min[i] = sc.aabb_min[i]; t.aabb_max[i] = sc.aabb_max[i]; }
 	return t;
 }
@@ -371,6 +373,7 @@ void launch_add_blocks(hipStream_t s, const DConfig &cfg, const TileMeta *tiles,
 void launch_fill_u32(hipStream_t s, uint32_t *p, uint32_t v, size_t n);
 void launch_iota(hipStream_t s, uint32_t *p, uint32_t n);
 size_t trace_spill_levels();
+int trace_tail_filter();          // MG_TAIL_FILTER of the build: scene upload computes the per-entry flags only when the kernels use them
 uint32_t trace_top_nodes();       // device nodes k_trace copies into LDS: the breadth-first top of the tree
 size_t trace_stack_levels();      // depth of the traversal stack (LDS + spill levels)
 

@@ -18,7 +18,17 @@ namespace mg {
 // (sahkdtree3.h:130-144) is kept (LDS) because it decides equal-t ties.
 // ===========================================================================
 
+// MG_TAIL_FILTER: the exact record-tail filter (api.cpp: tailFilterFlag).  The stack words then carry the split axis of their node
+// in bits 30-31 (node index * 2 + side stays below bit 30), so that the leaf loop knows through which face the ray leaves the
+// leaf -- axis, plane, side -- without fetching anything.  Exact (bit-identical results: the GPU suite and the film A/B ran on it),
+// it removes a quarter of the tail requests of a C3 frame -- and is NEUTRAL in time (profiles/r06g_exp_trace_exact_tail_filter.txt:
+// the skipped tails are L1 hits on their head's line, the test costs six vector instructions per candidate), so the product is
+// built without it.
+#ifndef MG_TAIL_FILTER
+#define MG_TAIL_FILTER 0
+#endif
 size_t trace_spill_levels() { return kSpillLevels; }      // in dwords per thread
+int trace_tail_filter() { return MG_TAIL_FILTER; }          // 0: the kernels were built without the record-tail filter (the default), 1: both kernels, 2: any-hit only
 size_t trace_stack_levels() { return kStackLDS + kSpillLevels; }
 uint32_t trace_top_nodes() { return 2u * kTopPairs; }
 
@@ -297,7 +307,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						++sp;
 						const uint32_t farRight = A ? 1u : 0u;
 						const float distToSplit = (split - sel3(ox, oy, oz, axis)) * sel3(rx, ry, rz, axis);
-						ex_ref = (cur << 1) | farRight;
+						ex_ref = (cur << 1) | farRight | (MG_TAIL_FILTER ? ((uint32_t) axis << 30) : 0u);
 						ex_t = distToSplit;
 						const float px = ox + distToSplit * dx, py = oy + distToSplit * dy, pz = oz + distToSplit * dz;
 						exx = (axis == 0) ? split : px; exy = (axis == 1) ? split : py; exz = (axis == 2) ? split : pz;   // selects, not branches
@@ -317,6 +327,19 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				MG_WSLOT(w_outer);
 				bool hitShadow = false, more = false;
 				{
+#if MG_TAIL_FILTER
+					// The face through which the ray leaves this leaf: the plane of the current exit point (sahkdtree3.h:233,248-249) on its
+					// axis; the leaf lies below the plane when the exit point's far child is the right one.  Kept with the sign that turns
+					// "beyond the face" into "greater than": fO + t fD is the plane point's coordinate on that axis -- the very expression
+					// o_u + t d_u (or o_v + t d_v) of triaccel.h:151-152 when the axis is one of the triangle's projection axes, negated
+					// exactly when the leaf lies above the plane -- and fS the plane.  The end of the ray itself is no face (fS = inf).
+					const uint32_t fAxisHi = ex_ref & 0xC0000000u;            // the axis where the records keep k; 3 for the sentinel
+					const int fAxis = (int) (ex_ref >> 30);
+					const uint32_t fFlip = (ex_ref & 1u) ? 0u : 0x80000000u;
+					const float fO = __uint_as_float(__float_as_uint(sel3(ox, oy, oz, fAxis)) ^ fFlip);
+					const float fD = __uint_as_float(__float_as_uint(sel3(dx, dy, dz, fAxis)) ^ fFlip);
+					const float fS = ex_ref == kSentinel ? MG_INF : __uint_as_float(__float_as_uint(sel3(exx, exy, exz, fAxis)) ^ fFlip);
+#endif
 					uint32_t e = (e_cont != kNoPrim) ? e_cont : (nd.x & 0x7FFFFFFFu);     // resume an interrupted leaf
 					const uint32_t last = nd.y;
 					// record = 3 x 16 B: A = (k<<30 | non-occluder<<29 | prim, n_u, n_v, n_d), B = (a_u, a_v, b_nu, b_nv),
@@ -334,7 +357,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					do { if (more) {
 						uint4 An = A;
 						if (e + 1 != last) { An = ld_stream<2>(leaf_head(sc, e + 1)); if (COUNT) { g_head++; rec_add(kReqLeaf, kLeafStride * (e + 1)); } }      // next record's head in flight
-						const uint32_t prim = A.x & 0x1FFFFFFFu, k = A.x >> 30;
+						const uint32_t prim = A.x & 0x0FFFFFFFu, k = A.x >> 30;
 						if (COUNT) c_idx++;
 						MG_WSLOT(w_leaf);
 						// Flat form of the mailbox test + TriAccel::rayIntersect: the plane distance t is computed for
@@ -368,7 +391,14 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 						const float d_u = k0 ? dy : (k1 ? dz : dx), d_v = k0 ? dz : (k1 ? dx : dy), d_k = k0 ? dx : (k1 ? dy : dz);
 						const float recip = 1.0f / (d_u * n_u + d_v * n_v + d_k);
 						const float t = (n_d - o_u * n_u - o_v * n_v - o_k) * recip;
+#if MG_TAIL_FILTER
+						// flagged entry (api.cpp: tailFilterFlag), exit axis one of the triangle's projection axes (not its k), plane point
+						// beyond the face by more than the margin: TriAccel::rayIntersect is certain to reject, the tail is not fetched
+						const bool beyond = (MG_TAIL_FILTER == 1 || MODE != 0) && (A.x & 0x10000000u) && ((A.x ^ fAxisHi) & 0xC0000000u) != 0u && (fO + t * fD) - fS > sc.tail_margin;
+						if (ok && !(t < mint || t > maxt) && !beyond) {
+#else
 						if (ok && !(t < mint || t > maxt)) {
+#endif
 							const uint4 B = ld_stream<2>(leaf_tail(sc, e, 0));
 							const uint4 C = ld_stream<2>(leaf_tail(sc, e, 1));         // c_nu, c_nv, shape index, -
 							if (COUNT) { g_tail += 2u; rec_add(kReqLeaf, kLeafStride * e + 1u); rec_add(kReqLeaf, kLeafStride * e + 2u); }
@@ -415,7 +445,7 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 							ex_node = kNullNode; ex_ref = kSentinel;
 						} else {
 							// the exit point is a function of (parent node, ray): rebuilt with the reference's formulas (sahkdtree3.h:233,248-249)
-							const uint2 pn = load_node(ref >> 1);
+							const uint2 pn = load_node(MG_TAIL_FILTER ? ((ref & 0x3FFFFFFFu) >> 1) : (ref >> 1));
 							const int axis = (int) (pn.x & 3u);
 							const float split = __uint_as_float(pn.y);
 							ex_node = (pn.x >> 2) + (ref & 1u);

@@ -257,7 +257,7 @@ def test_bench_world2_branch_on_one_gpu(gpu_lib, mts, orc, tmp_path):
     for mode, extra, spp_total in (("weak", ["--spp", "4"], 8), ("strong", ["--spp-total", "16"], 16)):
         out = str(tmp_path / ("film_%s.npy" % mode))
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--res", "96", "--grid", "24",
-               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-1spp", "--host-kd", "--dump-film", out] + extra
+               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-1spp", "--host-kd", "--c4-spp", "64", "--c4-steps", "1", "--dump-film", out] + extra
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
@@ -265,6 +265,14 @@ def test_bench_world2_branch_on_one_gpu(gpu_lib, mts, orc, tmp_path):
         assert rec["n_gpus"] == 2 and rec["scaling"] == mode and rec["value"] > 0
         assert len(rec["rank_ms"]) == 2 and len(rec["reduce_ms"]) == 2 and min(rec["rank_ms"]) > 0
         assert rec["roofline"]["frac"] > 0 and "cpu_baseline" not in rec
+        # the film reduce names itself; two ranks on one GPU cannot form an RCCL communicator (gloo on host copies: 0 RCCL ranks)
+        assert "gloo" in rec["reduce_kind"] and rec["rccl_ranks"] == 0
+        if mode == "weak":
+            # BASELINE.json configs[3] rides along: the C4 strong-scaling frame over the same two ranks
+            c4 = rec["c4_strong"]
+            assert c4["scaling"] == "strong" and c4["n_gpus"] == 2 and c4["spp_total"] == 64 and c4["value"] > 0 and "c4_strong" in rec["config"]["workload"]
+        else:
+            assert rec["c4_strong"] is None
         cam = mts.PerspectiveCamera.for_description(sd, 96, 96)
         it = mts.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth)
         it.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp_total, seed=0x5EED)

@@ -111,8 +111,11 @@ def test_bench_over_two_gpus_uses_the_nccl_backend(gpu_lib, mts, tmp_path):
         pytest.skip("one GPU visible: the nccl branch of bench.py needs two")
     out, gout = str(tmp_path / "film.npy"), str(tmp_path / "group.npy")
     rec = _bench(["--gpus", "2", "--res", "128", "--grid", "24", "--spp", "4", "--steps", "1", "--warmup", "0", "--host-kd",
-                  "--no-1spp", "--no-cpu-baseline", "--dump-film", out, "--dump-group-film", gout])
+                  "--no-1spp", "--no-cpu-baseline", "--c4-spp", "64", "--c4-steps", "1", "--dump-film", out, "--dump-group-film", gout])
     assert rec["n_gpus"] == 2 and len(rec["rank_ms"]) == 2
+    assert rec["rccl_ranks"] == 2 and "rccl" in rec["reduce_kind"]           # RCCL's first collective summed one per rank
+    assert rec["c4_strong"]["value"] > 0 and rec["c4_strong"]["n_gpus"] == 2
+    assert rec["group"].get("rccl_ranks") in (0, 2)                          # 2 unless the group fell back to the ordered sum (it says why)
     assert "error" not in rec["group"], rec["group"]
     sd = mts.scenes.cornell_c3(grid=24, sphere_subdiv=5)
     it = mts.MIPathTracer(maxDepth=sd.max_depth, rrDepth=sd.rr_depth)

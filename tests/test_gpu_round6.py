@@ -25,3 +25,76 @@ def test_ld_apply_in_memory_with_many_slots_groups_and_chunked_launches(gpu_lib,
         o, _ = orc.render(oscene.scene, ocam, op, rect=(x0, y0, x0 + 2, y0 + 1))
         assert np.array_equal(film[y0:y0 + 1, x0:x0 + 2].view(np.uint32), o[y0:y0 + 1, x0:x0 + 2].view(np.uint32)), (x0, y0)
         assert o[y0, x0, 4] > 0
+
+
+def _group(mts, devices):
+    sd = mts.scenes.cornell_c1()
+    scene = mts.Scene(sd); cam = mts.PerspectiveCamera.for_description(sd, 64, 48)
+    g = mts.DeviceGroup(devices, maxDepth=4)
+    g.preprocess(scene, cam, sampler="independent", sampleCount=4)
+    return g, scene, cam
+
+
+def test_group_rccl_self_check_and_rank_count(gpu_lib, mts):
+    """mtsgpu_group_render checks its communicator before the first frame depends on it (ncclCommInitAll gave every member a
+    communicator, a one-float sum of ones arrives as the number of members) and reports the verified rank count; a probe
+    that fails (injected) leaves the group on the ordered sum with the reason, and is an error when RCCL was demanded"""
+    g, scene, cam = _group(mts, [0])
+    assert g.rccl_ranks() == 0                           # no collective asked for yet
+    assert g.render(ordered_reduce=2) and g.reduce_kind() == "rccl ncclReduce"
+    assert g.rccl_ranks() == 1
+    ref = g.film()
+    g.set_tuning(rccl_fail=1)                            # the collective of the next frame fails: RCCL is given up
+    assert g.render(ordered_reduce=2) and g.rccl_ranks() == 0 and np.array_equal(g.film().view(np.uint32), ref.view(np.uint32))
+    g2, _, _ = _group(mts, [0])
+    g2.set_tuning(rccl_fail=1)                           # the probe itself fails
+    with pytest.raises(mts.MtsGpuError, match="self-check"):
+        g2.render(ordered_reduce=2)
+    assert g2.rccl_ranks() == 0
+    g2.set_tuning(rccl_fail=0)
+    assert g2.render() and np.array_equal(g2.film().view(np.uint32), ref.view(np.uint32))
+
+
+def test_group_rccl_reduce_equals_the_ordered_sum_on_eight_gpus(gpu_lib, mts):
+    """needs eight GPUs (skipped below): the node-sized form of the two-GPU test -- ncclCommInitAll over eight devices, the
+    self-check, ONE ncclReduce of the films (renderproc.cpp:123-130 in one collective) against the ordered peer-copy sum and
+    against the unsharded render; with the box filter every pixel has one writer, so all three films are equal bit for bit"""
+    import torch
+    if torch.cuda.device_count() < 8:
+        pytest.skip("fewer than eight GPUs")
+    g, scene, cam = _group(mts, list(range(8)))
+    assert g.render(ordered_reduce=1) and g.reduce_kind() == "ordered peer-copy sum"
+    a = g.film()
+    try:
+        assert g.render(ordered_reduce=2)
+    except mts.MtsGpuError as e:
+        pytest.skip("RCCL could not be initialised here: %s" % e)
+    assert np.array_equal(g.film().view(np.uint32), a.view(np.uint32)), g.reduce_note()
+    if g.reduce_kind() != "rccl ncclReduce":
+        pytest.skip("the collective fell back to the ordered sum (film still equal): %s" % g.reduce_note())
+    assert g.rccl_ranks() == 8
+    one, _, _ = _group(mts, [0])
+    assert one.render() and np.array_equal(one.film().view(np.uint32), a.view(np.uint32))
+
+
+def test_exact_tail_filter_variant_matches_the_oracle(gpu_lib, mts, orc, tmp_path):
+    """the record-tail filter build of the traversal kernels (tools/build_variant.sh tf -DMG_TAIL_FILTER=1; not the product:
+    it is time-neutral, profiles/r06g_*) skips a quarter of the record tails and must change nothing: the film of a child
+    process that loads the variant equals the oracle's bit for bit.  Skipped when the variant library has not been built"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "mitsuba-renderer_amd", "libmtsgpu_tf.so")
+    if not os.path.exists(lib):
+        pytest.skip("libmtsgpu_tf.so not built")
+    out = str(tmp_path / "film.npy")
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import _pkgload; pkg = _pkgload.load(); "
+            "sd = pkg.scenes.cornell_c5(sphere_subdiv=3); it = pkg.MIPathTracer(maxDepth=12); "
+            "it.preprocess(pkg.Scene(sd), pkg.PerspectiveCamera.for_description(sd, 96, 96), sampler='ldsampler', sampleCount=16, seed=11); "
+            "assert it.render(); assert pkg.lib().mtsgpu_source_hash; np.save(%r, it.film())") % (root, out)
+    env = dict(os.environ, MTSGPU_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    sd = mts.scenes.cornell_c5(sphere_subdiv=3)
+    ofilm, _ = orc.render(orc.FlatScene(sd).scene, orc.make_camera(sd, 96, 96),
+                          orc.render_params(12, sampler=mts.abi.SAMPLER_LD_KEYED, spp=16, seed=11))
+    assert np.array_equal(np.load(out).view(np.uint32), ofilm.view(np.uint32))
