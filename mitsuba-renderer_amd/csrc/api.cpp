@@ -978,6 +978,12 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 	c->haveScene = false;
 	DScene d{};
 	int rc = 0;
+	// entryOld[e]: which entry of the index list the device's leaf-record slot e holds.  The identity, unless the experiment knob
+	// MTSGPU_LEAF_ORDER=1 lays the leaves' runs out in the order of their nodes in the device tree (treelet order) instead of the
+	// builder's index-list order (profiles/r06h_*); leafFirst[i]: first slot of the leaf with (old) node index i
+	std::vector<uint32_t> entryOld(sc->n_indices), leafFirst;
+	for (uint32_t e = 0; e < sc->n_indices; ++e) entryOld[e] = e;
+	const bool leafReorder = getenv("MTSGPU_LEAF_ORDER") && atoi(getenv("MTSGPU_LEAF_ORDER")) == 1;
 	{
 		// Device node order.  The first trace_top_nodes() slots hold the root and the sibling pairs below it in
 		// breadth-first order: k_trace keeps that prefix in LDS.  After it, 128-byte lines (16 nodes) are filled with
@@ -1012,9 +1018,26 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 		if (total >= (1u << 29)) return fail(c, MTSGPU_EINVAL, "kd-tree too large");      // absolute child indices; k_trace's stack words keep node index * 2 below bit 30
 		std::vector<uint32_t> dev(2 * (size_t) total, 0u);
 		dev[2] = 0x80000000u; dev[3] = 0u;           // padding slot: empty leaf, never referenced
+		if (leafReorder) {
+			std::vector<std::pair<uint32_t, uint32_t>> leaves;      // (device node index, old node index)
+			uint64_t covered = 0;
+			for (uint32_t i = 0; i < N; ++i)
+				if (isLeaf(i)) { leaves.emplace_back(newIndex[i], i); covered += sc->kd_nodes[2 * (size_t) i + 1] - (sc->kd_nodes[2 * (size_t) i] & 0x7FFFFFFFu); }
+			if (covered == sc->n_indices) {           // every entry belongs to exactly one leaf (what the builders produce)
+				std::sort(leaves.begin(), leaves.end());
+				leafFirst.assign(N, 0u);
+				uint32_t at = 0;
+				for (const auto &lf : leaves) {
+					const uint32_t first = sc->kd_nodes[2 * (size_t) lf.second] & 0x7FFFFFFFu, end = sc->kd_nodes[2 * (size_t) lf.second + 1];
+					leafFirst[lf.second] = at;
+					for (uint32_t e = first; e < end; ++e) entryOld[at++] = e;
+				}
+			}
+		}
 		for (uint32_t i = 0; i < N; ++i) {
-			const uint32_t a = sc->kd_nodes[2 * (size_t) i], b = sc->kd_nodes[2 * (size_t) i + 1];
+			uint32_t a = sc->kd_nodes[2 * (size_t) i], b = sc->kd_nodes[2 * (size_t) i + 1];
 			uint32_t *o = &dev[2 * (size_t) newIndex[i]];
+			if ((a & 0x80000000u) && !leafFirst.empty()) { const uint32_t n = b - (a & 0x7FFFFFFFu); a = 0x80000000u | leafFirst[i]; b = leafFirst[i] + n; }
 			if (a & 0x80000000u) { o[0] = a; o[1] = b; }
 			else { o[0] = (a & 3u) | (newIndex[leftOf(i)] << 2); o[1] = b; }     // absolute left-child index (< 2^29)
 		}
@@ -1030,9 +1053,10 @@ int mtsgpu_upload_scene(mtsgpu_ctx *c, const mtsgpu_scene *sc) {
 		d.tail_margin = tailFilterMargin(sc);
 		if (trace_tail_filter()) tailFilterFlags(sc, d.tail_margin, tailFlags);      // experiment builds only (trace.hip: MG_TAIL_FILTER)
 		else tailFlags.assign(sc->n_indices, 0);
-		for (uint32_t e = 0; e < sc->n_indices; ++e) {
+		for (uint32_t slot = 0; slot < sc->n_indices; ++slot) {
+			const uint32_t e = entryOld[slot];
 			const uint32_t prim = sc->kd_indices[e];
-			uint32_t *dst = &ta[LS * (size_t) e];
+			uint32_t *dst = &ta[LS * (size_t) slot];
 			std::memcpy(dst, sc->triaccel + 12 * (size_t) prim, 48);
 			// dword 0 = k<<30 | non-occluder<<29 | primitive id (the head of the record decides everything
 			// up to the plane distance); dword 10 stays the shape index

@@ -10,8 +10,9 @@ if knobs.pop("debug", "0") == "1":
     os.environ["MTSGPU_DEBUG"] = "1"
 count = knobs.pop("count", "0") == "1"
 sampler = knobs.pop("sampler", "ldsampler")
+grid = int(knobs.pop("grid", "320"))          # 1000 = the 10 M-triangle scene
 timing = knobs.pop("timing", "1") == "1"      # timing=0: no HIP events around the launches (the frame as bench.py times it)
-sd = pkg.scenes.cornell_c3()
+sd = pkg.scenes.cornell_c3(grid=grid)
 scene = pkg.Scene(sd, None, gpu_binning=True, gpu_exact=True)
 cam = pkg.PerspectiveCamera.for_description(sd, res, res)
 it = pkg.MIPathTracer(maxDepth=sd.max_depth)
