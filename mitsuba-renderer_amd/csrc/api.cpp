@@ -277,7 +277,10 @@ int readCounters(mtsgpu_ctx *c) {
 // Closest-hit launch over queue[0..n) with the material sort, then the per-bin segment sizes (one blocking read of the
 // counters).  A shard segment that overflowed (possible only with dynamically claimed batches, see ensurePaths) makes
 // the launch run again with static dealing: tracing a ray twice writes the same hit twice.
-int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent, BinView *views, const std::function<int()> &afterLaunch = nullptr) {
+// pairWith (knob "merged"): the any-hit queue of the previous bounce rides in the same launch (k_trace_pair)
+struct PairedShadow { const DQueues *q; uint32_t n; bool coherent; };
+int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent, BinView *views, const std::function<int()> &afterLaunch = nullptr,
+                const PairedShadow *pairWith = nullptr) {
 	hipStream_t s = c->stream;
 	const size_t counterBytes = kNumCounters * kCounterStride * sizeof(uint32_t);
 	for (int attempt = 0; attempt < 2; ++attempt) {
@@ -285,7 +288,10 @@ int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent,
 		c->q.force_static = attempt ? 1u : 0u;
 		hipEvent_t *ev = c->timeKernels ? nextTraceEvents(c, coherent ? 1 : 0) : nullptr;
 		if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
-		launch_trace(s, 0, c->countTraversal && attempt == 0, true, c->dsc, c->paths, c->q, queue, n, coherent);
+		if (pairWith && attempt == 0 && !c->countTraversal)
+			launch_trace_pair(s, c->dsc, c->paths, c->q, queue, n, coherent, *pairWith->q, pairWith->q->shadow, pairWith->n, pairWith->coherent);
+		else
+			launch_trace(s, 0, c->countTraversal && attempt == 0, true, c->dsc, c->paths, c->q, queue, n, coherent);
 		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
 		c->q.force_static = 0;
 		HIPCHK(c, hipGetLastError());
@@ -508,6 +514,8 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 	// leave, i.e. into the 0.3-0.7 ms at the end of that launch in which its longest rays finish alone.  Legal either way: the
 	// any-hit kernel only parks direct-light terms, the shading of bounce b + 1 waits for both.
 	const long overlap = tuningOr(c, "overlap", 0);
+	// merged = 1: the held-back any-hit queue rides in the next closest-hit LAUNCH (k_trace_pair: one footprint, no second stream)
+	const bool merged = tuningOr(c, "merged", 0) != 0 && !overlap && !c->countTraversal;
 	uint32_t nQ = nPaths;
 	uint32_t *cur = c->queueA, *nxt = c->queueB;
 	bool first = true;       // camera rays and their shadow rays are coherent: plain 64-ray batches win there
@@ -548,7 +556,15 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		rayQueues(c, cur, nxt);
 		// closest hit + material sort (and, behind it, the any-hit launch of the previous bounce that was held back)
 		BinView views[kNumBins];
-		int rc = traceAndBin(c, cur, nQ, first, views, flushHeld); if (rc) return rc;
+		int rc;
+		if (merged && held.pending) {
+			const PairedShadow pair{ &held.q, held.n, held.coherent };
+			held.pending = false;
+			rc = traceAndBin(c, cur, nQ, first, views, nullptr, &pair);
+		} else {
+			rc = traceAndBin(c, cur, nQ, first, views, flushHeld);
+		}
+		if (rc) return rc;
 		c->stats.rays_closest += nQ;
 		// the shading of this bounce adds to Li after the shadow rays of the previous one have (path.cpp:124 before :80)
 		if (shadowPending && overlap) HIPCHK(c, hipStreamWaitEvent(s, c->evShadow[(b - 1) & 1], 0));
@@ -565,7 +581,7 @@ int runBounces(mtsgpu_ctx *c, const DConfig &cfg, uint32_t nPaths, volatile cons
 		if (nShadow) {
 			DQueues q2 = c->q; q2.spill = c->spillShadow;
 			c->lastPass.shadowMax = std::max(c->lastPass.shadowMax, nShadow);
-			if (overlap == 2 && nNext > 0) {
+			if ((overlap == 2 || merged) && nNext > 0) {
 				held.pending = true; held.q = q2; held.n = nShadow; held.coherent = first; held.bounce = b;
 			} else {
 				rc = launchShadow(q2, nShadow, first, b); if (rc) return rc;
@@ -1279,7 +1295,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 2 }, { "overlap_delay_us", 0, 100000 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 }, { "ray_queues", 0, 1 }, { "nee_parked", 0, 1 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 2 }, { "overlap_delay_us", 0, 100000 }, { "merged", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 }, { "ray_queues", 0, 1 }, { "nee_parked", 0, 1 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);

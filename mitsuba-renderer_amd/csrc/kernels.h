@@ -327,6 +327,10 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 // is only its upper bound (device-driven bounces: the host never learns the queue sizes)
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
                   const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *n_dev = nullptr);
+// one launch for the closest-hit queue of a bounce (mode 0 with the material sort) and, behind it in the same waves, the any-hit
+// queue of the bounce before (mode 1); host-sized grids only
+void launch_trace_pair(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &qc, const uint32_t *queue_c, uint32_t n_c, bool coherent_c,
+                       const DQueues &qs, const uint32_t *queue_s, uint32_t n_s, bool coherent_s);
 // prefix[s] = number of entries of the bin in segments < s (prefix[kBinShards] = total)
 struct BinView { uint32_t prefix[kBinShards + 1]; };
 // views_dev == NULL: the bin has view.prefix[kBinShards] entries.  Otherwise the view is views_dev[bin] (written by

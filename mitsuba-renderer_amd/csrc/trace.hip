@@ -504,6 +504,29 @@ __global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(MODE)) void k_tra
 	trace_body<MODE, COUNT, BIN>(sc, ps, q, plan, queue, n, first, stride, s_stack, s_mbox, s_top);
 }
 
+// ONE persistent launch per bounce (host-driven bounces, knob "merged"): its waves drain the closest-hit
+// queue of bounce b + 1 and then the any-hit queue of bounce b -- legal because the any-hit kernel only parks direct-light
+// terms, so neither queue depends on the other -- so that the waves that run out of closest-hit rays go on with shadow rays
+// instead of idling through the 0.3-0.7 ms in which the launch's longest rays finish alone.  One footprint: the closest-hit
+// kernel's (80 VGPRs, 52 KB of LDS, 3 workgroups per CU), which the any-hit phase then runs at too (6 waves per SIMD
+// instead of 8, no mailbox).  Each phase deals its queue exactly as the separate launches do (own plan, own counter set).
+__global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(0)) void k_trace_pair(DTraceScene sc, DPaths ps, DQueues qc, DQueues qs,
+                                                                                    const uint32_t *queue_c, uint32_t n_c, const uint32_t *queue_s, uint32_t n_s) {
+	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
+	__shared__ uint32_t s_mbox[8][kTraceBlock];
+	__shared__ uint4 s_top[kTopPairs ? kTopPairs : 1];
+	const TracePlan plan_c = trace_plan(n_c, 0, qc), plan_s = trace_plan(n_s, 1, qs);
+	if (kTopPairs) {
+		for (uint32_t t = threadIdx.x; t < kTopPairs; t += kTraceBlock) s_top[t] = reinterpret_cast<const uint4 *>(sc.nodes)[t];
+		__syncthreads();
+	}
+	const uint32_t wave = blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6);
+	if (blockIdx.x < plan_c.blocks)
+		trace_body<0, false, true>(sc, ps, qc, plan_c, queue_c, n_c, wave * plan_c.batch, plan_c.blocks * (kTraceBlock / 64u) * plan_c.batch, s_stack, s_mbox, s_top);
+	if (blockIdx.x < plan_s.blocks)
+		trace_body<1, false, false>(sc, ps, qs, plan_s, queue_s, n_s, wave * plan_s.batch, plan_s.blocks * (kTraceBlock / 64u) * plan_s.batch, s_stack, s_mbox, s_top);
+}
+
 // Device-driven bounces: the per-bin views k_shade needs, from the shard counters the closest-hit launch left in `cur`
 // (what the host computes from a read-back otherwise), and the counter set of the NEXT bounce cleared.  One workgroup.
 __global__ __launch_bounds__(256) void k_prep(const uint32_t *cur, uint32_t *next_set, BinView *views, uint32_t bin_seg_cap,
@@ -560,6 +583,18 @@ void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &s
 	} else {
 		if (count) launch_trace_t<2, true, false>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<2, false, false>(s, sc, ps, qq, queue, n, n_dev);
 	}
+}
+
+void launch_trace_pair(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &qc, const uint32_t *queue_c, uint32_t n_c, bool coherent_c,
+                       const DQueues &qs, const uint32_t *queue_s, uint32_t n_s, bool coherent_s) {
+	DQueues a = qc, b = qs;
+	a.coherent = coherent_c ? 1u : 0u; b.coherent = coherent_s ? 1u : 0u;
+	// the any-hit phase lives in the closest-hit kernel's footprint: 3 workgroups per CU
+	const uint32_t perCu = trace_blocks_per_cu(0);
+	if (!b.tune_blocks_per_cu || b.tune_blocks_per_cu > perCu) b.tune_blocks_per_cu = perCu;
+	const unsigned blocks = std::max(trace_plan(n_c, 0, a).blocks, trace_plan(n_s, 1, b).blocks);
+	if (!blocks) return;
+	hipLaunchKernelGGL(k_trace_pair, dim3(blocks), dim3(kTraceBlock), 0, s, trace_scene(sc), ps, a, b, queue_c, n_c, queue_s, n_s);
 }
 
 void launch_prep(hipStream_t s, const uint32_t *cur, uint32_t *next_set, BinView *views_dev, uint32_t bin_seg_cap,

@@ -98,3 +98,20 @@ def test_exact_tail_filter_variant_matches_the_oracle(gpu_lib, mts, orc, tmp_pat
     ofilm, _ = orc.render(orc.FlatScene(sd).scene, orc.make_camera(sd, 96, 96),
                           orc.render_params(12, sampler=mts.abi.SAMPLER_LD_KEYED, spp=16, seed=11))
     assert np.array_equal(np.load(out).view(np.uint32), ofilm.view(np.uint32))
+
+
+def test_traversal_launch_orders_do_not_change_the_film(gpu_lib, mts, orc):
+    """host-driven bounces with the any-hit launch of a bounce in front of / behind the next closest-hit launch on a second
+    stream (overlap = 1 / 2) and inside it (merged = 1: k_trace_pair, one launch per bounce; also when that launch is repeated
+    with static dealing): the any-hit kernel only parks direct-light terms, so every order gives the oracle's film"""
+    sd, scene, oscene, cam, ocam, it, op = _setup(mts, orc, "c5_small", W=48, H=40, sampler="ldsampler", spp=16, max_depth=8)
+    ofilm, _ = orc.render(oscene.scene, ocam, op)
+    for knobs in (dict(sync_free=0), dict(sync_free=0, overlap=1), dict(sync_free=0, overlap=2), dict(sync_free=0, overlap=2, overlap_delay_us=20),
+                  dict(sync_free=0, overlap=0, merged=1), dict(sync_free=0, merged=1, test_retry=1)):
+        it.set_tuning(**knobs)
+        it.clear_film(); assert it.render()
+        assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32)), knobs
+    it.set_tuning(sync_free=0, merged=1, test_retry=0)
+    it.set_options(max_paths=16 * 500)                     # ragged passes
+    it.clear_film(); assert it.render()
+    assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32))
