@@ -19,7 +19,8 @@ def sp(tmp_path_factory):
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     so = str(tmp_path_factory.mktemp("harness") / "libstreamharness.so")
-    subprocess.check_call(["g++", "-std=gnu++11", "-O1", "-Wall", "-Werror", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+    # undefined-behaviour checks stay on in the harness (misaligned reads, shifts, overflow: the parsers take bytes as they come)
+    subprocess.check_call(["g++", "-std=gnu++11", "-O1", "-Wall", "-Werror", "-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "integration"), os.path.join(ROOT, "tests", "stream_harness", "harness.cpp"), "-o", so])
     return C.CDLL(so)
 
@@ -28,7 +29,7 @@ def _call(fn, data, prec, *outs):
     msg = C.create_string_buffer(512)
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     rc = fn(buf, C.c_size_t(len(data)), prec, *outs, msg, C.c_size_t(512))
-    return rc, msg.value.decode()
+    return rc, msg.value.decode(errors="replace")
 
 
 def _parse_bsdf(sp, data, prec=4):
@@ -215,3 +216,36 @@ def test_spheres_from_bytes(sp, mts, prec):
     assert n == 8 and (fa["shape_lum"][fa["shape_type"] == mts.abi.SHAPE_SPHERE] >= 0).sum() == 1
     rc, msg, _ = _parse_block(sp, sp.sp_parse_sphere, s.bytes()[:40], mts.abi.SHAPE_NPARAMS, prec)
     assert rc != 0
+
+
+def test_parsers_survive_truncated_and_corrupted_streams(sp, mts):
+    """every prefix of a valid stream and a few hundred corrupted copies: the parsers answer (an error or a block), they never
+    read past the buffer (the harness is built with -fsanitize=undefined; lengths and ids come from the bytes)"""
+    rng = np.random.RandomState(3)
+    sd = mts.scenes.spheres()
+    fa = _flat(mts, sd)
+    streams = []
+    for i, (t, P) in enumerate(zip(fa["bsdf_type"], fa["bsdf_params"])):
+        s = W.Stream(); W.bsdf(s, ("b", i), int(t) & 0xFF, np.array(P, dtype=np.float32), twosided=bool(int(t) & mts.abi.BSDF_TWOSIDED), name="x")
+        streams.append(("bsdf", s.bytes()))
+    w2l, l2w = _rigid(rot=np.eye(3), pos=(0, 1, 0))
+    s = W.Stream(); W.spot(s, "l", w2l, l2w, (1, 1, 1), 0.2, 0.3); streams.append(("spot", s.bytes()))
+    s = W.Stream(); W.envmap(s, "l", w2l, l2w, 1.0, "x.exr", (0, 0, 0, 1), b"\x01" * 64); streams.append(("envmap", s.bytes()))
+    s = W.Stream(); W.sphere(s, "s", np.eye(4), np.eye(4), 1.0, (0, 0, 0), False, bsdf_args=(0, np.full(16, 0.5, dtype=np.float32), False), lum_intensity=(1, 1, 1))
+    streams.append(("sphere", s.bytes()))
+    def run(kind, data):
+        if kind == "bsdf": return _parse_bsdf(sp, data)[0]
+        if kind == "spot": return _parse_block(sp, sp.sp_parse_spot, data, mts.abi.LUM_NPARAMS)[0]
+        if kind == "sphere": return _parse_block(sp, sp.sp_parse_sphere, data, mts.abi.SHAPE_NPARAMS)[0]
+        g = np.zeros(mts.abi.LUM_NPARAMS, dtype=np.float32); off, size = C.c_uint64(0), C.c_uint32(0)
+        return _call(sp.sp_parse_envmap, data, 4, g.ctypes.data_as(C.POINTER(C.c_float)), C.byref(off), C.byref(size))[0]
+    for kind, data in streams:
+        assert run(kind, data) == 0
+        for n in range(1, len(data)):
+            rc = run(kind, data[:n])
+            assert rc != 0 or kind == "sphere"           # a sphere's fields are read from the END: a cut in the middle may still parse
+        for _ in range(60):
+            b = bytearray(data)
+            for _ in range(rng.randint(1, 4)):
+                b[rng.randint(len(b))] = rng.randint(256)
+            run(kind, bytes(b))                          # any answer, no crash
