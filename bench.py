@@ -550,14 +550,14 @@ def main():
         fabric = None
         if fabric_rec and trace_ms > 0:
             fb = fabric_rec.get("fabric_bytes_per_frame")
-            ceil = (fabric_rec.get("random_line_rate_G_per_s") or {}).get("k_g16_150MB")
+            ceil = (fabric_rec.get("random_line_rate_G_per_s") or {}).get("k_sustained_150MB")
             if fb:
                 lines = fb / 128.0 / (trace_ms * 1e-3) / 1e9
                 fabric = {"bytes_per_step": fb, "tb_per_s": fb / (trace_ms * 1e-3) / 1e12, "G_lines_per_s": lines,
                           "random_line_ceiling_G_per_s": ceil, "frac_of_ceiling": lines / ceil if ceil else None,
                           "read_requests_per_ray": (fabric_rec.get("fabric_read_requests_per_frame") or 0) / max(rays, 1) or None,
                           "what": "bytes between the L2s and the Infinity Cache / HBM per step (2 x FETCH_SIZE + WRITE_SIZE, the x2 measured) over the traversal "
-                                  "launches' time; ceiling = random 16-byte gathers on distinct lines of a 150 MB footprint (tools/micro/gather_calib.hip)"}
+                                  "launches' time; ceiling = sustained random 16-byte gathers, eight in flight per lane, on distinct lines of a 150 MB footprint (tools/micro/gather_calib.hip k_sustained)"}
         sh_bytes = shade_algorithmic_bytes(counts)
         sh_achieved = sh_bytes / (shade_ms * 1e-3) / 1e9 if shade_ms > 0 else 0.0
         out = {

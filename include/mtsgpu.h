@@ -225,6 +225,9 @@ typedef struct mtsgpu_stats {
 	/* parts of trace_ms: the closest-hit launch of the first bounce of every pass (camera rays), and all any-hit launches;
 	 * the remaining closest-hit launches are trace_ms - trace_first_ms - trace_shadow_ms */
 	double trace_first_ms, trace_shadow_ms;
+	/* closest-hit rays traced a second time, with the mailbox, because two primitives tied in t on them (the mailbox-free
+	 * closest-hit kernel of host-driven bounces lists them instead of binning them; sahkdtree3.h:130-144, :278-283) */
+	uint64_t rays_redone;
 } mtsgpu_stats;
 
 typedef struct mtsgpu_ctx mtsgpu_ctx;

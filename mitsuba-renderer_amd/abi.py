@@ -63,6 +63,7 @@ class Stats(C.Structure):
         ("req_pair_global", C.c_uint64), ("req_pair_lds", C.c_uint64), ("req_node_global", C.c_uint64), ("req_node_lds", C.c_uint64),
         ("req_tail", C.c_uint64), ("req_spill", C.c_uint64), ("req_head", C.c_uint64),
         ("trace_first_ms", C.c_double), ("trace_shadow_ms", C.c_double),
+        ("rays_redone", C.c_uint64),
     ]
 
     def as_dict(self):

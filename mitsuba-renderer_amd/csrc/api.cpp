@@ -103,7 +103,7 @@ bool samplerHasTables(const mtsgpu_ctx *c) {
 // Device bytes ensurePaths() allocates per path of a pass: the 128-byte record, the shadow ray (3 x 16), the nine material
 // bins sized for the all-in-one-bin case with a quarter of headroom (id 4 + hit 16 bytes per entry), the two next queues
 // (id 4 + ray 32 bytes each) and the shadow queue's ids -- about 480 bytes, 34 GB for the default pass of 72 M paths.
-constexpr size_t kBytesPerPath = kPathSlots * 16 + 3 * 16 + (size_t) (kNumBins * (4 + 16) * 5 / 4) + 2 * (4 + 32) + 4;
+constexpr size_t kBytesPerPath = kPathSlots * 16 + 3 * 16 + (size_t) (kNumBins * (4 + 16) * 5 / 4) + 2 * (4 + 32) + 4 + 4;
 // Paths per pass when the caller set none (mtsgpu_set_options max_paths == 0): 72 M, or what 60 % of the free device memory
 // holds if that is less (the sampler tables, the film and the scene of a later upload need room too)
 uint64_t defaultMaxPaths(mtsgpu_ctx *c) {
@@ -143,6 +143,7 @@ int ensurePaths(mtsgpu_ctx *c, size_t cap) {
 	rc |= devAlloc(c, &c->queueA, cap, o); rc |= devAlloc(c, &c->queueB, cap, o);
 	for (int k = 0; k < 2; ++k) { rc |= devAlloc(c, &c->rayqA[k], cap, o); rc |= devAlloc(c, &c->rayqB[k], cap, o); }
 	rc |= devAlloc(c, &c->q.shadow, cap, o);
+	rc |= devAlloc(c, &c->q.redo, cap, o);          // closest-hit rays on which two primitives tied (k_trace TIE): traced again with the mailbox
 	rc |= devAlloc(c, &c->counterSets, (size_t) kCounterSets * kNumCounters * kCounterStride, o);
 	rc |= devAlloc(c, &c->viewsDev, kNumBins, o);
 	rc |= devAlloc(c, &c->devStats, kNumDevStats, o);
@@ -288,16 +289,36 @@ int traceAndBin(mtsgpu_ctx *c, const uint32_t *queue, uint32_t n, bool coherent,
 		c->q.force_static = attempt ? 1u : 0u;
 		hipEvent_t *ev = c->timeKernels ? nextTraceEvents(c, coherent ? 1 : 0) : nullptr;
 		if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
+		// the closest-hit kernel without the mailbox (k_trace TIE, one more level of the tree in LDS); rays on which two primitives
+		// tied come back in q.redo and go through the kernel with the mailbox
+		const bool tie = tuningOr(c, "mailbox_free", 0) != 0 && !c->countTraversal && !(pairWith && attempt == 0);
 		if (pairWith && attempt == 0 && !c->countTraversal)
 			launch_trace_pair(s, c->dsc, c->paths, c->q, queue, n, coherent, *pairWith->q, pairWith->q->shadow, pairWith->n, pairWith->coherent);
 		else
-			launch_trace(s, 0, c->countTraversal && attempt == 0, true, c->dsc, c->paths, c->q, queue, n, coherent);
+			launch_trace(s, 0, c->countTraversal && attempt == 0, true, c->dsc, c->paths, c->q, queue, n, coherent, nullptr, tie);
 		if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
-		c->q.force_static = 0;
 		HIPCHK(c, hipGetLastError());
 		c->stats.trace_launches++;
-		if (attempt == 0 && afterLaunch) { const int rc2 = afterLaunch(); if (rc2) return rc2; }
-		int rc = readCounters(c); if (rc) return rc;
+		if (attempt == 0 && afterLaunch) { const int rc2 = afterLaunch(); if (rc2) { c->q.force_static = 0; return rc2; } }
+		int rc = readCounters(c); if (rc) { c->q.force_static = 0; return rc; }
+		if (tie) {
+			const uint32_t nRedo = c->hostCounters[kRedoWord];
+			if (nRedo > n) { c->q.force_static = 0; return fail(c, MTSGPU_EHIP, "internal: redo list longer than the queue"); }
+			if (nRedo) {
+				// their rays come from the path records (the list is not in queue order); statically dealt: no segment can overflow
+				DPaths viaRecords = c->paths; viaRecords.rq_o = viaRecords.rq_d = nullptr;
+				c->q.force_static = 1;
+				hipEvent_t *ev2 = c->timeKernels ? nextTraceEvents(c, 0) : nullptr;
+				if (ev2) HIPCHK(c, hipEventRecord(ev2[0], s));
+				launch_trace(s, 0, false, true, c->dsc, viaRecords, c->q, c->q.redo, nRedo, false);
+				if (ev2) HIPCHK(c, hipEventRecord(ev2[1], s));
+				HIPCHK(c, hipGetLastError());
+				c->stats.trace_launches++;
+				c->stats.rays_redone += nRedo;
+				rc = readCounters(c); if (rc) { c->q.force_static = 0; return rc; }
+			}
+		}
+		c->q.force_static = 0;
 		bool overflow = false;
 		for (int b = 0; b < kNumBins; ++b) {
 			uint32_t acc = 0;
@@ -1295,7 +1316,7 @@ int mtsgpu_set_tuning(mtsgpu_ctx *c, const char *key, long value) {
 	if (!c || !key) return fail(c, MTSGPU_EINVAL, "null argument");
 	struct Knob { const char *key; long lo, hi; };
 	static const Knob knobs[] = { { "refill_min", 1, 64 }, { "desc_min", 1, 64 }, { "leaf_min", 1, 64 }, { "batch", 0, 64 },
-	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 2 }, { "overlap_delay_us", 0, 100000 }, { "merged", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 }, { "ray_queues", 0, 1 }, { "nee_parked", 0, 1 } };
+	                              { "dyn_div", 0, 1 << 20 }, { "test_retry", 0, 1 }, { "sync_free", -1, 1 }, { "overlap", 0, 2 }, { "overlap_delay_us", 0, 100000 }, { "merged", 0, 1 }, { "mailbox_free", 0, 1 }, { "chunk", 1, 1024 }, { "blocks_per_cu", 0, (long) kTraceBlocksPerCuMax }, { "plain_below", 0, 1 << 30 }, { "dyn_min_rounds", 0, 1 << 20 }, { "shade_fused", 0, 1 }, { "ray_queues", 0, 1 }, { "nee_parked", 0, 1 } };
 	for (const Knob &k : knobs)
 		if (std::strcmp(k.key, key) == 0) {
 			if (value < k.lo || value > k.hi) return fail(c, MTSGPU_EINVAL, "tuning knob %s: %ld outside [%ld, %ld]", key, value, k.lo, k.hi);

@@ -39,6 +39,13 @@ constexpr int kStackLDS = MG_STACK_LDS;       // stack levels kept in LDS (deepe
 // levels that every other ray visits too, and a vector-memory request costs the CU ~0.5-1 ns per lane where an LDS
 // read costs ~0.05 (profiles/r02_ta_gather_microbench.txt).  0 switches the cache off.
 constexpr uint32_t kTopPairs = MG_TOP_PAIRS;
+// The closest-hit kernel of host-driven bounces runs WITHOUT the hashed mailbox (trace.hip: TIE) and spends the 16 KB on one more
+// level of the tree: 2 048 sibling pairs.  The breadth-first prefix of the device tree covers the larger of the two copies.
+#ifndef MG_TOP_PAIRS_TIE
+#define MG_TOP_PAIRS_TIE (2 * MG_TOP_PAIRS)
+#endif
+constexpr uint32_t kTopPairsTie = MG_TOP_PAIRS_TIE;
+constexpr uint32_t kTopPairsMax = kTopPairsTie > kTopPairs ? kTopPairsTie : kTopPairs;
 constexpr int kSpillLevels = 50 - kStackLDS;      // LDS + spill levels = MTS_KD_MAXDEPTH (48, gkdtree.h:35) + 2
 static_assert(kStackLDS >= 1 && kStackLDS + kSpillLevels >= 48 + 2, "the traversal stack must hold every tree the reference can build");
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
@@ -53,13 +60,13 @@ constexpr int kLumStride = 32;        // MTSGPU_LUM_NPARAMS
 constexpr int kCounterStride = 32;    // one 128-byte line per queue counter (atomics on one line serialise)
 constexpr int kBsdfNParams = 16;      // MTSGPU_BSDF_NPARAMS
 constexpr int kBinShards = 16;        // the closest-hit kernel appends to bins[b] through 16 independent segments
-constexpr int kNumCounters = kNumBins * kBinShards + 4;   // bins x shards, next, shadow, dynamic heads of the two traversal launches
+constexpr int kNumCounters = kNumBins * kBinShards + 5;   // bins x shards, next, shadow, dynamic heads of the two traversal launches, redo list
 // Two sets of counters, used by alternate bounces: the shadow rays of bounce b are traced (second stream) while the
 // closest-hit launch of bounce b + 1 already fills the next set
 constexpr int kCounterSets = 2;
-constexpr int kCntNext = kNumBins * kBinShards, kCntShadow = kCntNext + 1, kCntDynClosest = kCntNext + 2, kCntDynShadow = kCntNext + 3;
+constexpr int kCntNext = kNumBins * kBinShards, kCntShadow = kCntNext + 1, kCntDynClosest = kCntNext + 2, kCntDynShadow = kCntNext + 3, kCntRedo = kCntNext + 4;
 // word offsets of the two queue counters of k_shade inside a counter set (one 128-byte line each)
-constexpr int kNextWord = kCntNext * kCounterStride, kShadowWord = kCntShadow * kCounterStride;
+constexpr int kNextWord = kCntNext * kCounterStride, kShadowWord = kCntShadow * kCounterStride, kRedoWord = kCntRedo * kCounterStride;
 #ifndef MG_SHADE_BLOCK
 #define MG_SHADE_BLOCK 1024     // 512: two atomics-bound milliseconds more per 64-spp frame (one reservation per workgroup)
 #endif
@@ -215,6 +222,10 @@ struct DQueues {
 	__host__ __device__ uint32_t *bin(int b) const { return bins_base + (size_t) b * bin_stride; }
 	uint32_t *next;               // paths that continue (input of the next closest-hit launch)
 	uint32_t *shadow;             // paths with a pending shadow ray
+	// closest-hit launches without the mailbox (trace.hip: TIE): the path ids of rays on which two primitives tied in t -- the one
+	// case in which the mailbox decides the result (sahkdtree3.h:130-144, :278-283); they are not binned but traced again by the
+	// kernel with the mailbox.  Count in counters[kCntRedo]
+	uint32_t *redo;
 	uint32_t *counters;           // the counter set of this bounce, [i * kCounterStride]: i = b * kBinShards + shard for the bins, then kCnt*
 	// counting builds (u64 x kNumTraceCounts): n_inner, n_leaf, n_idx, n_tri_tested, the lane slots of the three loops and of
 	// the batches, then the vector-memory requests the kernel ISSUED: sibling pairs from global memory / from the LDS copy,
@@ -325,8 +336,9 @@ void launch_generate(hipStream_t s, const DScene &sc, const DPaths &ps, const DC
 // mode 2: any-hit over ps.ray_* (writes ps.hit.w = occluded) -- test/benchmark API
 // n_dev == NULL: n rays, grid sized for them.  n_dev != NULL: the count is read from device memory by the kernel and n
 // is only its upper bound (device-driven bounces: the host never learns the queue sizes)
+// tie: (mode 0 with bin, no counting) the mailbox-free kernel that lists tied rays in q.redo instead of binning them
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
-                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *n_dev = nullptr);
+                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *n_dev = nullptr, bool tie = false);
 // one launch for the closest-hit queue of a bounce (mode 0 with the material sort) and, behind it in the same waves, the any-hit
 // queue of the bounce before (mode 1); host-sized grids only
 void launch_trace_pair(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &qc, const uint32_t *queue_c, uint32_t n_c, bool coherent_c,

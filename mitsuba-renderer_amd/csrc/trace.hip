@@ -27,10 +27,13 @@ namespace mg {
 #ifndef MG_TAIL_FILTER
 #define MG_TAIL_FILTER 0
 #endif
+#ifndef MG_EXP_EXTRA_MISS
+#define MG_EXP_EXTRA_MISS 0
+#endif
 size_t trace_spill_levels() { return kSpillLevels; }      // in dwords per thread
 int trace_tail_filter() { return MG_TAIL_FILTER; }          // 0: the kernels were built without the record-tail filter (the default), 1: both kernels, 2: any-hit only
 size_t trace_stack_levels() { return kStackLDS + kSpillLevels; }
-uint32_t trace_top_nodes() { return 2u * kTopPairs; }
+uint32_t trace_top_nodes() { return 2u * kTopPairsMax; }
 
 // Persistent waves: the grid is sized to fill the chip once and every wave walks its own 64-ray
 // batches of the queue with a private cursor (no work-queue atomic: a single head word saturates at
@@ -46,7 +49,7 @@ uint32_t trace_top_nodes() { return 2u * kTopPairs; }
 __device__ __forceinline__ const uint4 *leaf_head(const DTraceScene &sc, uint32_t e) { return &sc.leaf_ta[kLeafStride * (size_t) e]; }
 __device__ __forceinline__ const uint4 *leaf_tail(const DTraceScene &sc, uint32_t e, uint32_t half) { return &sc.leaf_ta[kLeafStride * (size_t) e + 1 + half]; }
 
-template <int MODE, bool COUNT, bool BIN>
+template <int MODE, bool COUNT, bool BIN, bool TIE = false>
 __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &ps, const DQueues &q, const TracePlan &plan,
                                            const uint32_t *queue, uint32_t n, const uint32_t first, const uint32_t stride,
                                            uint32_t (*s_stack)[kTraceBlock], uint32_t (*s_mbox)[kTraceBlock], const uint4 *s_top) {
@@ -60,13 +63,14 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 			rec_n++;
 		}
 	};
+	constexpr uint32_t kTop = TIE ? kTopPairsTie : kTopPairs;      // sibling pairs of the LDS copy this instantiation was given
 	auto load_node = [&](uint32_t i) -> uint2 {
-		if (kTopPairs && i < 2u * kTopPairs) { if (COUNT) l_node++; return reinterpret_cast<const uint2 *>(s_top)[i]; }
+		if (kTop && i < 2u * kTop) { if (COUNT) l_node++; return reinterpret_cast<const uint2 *>(s_top)[i]; }
 		if (COUNT) { g_node++; rec_add(kReqNode, i); }
 		return sc.nodes[i];
 	};
 	auto load_pair = [&](uint32_t left) -> uint4 {
-		if (kTopPairs && left < 2u * kTopPairs) { if (COUNT) l_pair++; return s_top[left >> 1]; }
+		if (kTop && left < 2u * kTop) { if (COUNT) l_pair++; return s_top[left >> 1]; }
 		if (COUNT) { g_pair++; rec_add(kReqPair, left >> 1); }
 		return reinterpret_cast<const uint4 *>(sc.nodes)[left >> 1];
 	};
@@ -74,7 +78,13 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 	// closest-hit rays keep it.  For any-hit rays it only saves repeated tests of a primitive that spans several leaves --
 	// the answer is a disjunction over the same primitives either way -- and its 8 dwords per lane are better spent on
 	// the LDS copy of the tree: the shadow kernels run without it (counting builds keep it: the oracle counts with it).
-	constexpr bool kMbox = MODE == 0 || COUNT;
+	// TIE: closest-hit rays WITHOUT the mailbox.  Skipping a primitive that was tested before only saves work -- its test gives the
+	// same answer again (rejected: the interval has only shrunk; accepted before and still the best: t == maxt is accepted again and
+	// changes nothing) -- EXCEPT when two different primitives tie in t: then the later test wins and which tests run depends on the
+	// mailbox's eight hashed slots.  Such a ray (an accepted hit with t == best_t on another primitive) is flagged, listed in q.redo
+	// instead of being binned, and traced again by the kernel with the mailbox; everything else is bit-identical by the argument above.
+	static_assert(!TIE || (MODE == 0 && BIN && !COUNT), "the mailbox-free form exists for binned closest-hit launches");
+	constexpr bool kMbox = (MODE == 0 && !TIE) || COUNT;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t gtid = blockIdx.x * kTraceBlock + tid;     // spill slot of this lane
 	const uint32_t lane = lane_id();
@@ -146,7 +156,12 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 					if (BIN) {
 						bin = kNumBins - 1;
 						if (found) {
-							bin = (int) sc.shape_bin[best_shape];      // BSDF type of the hit shape, or the terminal bin (one lookup)
+							bin = (int) sc.shape_bin[TIE ? (best_shape & 0x7FFFFFFFu) : best_shape];      // BSDF type of the hit shape, or the terminal bin (one lookup)
+						}
+						if (TIE && (best_shape & 0x80000000u)) {
+							// two primitives tied on this ray: the mailbox decides (rare: coincident geometry, hits on shared edges)
+							q.redo[atomicAdd(&q.counters[kCntRedo * kCounterStride], 1u)] = id;
+							bin = -1;
 						}
 					}
 				}
@@ -326,6 +341,18 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 				if (COUNT && e_cont == kNoPrim) c_leaf++;      // a resumed leaf was counted already
 				MG_WSLOT(w_outer);
 				bool hitShadow = false, more = false;
+#if MG_EXP_EXTRA_MISS
+				// sensitivity probe (profiles/r06n_*): ONE more 16-byte request per leaf visit whose line is not in the L2 -- a pseudo-random
+				// line of the path records, inside a 128 MB window (1: served by the Infinity Cache) or anywhere in 8 GB of them (2: from HBM);
+				// the value is not used
+				if (e_cont == kNoPrim) {
+					uint32_t hsh = (id * 0x9E3779B9u) ^ (nd.x * 0x85EBCA6Bu); hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12;
+					const uint32_t lines = MG_EXP_EXTRA_MISS == 1 ? (1u << 20) : (1u << 26);
+					// 3: the same request to a line that IS in the L2 (the first 256 KB of the node array): what the request itself costs
+					const float4 probe = MG_EXP_EXTRA_MISS == 3 ? reinterpret_cast<const float4 *>(sc.nodes)[(hsh & 0x3FFFu) * 1u] : ps.base[(size_t) (hsh & (lines - 1u)) * 8u];
+					if (__float_as_uint(probe.x) == 0xDEADBEEFu && __float_as_uint(probe.w) == 0x12345u) best_u = 0.0f;
+				}
+#endif
 				{
 #if MG_TAIL_FILTER
 					// The face through which the ray leaves this leaf: the plane of the current exit point (sahkdtree3.h:233,248-249) on its
@@ -379,9 +406,10 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 							} else {
 								float ts;
 								if (sphere_intersect(ctr, rad, V3(ox, oy, oz), V3(dx, dy, dz), mint, maxt, ts)) {
+									const uint32_t tied = TIE ? ((ts == best_t && prim != best_prim) ? 0x80000000u : (best_shape & 0x80000000u)) : 0u;
 									maxt = ts;
 									best_t = ts; best_u = 0.0f; best_v = 0.0f; best_prim = prim;
-									best_shape = leaf_tail(sc, e, 1)->z;
+									best_shape = leaf_tail(sc, e, 1)->z | tied;
 								}
 							}
 						}
@@ -412,8 +440,9 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 							const float v = hu * c_nu + hv * c_nv;
 							if (u >= 0 && v >= 0 && u + v <= 1.0f) {
 								if (MODE != 0) hitShadow = true;
+								const uint32_t tied = TIE ? ((t == best_t && prim != best_prim) ? 0x80000000u : (best_shape & 0x80000000u)) : 0u;
 								maxt = t;      // a later hit with equal t replaces this one (t > maxt rejects)
-								best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = C.z;
+								best_t = t; best_u = u; best_v = v; best_prim = prim; best_shape = C.z | tied;
 							}
 						}
 						if (kMbox) *mslot = prim;         // (re)writing an entry that is already there changes nothing
@@ -479,12 +508,13 @@ __device__ __forceinline__ void trace_body(const DTraceScene &sc, const DPaths &
 	}
 }
 
-template <int MODE, bool COUNT, bool BIN>
+template <int MODE, bool COUNT, bool BIN, bool TIE = false>
 __global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(MODE)) void k_trace(DTraceScene sc, DPaths ps, DQueues q,
                                                           const uint32_t *queue, uint32_t n_host, const uint32_t *n_dev) {
+	constexpr uint32_t kTop = TIE ? kTopPairsTie : kTopPairs;
 	__shared__ uint32_t s_stack[kStackLDS][kTraceBlock];
-	__shared__ uint32_t s_mbox[(MODE == 0 || COUNT) ? 8 : 1][kTraceBlock];
-	__shared__ uint4 s_top[kTopPairs ? kTopPairs : 1];
+	__shared__ uint32_t s_mbox[((MODE == 0 && !TIE) || COUNT) ? 8 : 1][kTraceBlock];
+	__shared__ uint4 s_top[kTop ? kTop : 1];
 	// the number of rays: known to the host, or left in device memory by the kernel that filled the queue
 	const uint32_t n = n_dev ? (uint32_t) __builtin_amdgcn_readfirstlane((int) *n_dev) : n_host;
 	const TracePlan plan = trace_plan(n, MODE, q);
@@ -496,12 +526,12 @@ __global__ __launch_bounds__(kTraceBlock, trace_waves_per_simd(MODE)) void k_tra
 	}
 	const uint32_t first = (blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6)) * plan.batch;
 	const uint32_t stride = plan.blocks * (kTraceBlock / 64u) * plan.batch;      // queue entries per round of the grid
-	if (kTopPairs) {
-		// the device tree is padded to at least 2 * kTopPairs nodes (mtsgpu_upload_scene)
-		for (uint32_t t = threadIdx.x; t < kTopPairs; t += kTraceBlock) s_top[t] = reinterpret_cast<const uint4 *>(sc.nodes)[t];
+	if (kTop) {
+		// the device tree is padded to at least 2 * kTopPairsMax nodes (mtsgpu_upload_scene)
+		for (uint32_t t = threadIdx.x; t < kTop; t += kTraceBlock) s_top[t] = reinterpret_cast<const uint4 *>(sc.nodes)[t];
 		__syncthreads();
 	}
-	trace_body<MODE, COUNT, BIN>(sc, ps, q, plan, queue, n, first, stride, s_stack, s_mbox, s_top);
+	trace_body<MODE, COUNT, BIN, TIE>(sc, ps, q, plan, queue, n, first, stride, s_stack, s_mbox, s_top);
 }
 
 // ONE persistent launch per bounce (host-driven bounces, knob "merged"): its waves drain the closest-hit
@@ -551,7 +581,7 @@ __global__ __launch_bounds__(256) void k_prep(const uint32_t *cur, uint32_t *nex
 	}
 }
 
-template <int MODE, bool COUNT, bool BIN>
+template <int MODE, bool COUNT, bool BIN, bool TIE = false>
 static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, const DQueues &q, const uint32_t *queue, uint32_t n,
                            const uint32_t *n_dev) {
 	// persistent grid: enough workgroups to fill every CU, never more than there are rays (trace_plan); when only the
@@ -565,18 +595,18 @@ static void launch_trace_t(hipStream_t s, const DScene &sc, const DPaths &ps, co
 		blocks = std::min<unsigned>(blocks_for(n, minBatch * (kTraceBlock / 64)), q.n_cus * perCu);
 	}
 	if (!blocks) return;
-	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN>), dim3(blocks), dim3(kTraceBlock), 0, s, trace_scene(sc), ps, q, queue, n, n_dev);
+	hipLaunchKernelGGL((k_trace<MODE, COUNT, BIN, TIE>), dim3(blocks), dim3(kTraceBlock), 0, s, trace_scene(sc), ps, q, queue, n, n_dev);
 }
 
 void launch_trace(hipStream_t s, int mode, bool count, bool bin, const DScene &sc, const DPaths &ps,
-                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *n_dev) {
+                  const DQueues &q, const uint32_t *queue, uint32_t n, bool coherent, const uint32_t *n_dev, bool tie) {
 	if (!n) return;
 	DQueues qq = q;
 	qq.coherent = coherent ? 1u : 0u;
 	if (n_dev)
 		qq.force_static = 1u;        // no dynamically claimed batches: the material-queue segments cannot overflow then
 	if (mode == 0) {
-		if (bin) { if (count) launch_trace_t<0, true, true>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<0, false, true>(s, sc, ps, qq, queue, n, n_dev); }
+		if (bin) { if (count) launch_trace_t<0, true, true>(s, sc, ps, qq, queue, n, n_dev); else if (tie) launch_trace_t<0, false, true, true>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<0, false, true>(s, sc, ps, qq, queue, n, n_dev); }
 		else     { if (count) launch_trace_t<0, true, false>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<0, false, false>(s, sc, ps, qq, queue, n, n_dev); }
 	} else if (mode == 1) {
 		if (count) launch_trace_t<1, true, false>(s, sc, ps, qq, queue, n, n_dev); else launch_trace_t<1, false, false>(s, sc, ps, qq, queue, n, n_dev);

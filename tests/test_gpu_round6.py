@@ -95,7 +95,8 @@ def test_exact_tail_filter_variant_matches_the_oracle(gpu_lib, mts, orc, tmp_pat
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     sd = mts.scenes.cornell_c5(sphere_subdiv=3)
-    ofilm, _ = orc.render(orc.FlatScene(sd).scene, orc.make_camera(sd, 96, 96),
+    oscene = orc.FlatScene(sd)                              # kept alive: the oracle's scene lives as long as this object
+    ofilm, _ = orc.render(oscene.scene, orc.make_camera(sd, 96, 96),
                           orc.render_params(12, sampler=mts.abi.SAMPLER_LD_KEYED, spp=16, seed=11))
     assert np.array_equal(np.load(out).view(np.uint32), ofilm.view(np.uint32))
 
@@ -115,3 +116,43 @@ def test_traversal_launch_orders_do_not_change_the_film(gpu_lib, mts, orc):
     it.set_options(max_paths=16 * 500)                     # ragged passes
     it.clear_film(); assert it.render()
     assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32))
+
+
+def test_closest_hit_without_the_mailbox_hands_ties_back(gpu_lib, mts, orc):
+    """host-driven bounces trace closest hits WITHOUT the hashed mailbox (one more level of the tree in its LDS instead); the one
+    case in which the mailbox decides a result -- two primitives tied in t: the later test wins, and which tests run depends on
+    the mailbox (sahkdtree3.h:130-144, :278-283) -- is detected per ray and traced again by the kernel with the mailbox.  A box whose
+    every wall exists twice, with different reflectances, makes every hit a tie: the film equals the oracle's bit for bit, with the
+    knob on and off, and the statistics show the rays that went back"""
+    S = mts.scenes
+    sd = S.SceneDescription("tied_walls")
+    a, b = sd.lambertian(0.7, 0.2, 0.2), sd.lambertian(0.2, 0.7, 0.2)
+    for name, p0, e1, e2, nrm in S._box_faces():
+        pos, tri = S._quad(p0, e1, e2, nrm)
+        sd.add_mesh(pos, tri, bsdf=a, face_normals=True, name=name)
+        sd.add_mesh(pos.copy(), tri.copy(), bsdf=b, face_normals=True, name=name + "_again")
+    pos, tri = S.icosphere(2, 0.35, (0.1, 0.45, 0.0))
+    sd.add_mesh(pos, tri, bsdf=sd.dielectric(), face_normals=False, name="glass")
+    S._add_light(sd)
+    sd.max_depth = 6
+    W, H, spp = 48, 40, 16
+    scene = mts.Scene(sd); oscene = orc.FlatScene(sd)
+    cam = mts.PerspectiveCamera.for_description(sd, W, H); ocam = orc.make_camera(sd, W, H)
+    ofilm, _ = orc.render(oscene.scene, ocam, orc.render_params(6, sampler=mts.abi.SAMPLER_LD_KEYED, spp=spp, seed=5))
+    it = mts.MIPathTracer(maxDepth=6)
+    it.preprocess(scene, cam, sampler="ldsampler", sampleCount=spp, seed=5)
+    redone = {}
+    for knobs in (dict(sync_free=0, mailbox_free=1), dict(sync_free=0, mailbox_free=0), dict(sync_free=0, mailbox_free=1, test_retry=1),
+                  dict(sync_free=1, mailbox_free=1, test_retry=0)):
+        it.set_tuning(**knobs)
+        it.clear_film(); assert it.render()
+        assert np.array_equal(it.film().view(np.uint32), ofilm.view(np.uint32)), knobs
+        redone[tuple(sorted(knobs.items()))] = it.stats()["rays_redone"]
+    vals = list(redone.values())
+    assert vals[0] > 0.3 * it.stats()["rays_closest"] and vals[1] == 0 and vals[3] == 0, redone      # device-driven bounces keep the mailbox
+    # an ordinary scene hands back next to nothing
+    sd2, scene2, oscene2, cam2, ocam2, it2, op2 = _setup(mts, orc, "c5_small", W=48, H=40, sampler="ldsampler", spp=16, max_depth=8)
+    it2.set_tuning(sync_free=0, mailbox_free=1)
+    assert it2.render()
+    assert np.array_equal(it2.film().view(np.uint32), orc.render(oscene2.scene, ocam2, op2)[0].view(np.uint32))
+    assert it2.stats()["rays_redone"] < 1e-3 * it2.stats()["rays_closest"]

@@ -41,6 +41,11 @@ try:
         calib["%s_%dMB" % (e["shape"], e["footprint_mb"])] = e["lines_per_ns"]
 except Exception:
     pass
+# ... and the SUSTAINED rate (k_sustained of the same benchmark: the one-load-per-thread launches above are ramp-up limited)
+try:
+    calib.update(json.load(open(os.path.join(ROOT, "profiles", "r06n_sustained_line_rate.json")))["G_lines_per_s"])
+except Exception:
+    pass
 out = {
     "workload": {"grid": 320, "res": 1024, "spp": 64},
     "kernel_source_hash": bench.kernel_source_hash(),

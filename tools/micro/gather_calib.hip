@@ -52,6 +52,23 @@ __global__ __launch_bounds__(256) void k_stream(const uint4 *base, unsigned long
 	const uint4 v = base[i];
 	if ((v.x ^ v.y ^ v.z ^ v.w) == 0xDEADBEEFu) sink[0] = v.x;
 }
+// The SUSTAINED line rate: the launches above are over in 6-350 us (one load per thread), their rates are ramp-up limited.  Here a
+// chip-filling grid keeps eight independent 16-byte gathers per lane in flight for `iters` rounds over distinct random lines of the
+// footprint (line = hash(i) mod n_lines; with 2^k lines and an odd multiplier every line is equally likely, repeats are rare and
+// far apart): the rate the L2-miss path sustains for random lines.
+__global__ __launch_bounds__(256) void k_sustained(const uint4 *base, unsigned long long n_lines, int iters, uint32_t *sink) {
+	unsigned long long i = ((unsigned long long) blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+	uint32_t acc = 0;
+	for (int it = 0; it < iters; ++it) {
+		uint4 v[8];
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) { i = i * 6364136223846793005ull + 1442695040888963407ull; v[k] = base[((i >> 20) % n_lines) * 8ull + (i & 7ull)]; }
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) acc ^= v[k].x ^ v[k].w;
+	}
+	if (acc == 0xDEADBEEFu) sink[0] = acc;
+}
+
 // evicts the caches between launch groups: a 1 GiB stream through another buffer
 __global__ __launch_bounds__(256) void k_flush(uint4 *p, unsigned long long n16) {
 	const unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,6 +117,22 @@ int main() {
 			printf("%s %llu %llu %llu %llu %llu %llu %.4f %.4f %.3f\n", names[shape], bytes >> 20, units, lines, lines * 128ull,
 			       shape == 3 ? lines * 128ull : sect64 * 64ull, shape == 3 ? lines * 128ull : sect32 * 32ull, msFirst, msRest, lines / (msRest * 1e6));
 		}
+	}
+	// sustained random-line rates (see k_sustained): 256 CUs x 8 workgroups of 256 lanes, 8 x iters gathers per lane
+	printf("sustained random 16-byte gathers, 8 in flight per lane, 2048 workgroups of 256:\n");
+	for (int f = 0; f < 3; ++f) {
+		const unsigned long long nLines = footprints[f] / 128ull;
+		const int iters = 64;
+		hipLaunchKernelGGL(k_flush, dim3((unsigned) ((1ull << 26) / 256ull)), dim3(256), 0, 0, flush, 1ull << 26);
+		float best = 1e30f;
+		for (int rep = 0; rep < 3; ++rep) {
+			CHECK(hipEventRecord(e0));
+			hipLaunchKernelGGL(k_sustained, dim3(2048), dim3(256), 0, 0, buf, nLines, iters, sink);
+			CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+			float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+		}
+		const double loads = 2048.0 * 256.0 * 8.0 * iters;
+		printf("k_sustained %llu MB: %.3f ms for %.0f line requests = %.2f G lines/s = %.2f TB/s in 128-byte lines\n", footprints[f] >> 20, best, loads, loads / (best * 1e6), loads * 128.0 / (best * 1e-3) / 1e12);
 	}
 	return 0;
 }
