@@ -39,14 +39,15 @@ for seed in range(first, first + count):
     # (one read-back per bounce, exact grids, dynamically claimed batches, one shading launch per BSDF type), 2 the host over
     # several ragged passes, 3 device-driven with one shading launch per BSDF type
     # 4 / 5 (round 6): the host with the any-hit launch of a bounce BEHIND / in front of the next closest-hit launch on a second stream
-    # 6: the host with ONE traversal launch per bounce (k_trace_pair)
-    drive = (seed // 5) % 7
+    # 6: the host with ONE traversal launch per bounce (k_trace_pair); 7: the host with the mailbox-free closest-hit kernel (tied rays traced again)
+    drive = (seed // 5) % 8
     if drive == 1: it.set_tuning(sync_free=0)
     elif drive == 2: it.set_tuning(sync_free=0); it.set_options(max_paths=spp * (W * H // 3 + 1))
     elif drive == 3: it.set_tuning(sync_free=1, shade_fused=0)
     elif drive == 4: it.set_tuning(sync_free=0, overlap=2)
     elif drive == 5: it.set_tuning(sync_free=0, overlap=1); it.set_options(max_paths=spp * (W * H // 2 + 1))
     elif drive == 6: it.set_tuning(sync_free=0, merged=1)
+    elif drive == 7: it.set_tuning(sync_free=0, mailbox_free=1)
     assert it.render()
     film = it.film()
     ofilm, _ = orc.render(oscene.scene, ocam, op)
